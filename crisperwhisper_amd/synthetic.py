@@ -1,0 +1,235 @@
+"""Synthetic vocabulary / configuration / weights for offline runs.
+
+The real ``nyrahealth/CrisperWhisper`` checkpoint and tokenizer are not available offline
+(SURVEY.md section 8c), so benchmarks and parity tests run on a *synthetic* byte-level
+vocabulary and seeded random weights of the requested geometry.  Nothing in here touches
+``transformers``; the HF-object builders that mirror this layout live in
+``tests/golden/hf_synth.py`` and are only used to produce/validate golden fixtures.
+
+Vocabulary layout (mirrors the probe described in SURVEY.md section 8c):
+
+    0..255                      byte-level tokens (GPT-2 ``bytes_to_unicode`` alphabet)
+    256..256+n_extra-1          optional synthetic "word" tokens (large geometry only)
+    eos = 256+n_extra           <|endoftext|>  (also pad / bos / unk)
+    eos+1                       <|startoftranscript|>
+    eos+2 .. eos+1+n_lang       language tags
+    then                        <|translate|> <|transcribe|> <|startoflm|> <|startofprev|>
+                                <|nospeech|> <|notimestamps|>
+    timestamp_begin ..          <|0.00|> .. <|30.00|>   (1501 tokens)
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+SYNTH_LANGS = ("en", "zh", "de", "es")  # first four keys of Whisper's LANGUAGES table
+
+
+def bytes_to_unicode() -> Dict[int, str]:
+    """GPT-2 byte -> printable unicode map (public algorithm, restated)."""
+    keep = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+    chars = keep[:]
+    extra = 0
+    for b in range(256):
+        if b not in keep:
+            keep.append(b)
+            chars.append(256 + extra)
+            extra += 1
+    return {b: chr(c) for b, c in zip(keep, chars)}
+
+
+@dataclasses.dataclass
+class SynthVocab:
+    n_extra: int = 0
+
+    @property
+    def eos(self) -> int:
+        return 256 + self.n_extra
+
+    @property
+    def sot(self) -> int:
+        return self.eos + 1
+
+    def lang_id(self, lang: str) -> int:
+        return self.sot + 1 + SYNTH_LANGS.index(lang)
+
+    @property
+    def translate(self) -> int:
+        return self.sot + 1 + len(SYNTH_LANGS)
+
+    @property
+    def transcribe(self) -> int:
+        return self.translate + 1
+
+    @property
+    def startoflm(self) -> int:
+        return self.translate + 2
+
+    @property
+    def startofprev(self) -> int:
+        return self.translate + 3
+
+    @property
+    def nospeech(self) -> int:
+        return self.translate + 4
+
+    @property
+    def notimestamps(self) -> int:
+        return self.translate + 5
+
+    @property
+    def timestamp_begin(self) -> int:
+        return self.notimestamps + 1
+
+    @property
+    def size(self) -> int:
+        return self.timestamp_begin + 1501
+
+    def extra_token_bytes(self, i: int) -> bytes:
+        """Synthetic multi-byte tokens: two thirds start a new word (leading space)."""
+        word = f"w{i:x}".encode()
+        return (b" " + word) if (i % 3) != 2 else word
+
+    def token_bytes(self) -> List[Optional[bytes]]:
+        """id -> raw bytes for text tokens, None for special / timestamp tokens."""
+        out: List[Optional[bytes]] = [bytes([b]) for b in range(256)]
+        out += [self.extra_token_bytes(i) for i in range(self.n_extra)]
+        out += [None] * (self.size - len(out))
+        return out
+
+    def special_names(self) -> List[str]:
+        return (["<|endoftext|>", "<|startoftranscript|>"] + [f"<|{l}|>" for l in SYNTH_LANGS]
+                + ["<|translate|>", "<|transcribe|>", "<|startoflm|>", "<|startofprev|>",
+                   "<|nospeech|>", "<|notimestamps|>"])
+
+    def suppress_tokens(self) -> List[int]:
+        """Mimics Whisper's non-speech/special suppress list: a few punctuation bytes +
+        every special except eos.  The penultimate entry is <|startofprev|> like upstream."""
+        punct = [ord(c) for c in "#()*<=>@[\\]^_`{|}~"]
+        specials = [self.sot] + [self.lang_id(l) for l in SYNTH_LANGS] + [
+            self.translate, self.transcribe, self.startoflm, self.nospeech, self.startofprev,
+            self.notimestamps]
+        return sorted(punct) + specials
+
+    def begin_suppress_tokens(self) -> List[int]:
+        return [ord(" "), self.eos]
+
+
+@dataclasses.dataclass
+class Geometry:
+    d_model: int = 1280
+    heads: int = 20
+    ffn: int = 5120
+    enc_layers: int = 32
+    dec_layers: int = 32
+    n_mels: int = 128
+    vocab: int = 51866
+    max_source_positions: int = 1500
+    max_target_positions: int = 448
+    median_filter_width: int = 7
+
+
+def large_v3_geometry() -> Tuple[Geometry, SynthVocab]:
+    # large-v3: vocab 51866 = 50257 text + 1 eos ... ; we keep the total and derive n_extra.
+    v = SynthVocab(n_extra=0)
+    n_extra = 51866 - v.size
+    v = SynthVocab(n_extra=n_extra)
+    assert v.size == 51866
+    return Geometry(), v
+
+
+def tiny_geometry() -> Tuple[Geometry, SynthVocab]:
+    v = SynthVocab(n_extra=0)
+    return Geometry(d_model=128, heads=2, ffn=256, enc_layers=2, dec_layers=2, n_mels=128,
+                    vocab=v.size), v
+
+
+def alignment_heads(geom: Geometry, n: int = 15) -> List[List[int]]:
+    """Deterministic synthetic alignment heads spread over the upper decoder layers."""
+    out = []
+    lo = geom.dec_layers // 2
+    i = 0
+    while len(out) < min(n, (geom.dec_layers - lo) * geom.heads):
+        layer = lo + (i * 7) % (geom.dec_layers - lo)
+        head = (i * 3 + layer) % geom.heads
+        if [layer, head] not in out:
+            out.append([layer, head])
+        i += 1
+    return out
+
+
+def weight_shapes(g: Geometry) -> Dict[str, Tuple[int, ...]]:
+    """HF ``WhisperForConditionalGeneration.state_dict()`` names -> shapes
+    (TF/models/whisper/modeling_whisper.py:526-570, 660-686; proj_out tied :965)."""
+    d, f = g.d_model, g.ffn
+    s: Dict[str, Tuple[int, ...]] = {
+        "model.encoder.conv1.weight": (d, g.n_mels, 3), "model.encoder.conv1.bias": (d,),
+        "model.encoder.conv2.weight": (d, d, 3), "model.encoder.conv2.bias": (d,),
+        "model.encoder.embed_positions.weight": (g.max_source_positions, d),
+        "model.encoder.layer_norm.weight": (d,), "model.encoder.layer_norm.bias": (d,),
+        "model.decoder.embed_tokens.weight": (g.vocab, d),
+        "model.decoder.embed_positions.weight": (g.max_target_positions, d),
+        "model.decoder.layer_norm.weight": (d,), "model.decoder.layer_norm.bias": (d,),
+    }
+
+    def attn(p):
+        s[p + ".q_proj.weight"] = (d, d); s[p + ".q_proj.bias"] = (d,)
+        s[p + ".k_proj.weight"] = (d, d)
+        s[p + ".v_proj.weight"] = (d, d); s[p + ".v_proj.bias"] = (d,)
+        s[p + ".out_proj.weight"] = (d, d); s[p + ".out_proj.bias"] = (d,)
+
+    def ln(p):
+        s[p + ".weight"] = (d,); s[p + ".bias"] = (d,)
+
+    def mlp(p):
+        s[p + ".fc1.weight"] = (f, d); s[p + ".fc1.bias"] = (f,)
+        s[p + ".fc2.weight"] = (d, f); s[p + ".fc2.bias"] = (d,)
+
+    for i in range(g.enc_layers):
+        p = f"model.encoder.layers.{i}"
+        attn(p + ".self_attn"); ln(p + ".self_attn_layer_norm"); mlp(p); ln(p + ".final_layer_norm")
+    for i in range(g.dec_layers):
+        p = f"model.decoder.layers.{i}"
+        attn(p + ".self_attn"); ln(p + ".self_attn_layer_norm")
+        attn(p + ".encoder_attn"); ln(p + ".encoder_attn_layer_norm")
+        mlp(p); ln(p + ".final_layer_norm")
+    return s
+
+
+def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.ndarray:
+    """Frozen encoder position table (TF/models/whisper/modeling_whisper.py:55-64)."""
+    inc = np.log(max_timescale) / (channels // 2 - 1)
+    inv = np.exp(-inc * np.arange(channels // 2, dtype=np.float64)).astype(np.float32)
+    t = np.arange(length, dtype=np.float32)[:, None] * inv[None, :]
+    return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
+
+
+def random_weights(g: Geometry, seed: int = 0, gain: float = 1.0, dtype=np.float32) -> Dict[str, np.ndarray]:
+    """Seeded random weights with fan-in scaling so activations stay O(1) through the stack and
+    logits / attention rows are *not* near-uniform (HF's N(0, 0.02) init makes a random model
+    degenerate, which would hide argmax / softmax bugs).  numpy's Generator stream is stable, so
+    the golden generator and the GPU-side tests rebuild identical tensors from the seed."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in weight_shapes(g).items():
+        if name == "model.encoder.embed_positions.weight":
+            out[name] = sinusoids(*shape)
+            continue
+        if name.endswith("layer_norm.weight"):
+            w = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith(".bias"):
+            w = 0.1 * rng.standard_normal(shape)
+        elif name == "model.decoder.embed_tokens.weight":
+            w = rng.standard_normal(shape) * (2.0 * gain / np.sqrt(shape[1]))
+        elif name == "model.decoder.embed_positions.weight":
+            w = rng.standard_normal(shape) * 0.1
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            s = gain / np.sqrt(fan_in)
+            if ".q_proj." in name or ".k_proj." in name:
+                s *= 2.0  # sharper attention rows
+            w = rng.standard_normal(shape) * s
+        out[name] = w.astype(dtype)
+    return out
