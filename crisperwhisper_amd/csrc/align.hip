@@ -1,0 +1,216 @@
+// Token-timestamp stage on device (TF/models/whisper/generation_whisper.py:241-381):
+//   align_stats_kernel   population mean/std over the token axis per (item, head, frame)   (:343-345)
+//   align_filter_kernel  z-score -> width-w running median along frames (reflect edges, exact selection
+//                        by sorting network, :43-61) -> mean over heads (:349), fused, one LDS-staged row
+//                        segment per head
+//   dtw_kernel           anti-diagonal wavefront DTW over the (N+1) x (M+1) cost lattice with the
+//                        reference's asymmetric tie rule (:80-85) and f32 cost accumulation (:70,87),
+//                        three rolling diagonals in LDS, byte trace in global (L2), on-device backtrace
+//                        (:89-115) that also emits, per token row, the first frame of its run (= jump
+//                        time / 0.02 s, :368-369)
+//   pauses_kernel        REF/utils.py:8-26: per-boundary pause redistribution (boundaries independent)
+#include "common.h"
+#include "kernels.h"
+
+// w: [B][Ha][rows_cap][S]; token rows row0 .. row0+N-1; frames j < n_cols[b].
+__global__ void align_stats_kernel(const float* __restrict__ w, int Ha, int rows_cap, int S, int row0, int N,
+                                   const int* __restrict__ n_cols, float* __restrict__ mean, float* __restrict__ stdv) {
+    const int a = blockIdx.y, b = blockIdx.z;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cols[b]) return;
+    const float* base = w + (((size_t)b * Ha + a) * rows_cap + row0) * S + j;
+    double s = 0.0;
+    for (int i = 0; i < N; ++i) s += (double)base[(size_t)i * S];
+    const double mu = s / N;
+    double q = 0.0;
+    for (int i = 0; i < N; ++i) { double d = (double)base[(size_t)i * S] - mu; q += d * d; }
+    const size_t o = ((size_t)b * Ha + a) * S + j;
+    mean[o] = (float)mu;
+    stdv[o] = (float)sqrt(q / N);
+}
+
+__device__ inline void cswap(float& a, float& b) { float lo = fminf(a, b), hi = fmaxf(a, b); a = lo; b = hi; }
+
+// exact median of up to 9 values (odd width) by insertion-free sorting network on registers
+template <int W> __device__ inline float median_w(float* v) {
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+#pragma unroll
+        for (int j = 0; j + 1 < W - i; ++j) cswap(v[j], v[j + 1]);
+    return v[W / 2];
+}
+
+#define FT 256  // frames per block
+// grid: (ceil(maxcols/FT), N, B); out mat[b][i][j] (row stride S)
+template <int W>
+__global__ __launch_bounds__(FT) void align_filter_kernel(const float* __restrict__ w, int Ha, int rows_cap, int S,
+                                                          int row0, int N, const int* __restrict__ n_cols,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv, float* __restrict__ mat) {
+    __shared__ float z[FT + 2 * (W / 2)];
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int M = n_cols[b];
+    const int j0 = blockIdx.x * FT;
+    if (j0 >= M) return;
+    const int pad = W / 2;
+    const int j = j0 + threadIdx.x;
+    float acc = 0.f;
+    for (int a = 0; a < Ha; ++a) {
+        const float* row = w + (((size_t)b * Ha + a) * rows_cap + row0 + i) * S;
+        const float* mu = mean + ((size_t)b * Ha + a) * S;
+        const float* sd = stdv + ((size_t)b * Ha + a) * S;
+        __syncthreads();
+        for (int t = threadIdx.x; t < FT + 2 * pad; t += FT) {
+            int jj = j0 - pad + t;
+            if (M > pad) {                     // reflect padding (:57)
+                if (jj < 0) jj = -jj;
+                if (jj >= M) jj = 2 * (M - 1) - jj;
+            }
+            float zz = 0.f;
+            if (jj >= 0 && jj < M) zz = (row[jj] - mu[jj]) / sd[jj];
+            z[t] = zz;
+        }
+        __syncthreads();
+        if (j < M) {
+            float v;
+            if (M <= pad) {
+                v = z[threadIdx.x + pad];      // early return of _median_filter (:53-54)
+            } else {
+                float win[W];
+#pragma unroll
+                for (int t = 0; t < W; ++t) win[t] = z[threadIdx.x + t];
+                v = median_w<W>(win);
+            }
+            acc += v;
+        }
+    }
+    if (j < M) mat[((size_t)b * N + i) * S + j] = acc / (float)Ha;
+}
+
+// One block per item.  Diagonal d = i + j (1 <= i <= N, 1 <= j <= M).  cost index by i.
+#define DTW_THREADS 512
+__global__ __launch_bounds__(DTW_THREADS) void dtw_kernel(const float* __restrict__ mat, int N, int S,
+                                                          const int* __restrict__ n_cols,
+                                                          unsigned char* __restrict__ trace,
+                                                          int* __restrict__ first_col, int* __restrict__ path_text,
+                                                          int* __restrict__ path_time, int* __restrict__ path_len) {
+    __shared__ float diag[3][DTW_THREADS + 1];
+    const int b = blockIdx.x;
+    const int M = n_cols[b];
+    const float* x = mat + (size_t)b * N * S;              // x[i-1][j-1]; the DP runs on -x (:367)
+    unsigned char* tr = trace + (size_t)b * N * S;           // tr[(i-1)*S + (j-1)]
+    const int i = threadIdx.x + 1;                           // this thread's row, 1..N
+    const bool active = i <= N;
+
+    // d = 0: only cost[0][0] = 0; d = 1: cost[0][1] = cost[1][0] = inf
+    for (int k = threadIdx.x; k <= DTW_THREADS; k += DTW_THREADS) {
+        diag[0][k] = INFINITY; diag[1][k] = INFINITY; diag[2][k] = INFINITY;
+    }
+    if (threadIdx.x == 0) { diag[0][DTW_THREADS] = INFINITY; diag[1][DTW_THREADS] = INFINITY; diag[2][DTW_THREADS] = INFINITY; }
+    __syncthreads();
+    if (threadIdx.x == 0) diag[0][0] = 0.f;                  // diag for d-2 at step d=2 is "d = 0"
+    __syncthreads();
+
+    int p2 = 0, p1 = 1, cur = 2;                             // buffers for d-2, d-1, d
+    float xnext = 0.f;
+    {   // prefetch for d = 2
+        int j = 2 - i;
+        if (active && j >= 1 && j <= M) xnext = -x[(size_t)(i - 1) * S + (j - 1)];
+    }
+    for (int d = 2; d <= N + M; ++d) {
+        const int j = d - i;
+        const bool on = active && j >= 1 && j <= M;
+        const float xv = xnext;
+        {   // prefetch next diagonal's matrix value (independent of the DP chain)
+            int jn = d + 1 - i;
+            xnext = (active && jn >= 1 && jn <= M) ? -x[(size_t)(i - 1) * S + (jn - 1)] : 0.f;
+        }
+        float c = INFINITY;
+        if (on) {
+            const float c0 = diag[p2][i - 1];               // cost[i-1][j-1]
+            const float c1 = diag[p1][i - 1];               // cost[i-1][j]
+            const float c2 = diag[p1][i];                   // cost[i][j-1]
+            float cm; unsigned char t;
+            if (c0 < c1 && c0 < c2) { cm = c0; t = 0; }
+            else if (c1 < c0 && c1 < c2) { cm = c1; t = 1; }
+            else { cm = c2; t = 2; }
+            c = xv + cm;
+            tr[(size_t)(i - 1) * S + (j - 1)] = t;
+        }
+        if (active) diag[cur][i] = c;                        // cells off the lattice stay +inf
+        if (threadIdx.x == 0) diag[cur][0] = INFINITY;       // cost[0][d] = inf for d >= 1
+        __syncthreads();
+        int tmp = p2; p2 = p1; p1 = cur; cur = tmp;
+    }
+
+    // backtrace (:89-115), single lane; trace[0][:] = 2 and trace[:][0] = 1 are implicit
+    if (threadIdx.x == 0) {
+        __threadfence_block();
+        int ii = N, jj = M, n = 0;
+        int* pt = path_text + (size_t)b * (N + S + 2);
+        int* pj = path_time + (size_t)b * (N + S + 2);
+        while (ii > 0 || jj > 0) {
+            pt[n] = ii - 1; pj[n] = jj - 1; ++n;
+            if (ii > 0 && jj > 0) first_col[(size_t)b * N + (ii - 1)] = jj - 1;
+            unsigned char t = (ii == 0) ? 2 : (jj == 0) ? 1 : tr[(size_t)(ii - 1) * S + (jj - 1)];
+            if (t == 0) { --ii; --jj; } else if (t == 1) { --ii; } else { --jj; }
+        }
+        path_len[b] = n;   // stored in reverse order (end -> start); the host flips it
+    }
+}
+
+__global__ void pauses_kernel(const double* __restrict__ start_in, const double* __restrict__ end_in,
+                              double* __restrict__ start_out, double* __restrict__ end_out, int W, double thr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W) return;
+    // word i's end is moved by boundary (i, i+1); its start by boundary (i-1, i) -- both computed from
+    // the *original* neighbour fields, exactly what the sequential loop of REF/utils.py:8-26 reads.
+    double s = start_in[i], e = end_in[i];
+    if (i + 1 < W) {
+        double pause = start_in[i + 1] - e;
+        if (pause > 0) e = e + (pause > thr ? thr / 2 : pause / 2);
+    }
+    if (i > 0) {
+        double pause = s - end_in[i - 1];
+        if (pause > 0) s = s - (pause > thr ? thr / 2 : pause / 2);
+    }
+    start_out[i] = s; end_out[i] = e;
+}
+
+int cw_launch_align_stats(const float* w, int B, int Ha, int rows_cap, int S, int row0, int N, const int* n_cols,
+                          float* mean, float* stdv, hipStream_t st) {
+    hipLaunchKernelGGL(align_stats_kernel, dim3((S + 255) / 256, Ha, B), dim3(256), 0, st, w, Ha, rows_cap, S, row0, N,
+                       n_cols, mean, stdv);
+    return CW_OK;
+}
+
+int cw_launch_align_filter(const float* w, int B, int Ha, int rows_cap, int S, int row0, int N, const int* n_cols,
+                           const float* mean, const float* stdv, int width, float* mat, hipStream_t st) {
+    dim3 grid((S + FT - 1) / FT, N, B);
+#define LAUNCH_W(WW) hipLaunchKernelGGL((align_filter_kernel<WW>), grid, dim3(FT), 0, st, w, Ha, rows_cap, S, row0, N, \
+                                        n_cols, mean, stdv, mat)
+    switch (width) {
+        case 1: LAUNCH_W(1); break;
+        case 3: LAUNCH_W(3); break;
+        case 5: LAUNCH_W(5); break;
+        case 7: LAUNCH_W(7); break;
+        case 9: LAUNCH_W(9); break;
+        default: return CW_ERR_INVALID;
+    }
+#undef LAUNCH_W
+    return CW_OK;
+}
+
+int cw_launch_dtw(const float* mat, int B, int N, int S, const int* n_cols, unsigned char* trace, int* first_col,
+                  int* path_text, int* path_time, int* path_len, hipStream_t st) {
+    if (N > DTW_THREADS || N <= 0) return CW_ERR_INVALID;
+    hipLaunchKernelGGL(dtw_kernel, dim3(B), dim3(DTW_THREADS), 0, st, mat, N, S, n_cols, trace, first_col, path_text,
+                       path_time, path_len);
+    return CW_OK;
+}
+
+int cw_launch_pauses(double* start, double* end, int W, double thr, hipStream_t st) {
+    // in: start/end ; out: start + W / end + W  (caller provides 2*W doubles each)
+    hipLaunchKernelGGL(pauses_kernel, dim3((W + 255) / 256), dim3(256), 0, st, start, end, start + W, end + W, W, thr);
+    return CW_OK;
+}

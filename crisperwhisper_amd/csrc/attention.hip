@@ -1,0 +1,315 @@
+// Attention kernels (head_dim = 64 for every Whisper size).
+//
+//   attn_encoder_bf16   flash-style fused softmax(Q K^T) V over S = 1500 frames, no mask
+//                       (TF/models/whisper/modeling_whisper.py:215-238, 284-356; q is pre-scaled by
+//                       the projection).  Never materialises the S x S map the HF eager path keeps.
+//                       Computes S^T = K Q^T with MFMA 16x16x32 so that each lane owns one query column:
+//                       softmax statistics are lane-local + 2 cross-lane shuffles, the probabilities are
+//                       already in B-operand layout for O^T = V^T P^T (no LDS round trip for P), and the
+//                       running rescale of O is a per-lane scalar.
+//   attn_encoder_f32    straightforward f32 version (parity mode + on-device reference).
+//   attn_decode         one query per (batch, head) against a KV cache (decoder self-attention with
+//                       n_keys = t+1, cross-attention with n_keys = 1500).  HBM-bound: coalesced 16-byte
+//                       loads, 8 lanes per key row.  For alignment heads the normalised probability row
+//                       is written straight into the [B, H_a, L, S] alignment buffer consumed by the DTW
+//                       stage (replaces HF's per-step retention of all 32x20 heads,
+//                       TF/generation/utils.py:2909-2910).
+#include "common.h"
+#include "kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+__device__ inline f32x4_t mfma16a(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                   __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+
+#define KT 64          // keys per LDS tile
+#define KS_STRIDE 72   // bf16 per K row in LDS (64 + 8)
+#define VS_STRIDE 66   // bf16 per V^T row in LDS (64 keys + 2): 33 dwords -> spreads the transposing writes
+
+// grid: (ceil(S/128), H, B), 256 threads; wave w owns queries q0 + w*32 .. +31 (two 16-query tiles).
+__global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __restrict__ Q,
+                                                                const bf16_t* __restrict__ K,
+                                                                const bf16_t* __restrict__ V,
+                                                                bf16_t* __restrict__ out, int H, int S, int S_pad) {
+    __shared__ __attribute__((aligned(16))) bf16_t sK[KT * KS_STRIDE];
+    __shared__ __attribute__((aligned(16))) bf16_t sVt[64 * VS_STRIDE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const size_t head_off = ((size_t)b * H + h) * S_pad * 64;
+    const bf16_t* Qh = Q + head_off;
+    const bf16_t* Kh = K + head_off;
+    const bf16_t* Vh = V + head_off;
+    const int qbase = blockIdx.x * 128 + wave * 32;
+
+    // Q fragments (B operand of S^T = K Q^T): lane supplies Q[q = l15][d = kk*32 + g*8 .. +7]
+    bf16x8_t fq[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = qbase + qt * 16 + l15;
+        if (q >= S) q = S - 1;  // clamp: rows beyond S are computed but never stored
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fq[qt][kk] = *(const bf16x8_t*)(Qh + (size_t)q * 64 + kk * 32 + g * 8);
+    }
+
+    f32x4_t o[2][4];
+    float mrow[2], lrow[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        mrow[qt] = -INFINITY; lrow[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ntiles = (S + KT - 1) / KT;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int k0 = tile * KT;
+        __syncthreads();  // previous tile fully consumed
+        // stage K tile: 64 keys x 64 d = 512 16-byte chunks, 2 per thread (rows < S_pad are allocated/zeroed)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + i * 256, row = c >> 3, col = (c & 7) * 8;
+            uint4 kv = *(const uint4*)(Kh + (size_t)(k0 + row) * 64 + col);
+            *(uint4*)(sK + row * KS_STRIDE + col) = kv;
+            // V: transpose while staging -> sVt[d][key]
+            uint4 vv = *(const uint4*)(Vh + (size_t)(k0 + row) * 64 + col);
+            const bf16_t* ve = (const bf16_t*)&vv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sVt[(col + e) * VS_STRIDE + row] = ve[e];
+        }
+        __syncthreads();
+
+        // S^T tiles: st[qt][kt][r] = score(key = k0 + kt*16 + g*4 + r, query = qbase + qt*16 + l15)
+        f32x4_t st[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            bf16x8_t fk0 = *(const bf16x8_t*)(sK + (kt * 16 + l15) * KS_STRIDE + g * 8);
+            bf16x8_t fk1 = *(const bf16x8_t*)(sK + (kt * 16 + l15) * KS_STRIDE + 32 + g * 8);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                z = mfma16a(fk0, fq[qt][0], z);
+                z = mfma16a(fk1, fq[qt][1], z);
+                st[qt][kt] = z;
+            }
+        }
+        // mask keys beyond S (only the last tile), online softmax per query column
+        bf16x8_t fp[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int key = k0 + kt * 16 + g * 4 + r;
+                    float s = (key < S) ? st[qt][kt][r] : -INFINITY;
+                    st[qt][kt][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrow[qt], mx);
+            const float alpha = __expf(mrow[qt] - mnew);   // exp(-inf) = 0 on the first tile
+            mrow[qt] = mnew;
+            float psum = 0.f;
+            bf16_t pb[16];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = __expf(st[qt][kt][r] - mnew);
+                    psum += pv;
+                    pb[kt * 4 + r] = f32_to_bf16(pv);
+                }
+            lrow[qt] = lrow[qt] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+            // B operand of O^T = V^T P^T for k-step kp: contraction index j<4 -> key (2kp)*16 + g*4 + j,
+            // j>=4 -> key (2kp+1)*16 + g*4 + (j-4); the A operand below uses the same mapping.
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                bf16x8_t f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[j] = (short)pb[(2 * kp) * 4 + j];
+                    f[4 + j] = (short)pb[(2 * kp + 1) * 4 + j];
+                }
+                fp[qt][kp] = f;
+            }
+        }
+        // O^T[d][q] += sum_key V^T[d][key] P^T[key][q]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const bf16_t* vr = sVt + (dt * 16 + l15) * VS_STRIDE;
+                bf16x8_t fv;
+                const uint32_t* a0 = (const uint32_t*)(vr + (2 * kp) * 16 + g * 4);
+                const uint32_t* a1 = (const uint32_t*)(vr + (2 * kp + 1) * 16 + g * 4);
+                uint32_t w0 = a0[0], w1 = a0[1], w2 = a1[0], w3 = a1[1];
+                fv[0] = (short)(w0 & 0xffff); fv[1] = (short)(w0 >> 16);
+                fv[2] = (short)(w1 & 0xffff); fv[3] = (short)(w1 >> 16);
+                fv[4] = (short)(w2 & 0xffff); fv[5] = (short)(w2 >> 16);
+                fv[6] = (short)(w3 & 0xffff); fv[7] = (short)(w3 >> 16);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mfma16a(fv, fp[qt][kp], o[qt][dt]);
+            }
+        }
+    }
+
+    // finalise: l is a per-lane partial over this lane's keys -> sum the 4 lane groups of each column
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lrow[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = qbase + qt * 16 + l15;
+        if (q < S) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                ushort4 pk;
+                pk.x = f32_to_bf16(o[qt][dt][0] * inv); pk.y = f32_to_bf16(o[qt][dt][1] * inv);
+                pk.z = f32_to_bf16(o[qt][dt][2] * inv); pk.w = f32_to_bf16(o[qt][dt][3] * inv);
+                // out[b][q][h*64 + dt*16 + g*4 .. +3]
+                *(ushort4*)(out + ((size_t)b * S + q) * (H * 64) + h * 64 + dt * 16 + g * 4) = pk;
+            }
+        }
+    }
+}
+
+// f32 flavour: one wave per query, scores in LDS.  grid (ceil(S/4), H, B), 256 threads.
+__global__ __launch_bounds__(256) void attn_encoder_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                               const float* __restrict__ V, float* __restrict__ out,
+                                                               int H, int S, int S_pad) {
+    extern __shared__ float sc[];  // [4][S]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= S) return;
+    const size_t head_off = ((size_t)b * H + h) * S_pad * 64;
+    const float* qr = Q + head_off + (size_t)q * 64;
+    float* s = sc + (size_t)wave * S;
+    float mx = -INFINITY;
+    for (int k = lane; k < S; k += 64) {
+        const float* kr = K + head_off + (size_t)k * 64;
+        float d = 0.f;
+#pragma unroll 16
+        for (int e = 0; e < 64; ++e) d = fmaf(qr[e], kr[e], d);
+        s[k] = d;
+        mx = fmaxf(mx, d);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < S; k += 64) { float p = expf(s[k] - mx); s[k] = p; sum += p; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    // lane = output feature; keys sequentially (p read from LDS is a broadcast)
+    float acc = 0.f;
+    for (int k = 0; k < S; ++k) acc = fmaf(s[k] * inv, V[head_off + (size_t)k * 64 + lane], acc);
+    out[((size_t)b * S + q) * (H * 64) + h * 64 + lane] = acc;
+}
+
+int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* V, void* out, int B, int H, int S,
+                           int S_pad, hipStream_t st) {
+    if (bf16) {
+        if (S_pad % KT != 0 || S_pad < S) return CW_ERR_INVALID;
+        hipLaunchKernelGGL(attn_encoder_bf16_kernel, dim3((S + 127) / 128, H, B), dim3(256), 0, st, (const bf16_t*)Q,
+                           (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
+    } else {
+        hipLaunchKernelGGL(attn_encoder_f32_kernel, dim3((S + 3) / 4, H, B), dim3(256), (size_t)4 * S * sizeof(float),
+                           st, (const float*)Q, (const float*)K, (const float*)V, (float*)out, H, S, S_pad);
+    }
+    return CW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Decode attention: grid (H, B), 512 threads.  8 lanes cooperate on one 64-wide key row.
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct Row8;  // loads 8 consecutive elements as f32
+template <> struct Row8<float> {
+    __device__ static inline void ld(const float* p, float* o) {
+        float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+};
+template <> struct Row8<bf16_t> {
+    __device__ static inline void ld(const bf16_t* p, float* o) {
+        uint4 a = *(const uint4*)p;
+        o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
+        o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
+        o[4] = __uint_as_float(a.z << 16); o[5] = __uint_as_float(a.z & 0xffff0000u);
+        o[6] = __uint_as_float(a.w << 16); o[7] = __uint_as_float(a.w & 0xffff0000u);
+    }
+};
+
+#define DEC_THREADS 512
+#define DEC_GROUPS (DEC_THREADS / 8)
+
+template <typename T>
+__global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams p) {
+    extern __shared__ float dsm[];          // scores [n_keys] | red [DEC_GROUPS][64] | scratch [64]
+    float* sc = dsm;
+    float* red = dsm + ((p.n_keys + 63) & ~63);
+    float* scratch = red + DEC_GROUPS * 64;
+    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const T* Kh = (const T*)p.K + ((size_t)b * p.H + h) * p.cap * 64;
+    const T* Vh = (const T*)p.V + ((size_t)b * p.H + h) * p.cap * 64;
+    float qv[8];
+    Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
+
+    float mx = -INFINITY;
+    for (int k = grp; k < p.n_keys; k += DEC_GROUPS) {
+        float kv[8];
+        Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[e], d);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if (sub == 0) sc[k] = d;
+        mx = fmaxf(mx, d);
+    }
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int k = tid; k < p.n_keys; k += DEC_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
+    sum = block_sum(sum, scratch);      // includes the barriers that publish sc[]
+    const float inv = 1.0f / sum;
+
+    const int slot = p.align_out ? p.align_slot[h] : -1;
+    if (slot >= 0) {
+        float* dst = p.align_out + (((size_t)b * p.n_align + slot) * p.align_rows + p.align_row) * p.n_keys;
+        for (int k = tid; k < p.n_keys; k += DEC_THREADS) dst[k] = sc[k] * inv;
+    }
+
+    float acc[8] = {};
+    for (int k = grp; k < p.n_keys; k += DEC_GROUPS) {
+        float vv[8];
+        Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv);
+        const float pk = sc[k] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[grp * 64 + sub * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        float r = 0.f;
+        for (int gI = 0; gI < DEC_GROUPS; ++gI) r += red[gI * 64 + tid];
+        p.out[(size_t)b * p.H * 64 + h * 64 + tid] = r;
+    }
+}
+
+int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
+    size_t lds = ((size_t)((p.n_keys + 63) & ~63) + DEC_GROUPS * 64 + 64) * sizeof(float);
+    if (bf16)
+        hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+    else
+        hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+    return CW_OK;
+}

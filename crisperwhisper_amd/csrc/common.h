@@ -1,0 +1,146 @@
+// Shared device/host helpers for the CrisperWhisper MI355X (gfx950) hot path.
+// Written for CDNA4 only: wave = 64 lanes, MFMA 16x16x32 bf16, 160 KiB LDS/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 storage
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;  // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;   // one MFMA 16x16 C/D fragment
+
+#define CW_WAVE 64
+
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+    union { uint32_t u; float f; } x; x.u = ((uint32_t)v) << 16; return x.f;
+}
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } x; x.f = f;
+    if ((x.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x.u >> 16) | 0x40);  // quiet NaN
+    x.u += 0x7fffu + ((x.u >> 16) & 1u);                                          // round-nearest-even
+    return (bf16_t)(x.u >> 16);
+}
+
+// Activation storage trait: the engine runs either fully in f32 (parity mode) or with bf16
+// weights/activations (performance mode); memory-bound kernels are templated on the storage type.
+template <typename T> struct Act;
+template <> struct Act<float> {
+    __device__ static inline float ld(const float* p) { return *p; }
+    __device__ static inline void st(float* p, float v) { *p = v; }
+};
+template <> struct Act<bf16_t> {
+    __device__ static inline float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static inline void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ inline float gelu_erf(float x) {  // nn.functional.gelu default (exact erf form)
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide reductions through a small LDS scratch (>= 32 floats).  All threads get the result.
+__device__ inline float block_sum(float v, float* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+__device__ inline float block_max(float v, float* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM epilogues.  Every GEMM flavour (MFMA bf16 tile GEMM, f32 parity GEMM, decode GEMV) funnels
+// its accumulators through epi_store4(): 4 consecutive output columns n..n+3 of one row m.
+// ---------------------------------------------------------------------------------------------
+enum EpiMode {
+    EPI_STORE = 0,       // out[m][n] = T(acc + bias)
+    EPI_GELU = 1,        // out[m][n] = T(gelu(acc + bias))
+    EPI_RESID_F32 = 2,   // outf[m][n] = resid[m][n] + acc + bias            (f32 residual stream)
+    EPI_GELU_POS_F32 = 3,// outf[m][n] = gelu(acc + bias) + pos[m % T][n]     (conv2 + sinusoid pos)
+    EPI_HEADS = 4,       // split columns into (which, head, dd); rows into (b, s):
+                         //   outs[which][((b*H + h)*S_pad + s)*64 + dd] = T(acc + bias)
+    EPI_STORE_F32 = 5,   // outf[m][n] = acc + bias                            (logits, q vectors)
+    EPI_QKV_CACHE = 6,   // decode: which==0 -> outf[m][n] (q, f32); 1/2 -> self-KV cache row `pos`
+    EPI_GELU_F32 = 7,    // outf[m][n] = gelu(acc + bias)                      (decode MLP mid)
+};
+
+struct EpiParams {
+    void* out;            // T* (EPI_STORE/GELU) or base for `which == 0` (EPI_HEADS)
+    void* out1;           // which == 1
+    void* out2;           // which == 2
+    float* outf;          // f32 outputs
+    const float* bias;    // [N] or null
+    const float* resid;   // [M][ldo] f32
+    const float* pos;     // [T][N] f32
+    int ldo;              // leading dimension of out/outf/resid
+    int T;                // rows per batch item (EPI_GELU_POS_F32, EPI_HEADS)
+    int S_pad;            // padded per-head sequence capacity (EPI_HEADS / cache capacity)
+    int H;                // heads
+    int d_model;          // columns per `which`
+    int pos_row;          // EPI_QKV_CACHE: cache position to write
+};
+
+template <typename T, int MODE>
+__device__ inline void epi_store1(const EpiParams& p, int m, int n, float acc) {
+    float v = acc + (p.bias ? p.bias[n] : 0.f);
+    if (MODE == EPI_STORE) {
+        Act<T>::st((T*)p.out + (size_t)m * p.ldo + n, v);
+    } else if (MODE == EPI_GELU) {
+        Act<T>::st((T*)p.out + (size_t)m * p.ldo + n, gelu_erf(v));
+    } else if (MODE == EPI_RESID_F32) {
+        size_t o = (size_t)m * p.ldo + n;
+        p.outf[o] = p.resid[o] + v;
+    } else if (MODE == EPI_GELU_POS_F32) {
+        p.outf[(size_t)m * p.ldo + n] = gelu_erf(v) + p.pos[(size_t)(m % p.T) * p.ldo + n];
+    } else if (MODE == EPI_HEADS) {
+        int which = n / p.d_model, r = n - which * p.d_model;
+        int h = r >> 6, dd = r & 63;
+        int b = m / p.T, s = m - b * p.T;
+        T* base = (T*)(which == 0 ? p.out : (which == 1 ? p.out1 : p.out2));
+        Act<T>::st(base + (((size_t)b * p.H + h) * p.S_pad + s) * 64 + dd, v);
+    } else if (MODE == EPI_STORE_F32) {
+        p.outf[(size_t)m * p.ldo + n] = v;
+    } else if (MODE == EPI_GELU_F32) {
+        p.outf[(size_t)m * p.ldo + n] = gelu_erf(v);
+    } else if (MODE == EPI_QKV_CACHE) {
+        int which = n / p.d_model, r = n - which * p.d_model;
+        if (which == 0) {
+            p.outf[(size_t)m * p.d_model + r] = v;
+        } else {
+            int h = r >> 6, dd = r & 63;
+            T* base = (T*)(which == 1 ? p.out1 : p.out2);
+            Act<T>::st(base + (((size_t)m * p.H + h) * p.S_pad + p.pos_row) * 64 + dd, v);
+        }
+    }
+}
+
+// Host-side error plumbing -----------------------------------------------------------------------
+#define CW_OK 0
+#define CW_ERR_INVALID (-22)
+#define CW_ERR_NOMEM (-12)
+#define CW_ERR_HIP (-5)
+#define CW_ERR_STATE (-1)

@@ -1,0 +1,190 @@
+// Row-wise kernels: LayerNorm, token embedding, and the fused logits-processing + greedy sampling
+// kernel (TF/generation/logits_process.py:203-260, 1816-2047 + argmax TF/generation/utils.py:2925).
+#include "common.h"
+#include "kernels.h"
+
+// One wave per row (rows of d_model f32 from the residual stream), vectorised float4 loads,
+// two-pass statistics (mean, then variance) like nn.LayerNorm, eps = 1e-5.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, T* __restrict__ out, int rows,
+                                                        int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * d;
+    float s = 0.f;
+    for (int k = lane * 4; k < d; k += 256) {
+        float4 v = *(const float4*)(xr + k);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int k = lane * 4; k < d; k += 256) {
+        float4 v = *(const float4*)(xr + k);
+        float a = v.x - mean, bb = v.y - mean, c = v.z - mean, e = v.w - mean;
+        q += (a * a + bb * bb) + (c * c + e * e);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+    T* o = out + (size_t)row * d;
+    for (int k = lane * 4; k < d; k += 256) {
+        float4 v = *(const float4*)(xr + k);
+        float4 gg = *(const float4*)(g + k), bb = *(const float4*)(b + k);
+        Act<T>::st(o + k + 0, (v.x - mean) * rstd * gg.x + bb.x);
+        Act<T>::st(o + k + 1, (v.y - mean) * rstd * gg.y + bb.y);
+        Act<T>::st(o + k + 2, (v.z - mean) * rstd * gg.z + bb.z);
+        Act<T>::st(o + k + 3, (v.w - mean) * rstd * gg.w + bb.w);
+    }
+}
+
+int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d,
+                        hipStream_t st) {
+    if (d % 4 != 0 || rows <= 0) return CW_ERR_INVALID;
+    dim3 grid((rows + 3) / 4);
+    if (bf16_out)
+        hipLaunchKernelGGL((layernorm_kernel<bf16_t>), grid, dim3(256), 0, st, x, g, b, (bf16_t*)out, rows, d);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<float>), grid, dim3(256), 0, st, x, g, b, (float*)out, rows, d);
+    return CW_OK;
+}
+
+int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d,
+                            hipStream_t st) {
+    return cw_launch_layernorm(false, x, g, b, out, rows, d, st);
+}
+
+// x_out[b][:] = embed[ids[b][t]][:] + pos_embed[t][:]   (TF modeling_whisper.py:737, 754-762)
+template <typename T>
+__global__ void embed_kernel(const int* __restrict__ ids, int ids_stride, int t, const T* __restrict__ embed,
+                             const float* __restrict__ pos_embed, float* __restrict__ x_out, int d) {
+    const int b = blockIdx.x;
+    const int tok = ids[(size_t)b * ids_stride + t];
+    for (int k = threadIdx.x; k < d; k += blockDim.x)
+        x_out[(size_t)b * d + k] = Act<T>::ld(embed + (size_t)tok * d + k) + pos_embed[(size_t)t * d + k];
+}
+
+int cw_launch_embed(const int* ids, int ids_stride, int t, const void* embed, int embed_bf16, const float* pos_embed,
+                    float* x_out, int B, int d, hipStream_t st) {
+    if (embed_bf16)
+        hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(B), dim3(256), 0, st, ids, ids_stride, t,
+                           (const bf16_t*)embed, pos_embed, x_out, d);
+    else
+        hipLaunchKernelGGL((embed_kernel<float>), dim3(B), dim3(256), 0, st, ids, ids_stride, t, (const float*)embed,
+                           pos_embed, x_out, d);
+    return CW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused logits processors + greedy choice + next-step embedding.  One block (1024 threads) per row.
+//
+// Effective score s(v) after, in HF's order: MinNewTokensLength -> SuppressTokensAtBegin ->
+// SuppressTokens -> WhisperTimeStamp.  All of them only write -inf, so they commute and collapse
+// into one predicate.  The timestamp "logsumexp rule" (logits_process.py:2040-2045):
+//     logsumexp(logp[tb:]) > max(logp[:tb])   <=>   log(sum_{v>=tb} exp(s_v - M)) > max_text - M
+// with M the row max, so the partition function cancels and never has to be computed.
+// ---------------------------------------------------------------------------------------------------
+struct ArgPair { float v; int i; };
+__device__ inline ArgPair arg_better(ArgPair a, ArgPair b) {  // larger value wins, ties -> lower index
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+__device__ inline ArgPair wave_argmax(ArgPair a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgPair b; b.v = __shfl_xor(a.v, o, 64); b.i = __shfl_xor(a.i, o, 64);
+        a = arg_better(a, b);
+    }
+    return a;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
+    __shared__ float s_f[64];
+    __shared__ int s_i[64];
+    __shared__ int s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const float* lg = p.logits + (size_t)b * p.V;
+    int* ids = p.ids + (size_t)b * p.ids_stride;
+    const int t = p.t, tb = p.timestamp_begin;
+    const int n_gen = t - p.n_prompt;
+
+    const bool was_finished = p.finished[b] != 0;
+    int forced = p.forced ? p.forced[(size_t)b * p.ids_stride + t] : -1;
+
+    // timestamp grammar state from the generated suffix
+    const bool last_ts = n_gen >= 1 && ids[t - 1] >= tb;
+    const bool penult_ts = n_gen < 2 || ids[t - 2] >= tb;
+    const int last_tok = p.last_ts_tok[b];
+    const int ts_floor = (last_tok >= 0) ? ((last_ts && !penult_ts) ? last_tok : last_tok + 1) : tb;
+    const bool at_begin = (n_gen == 0);
+    const int ts_cap = (at_begin && p.max_initial_timestamp_index >= 0) ? tb + p.max_initial_timestamp_index
+                                                                         : 0x7fffffff;
+    auto score = [&](int v) -> float {
+        unsigned char mk = p.mask[v];
+        bool dead = (mk & 1) || (at_begin && (mk & 2));
+        dead |= (v == p.eos && n_gen < p.min_new_tokens);
+        if (last_ts) dead |= penult_ts ? (v >= tb) : (v < p.eos);
+        dead |= (v >= tb && v < ts_floor);
+        if (at_begin) dead |= (v < tb) || (v > ts_cap);
+        return dead ? -INFINITY : lg[v];
+    };
+
+    // pass 1: best text token, best timestamp token
+    ArgPair bt = {-INFINITY, 0x7fffffff}, bs = {-INFINITY, 0x7fffffff};
+    for (int v = tid; v < p.V; v += blockDim.x) {
+        ArgPair c = {score(v), v};
+        if (v < tb) bt = arg_better(bt, c); else bs = arg_better(bs, c);
+    }
+    bt = wave_argmax(bt);
+    bs = wave_argmax(bs);
+    __syncthreads();
+    if (lane == 0) { s_f[wave] = bt.v; s_i[wave] = bt.i; s_f[32 + wave] = bs.v; s_i[32 + wave] = bs.i; }
+    __syncthreads();
+    bt = {-INFINITY, 0x7fffffff}; bs = {-INFINITY, 0x7fffffff};
+    for (int w = 0; w < nw; ++w) {
+        bt = arg_better(bt, ArgPair{s_f[w], s_i[w]});
+        bs = arg_better(bs, ArgPair{s_f[32 + w], s_i[32 + w]});
+    }
+    const float M = fmaxf(bt.v, bs.v);
+
+    // pass 2: sum over timestamp tokens of exp(s - M)
+    float acc = 0.f;
+    for (int v = tb + tid; v < p.V; v += blockDim.x) {
+        float s = score(v);
+        if (s > -INFINITY) acc += expf(s - M);
+    }
+    acc = block_sum(acc, s_f);
+
+    if (tid == 0) {
+        bool force_ts = (acc > 0.f) && (logf(acc) > bt.v - M);
+        int choice;
+        if (force_ts || !(bt.v > -INFINITY)) choice = bs.i;
+        else choice = arg_better(bt, bs).i;
+        if (p.argmax_trace) p.argmax_trace[(size_t)b * p.ids_stride + t] = choice;
+        int tok = (forced >= 0) ? forced : choice;
+        if (was_finished) tok = p.pad;                                  // utils.py:2928-2929
+        ids[t] = tok;
+        if (tok >= tb && n_gen >= 0) p.last_ts_tok[b] = tok;
+        int fin = was_finished || (n_gen >= 0 && tok == p.eos) || (t + 1 >= p.max_length);
+        p.finished[b] = fin;
+        if (!fin) atomicAdd(p.n_unfinished, 1);
+        s_tok = tok;
+    }
+    __syncthreads();
+    // embedding for the next decoder step: token at sequence index t is fed at position t
+    const int tok = s_tok;
+    if (p.x_out && t < p.max_length) {
+        const T* e = (const T*)p.embed + (size_t)tok * p.d;
+        const float* pe = p.pos_embed + (size_t)t * p.d;
+        for (int k = tid; k < p.d; k += blockDim.x) p.x_out[(size_t)b * p.d + k] = Act<T>::ld(e + k) + pe[k];
+    }
+}
+
+int cw_launch_sample(const SampleParams& p, hipStream_t st) {
+    hipMemsetAsync(p.n_unfinished, 0, sizeof(int), st);
+    if (p.embed_bf16)
+        hipLaunchKernelGGL((sample_kernel<bf16_t>), dim3(p.B), dim3(1024), 0, st, p);
+    else
+        hipLaunchKernelGGL((sample_kernel<float>), dim3(p.B), dim3(1024), 0, st, p);
+    return CW_OK;
+}

@@ -1,0 +1,962 @@
+// Engine + C ABI (include/crisperwhisper.h): owns device memory, the HIP stream, the weights and the
+// per-stage orchestration of the CrisperWhisper hot path on one MI355X.  No CPU fallbacks: every entry
+// point either runs the HIP kernels or returns an error.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/crisperwhisper.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+struct LayerW {
+    void* wqkv = nullptr; float* bqkv = nullptr;
+    void* wo = nullptr; float* bo = nullptr;
+    float *ln1_g = nullptr, *ln1_b = nullptr;
+    void* wq_c = nullptr; float* bq_c = nullptr;
+    void* wkv_c = nullptr; float* bkv_c = nullptr;
+    void* wo_c = nullptr; float* bo_c = nullptr;
+    float *lnc_g = nullptr, *lnc_b = nullptr;
+    void* w1 = nullptr; float* b1 = nullptr;
+    void* w2 = nullptr; float* b2 = nullptr;
+    float *ln2_g = nullptr, *ln2_b = nullptr;
+    void *ck = nullptr, *cv = nullptr;   // cross K/V cache   [Bm][H][1500][64]
+    void *sk = nullptr, *sv = nullptr;   // self  K/V cache   [Bm][H][448][64]
+};
+
+struct cw_ctx {
+    cw_model_desc d;
+    bool bf16 = false;
+    int device = 0;
+    int Bm = 0, S_pad = 0;
+    size_t esz = 4;
+    hipStream_t st = nullptr;
+    std::vector<void*> allocs;
+    char err[512] = "";
+    std::vector<int> align_layers, align_heads;
+
+    // weights
+    void *conv1_w = nullptr, *conv2_w = nullptr, *embed = nullptr;
+    float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *dec_pos = nullptr;
+    float *enc_ln_g = nullptr, *enc_ln_b = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
+    std::vector<LayerW> enc, dec;
+
+    // front end
+    MelTables mel{};
+    float *d_pcm = nullptr, *d_logspec = nullptr, *d_feats_hf = nullptr;
+    unsigned int* d_gmax = nullptr;
+    void* d_feats_tm = nullptr;
+    std::vector<int> n_frames_items;
+
+    // encoder workspace
+    void *c1 = nullptr, *h = nullptr, *qb = nullptr, *kb = nullptr, *vb = nullptr, *ao = nullptr, *mid = nullptr,
+         *enc_out = nullptr;
+    float* x = nullptr;
+    int *d_row_off = nullptr, *d_row_valid = nullptr, *d_row_off2 = nullptr, *d_row_valid2 = nullptr;
+    int nb_encoded = 0;
+
+    // decoder state
+    float *dx = nullptr, *dxn = nullptr, *dq = nullptr, *dattn = nullptr, *dmid = nullptr, *dlogits = nullptr;
+    int *d_ids = nullptr, *d_forced = nullptr, *d_argmax = nullptr, *d_last_ts = nullptr, *d_finished = nullptr,
+        *d_nunf = nullptr, *d_align_slot = nullptr;
+    unsigned char* d_mask = nullptr;
+    float* d_align = nullptr;
+    int* h_nunf = nullptr;  // pinned
+    cw_gen_cfg gen{};
+    bool gen_set = false;
+    float* logits_capture = nullptr;
+    int logits_capture_steps = 0;
+    int last_L = 0, last_nb = 0;
+
+    // timestamps workspace
+    float *d_mean = nullptr, *d_std = nullptr, *d_mat = nullptr;
+    unsigned char* d_trace = nullptr;
+    int *d_first_col = nullptr, *d_path_text = nullptr, *d_path_time = nullptr, *d_path_len = nullptr,
+        *d_ncols = nullptr;
+
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float stage_ms[CW_N_STAGES] = {};
+    int stage_calls[CW_N_STAGES] = {};
+};
+
+static int fail(cw_ctx* c, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c ? c->err : g_err, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) return fail(c, CW_ERR_HIP, "%s failed: %s (%s:%d)", #call,            \
+                                          hipGetErrorString(e_), __FILE__, __LINE__);               \
+    } while (0)
+#define CWCHK(c, call)                                                          \
+    do {                                                                        \
+        int r_ = (call);                                                        \
+        if (r_ != CW_OK) return fail(c, r_, "%s -> %d (%s:%d)", #call, r_, __FILE__, __LINE__); \
+    } while (0)
+#define KCHK(c) HIPCHK(c, hipGetLastError())
+
+template <typename P>
+static int dmalloc(cw_ctx* c, P** p, size_t bytes, bool zero = true) {
+    void* q = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(c, CW_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) hipMemset(q, 0, bytes);
+    c->allocs.push_back(q);
+    *p = (P*)q;
+    return CW_OK;
+}
+
+// host f32 -> device T (optionally scaled), at element offset `off` of dst
+static int upload_T(cw_ctx* c, void* dst, size_t off, const float* src, size_t n, float scale = 1.0f) {
+    if (c->bf16) {
+        std::vector<bf16_t> tmp(n);
+        for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16(src[i] * scale);
+        HIPCHK(c, hipMemcpy((bf16_t*)dst + off, tmp.data(), n * 2, hipMemcpyHostToDevice));
+    } else if (scale != 1.0f) {
+        std::vector<float> tmp(n);
+        for (size_t i = 0; i < n; ++i) tmp[i] = src[i] * scale;
+        HIPCHK(c, hipMemcpy((float*)dst + off, tmp.data(), n * 4, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(c, hipMemcpy((float*)dst + off, src, n * 4, hipMemcpyHostToDevice));
+    }
+    return CW_OK;
+}
+static int upload_f32(cw_ctx* c, float* dst, size_t off, const float* src, size_t n, float scale = 1.0f) {
+    if (scale != 1.0f) {
+        std::vector<float> tmp(n);
+        for (size_t i = 0; i < n; ++i) tmp[i] = src[i] * scale;
+        HIPCHK(c, hipMemcpy(dst + off, tmp.data(), n * 4, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(c, hipMemcpy(dst + off, src, n * 4, hipMemcpyHostToDevice));
+    }
+    return CW_OK;
+}
+// device T -> host f32
+static int download_T(cw_ctx* c, const void* src, size_t off, float* dst, size_t n) {
+    if (c->bf16) {
+        std::vector<bf16_t> tmp(n);
+        HIPCHK(c, hipMemcpy(tmp.data(), (const bf16_t*)src + off, n * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) dst[i] = bf16_to_f32(tmp[i]);
+    } else {
+        HIPCHK(c, hipMemcpy(dst, (const float*)src + off, n * 4, hipMemcpyDeviceToHost));
+    }
+    return CW_OK;
+}
+
+struct StageTimer {
+    cw_ctx* c; int stage;
+    StageTimer(cw_ctx* c_, int s) : c(c_), stage(s) { hipEventRecord(c->ev0, c->st); }
+    void stop() {
+        hipEventRecord(c->ev1, c->st);
+        hipEventSynchronize(c->ev1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->stage_ms[stage] += ms;
+        c->stage_calls[stage] += 1;
+    }
+};
+
+extern "C" {
+
+int32_t cw_abi_version(void) { return 1; }
+
+const char* cw_last_error(cw_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+int32_t cw_sync(cw_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return CW_OK;
+}
+
+static int create_impl(cw_ctx* c) {
+    const cw_model_desc& d = c->d;
+    const int D = d.d_model, H = d.n_heads, F = d.ffn_dim, V = d.vocab_size, Bm = d.max_batch;
+    if (D != H * 64) return fail(c, CW_ERR_INVALID, "head_dim must be 64 (d_model=%d heads=%d)", D, H);
+    if (D % 128 || F % 128 || d.n_mels % 64) return fail(c, CW_ERR_INVALID, "d_model/ffn must be multiples of 128, n_mels of 64");
+    if (Bm < 1 || Bm > 64) return fail(c, CW_ERR_INVALID, "max_batch must be in 1..64");
+    if (d.max_target_positions > 512) return fail(c, CW_ERR_INVALID, "max_target_positions > 512 unsupported");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamCreate(&c->st));
+    HIPCHK(c, hipEventCreate(&c->ev0));
+    HIPCHK(c, hipEventCreate(&c->ev1));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 64, hipHostMallocDefault));
+    c->bf16 = d.dtype == CW_DTYPE_BF16;
+    c->esz = c->bf16 ? 2 : 4;
+    c->Bm = Bm;
+    c->S_pad = 1536;
+    const size_t e = c->esz;
+    const int TGT = d.max_target_positions;
+
+    // ---- weights
+    CWCHK(c, dmalloc(c, &c->conv1_w, (size_t)D * 3 * d.n_mels * e));
+    CWCHK(c, dmalloc(c, &c->conv2_w, (size_t)D * 3 * D * e));
+    CWCHK(c, dmalloc(c, &c->conv1_b, (size_t)D * 4));
+    CWCHK(c, dmalloc(c, &c->conv2_b, (size_t)D * 4));
+    CWCHK(c, dmalloc(c, &c->enc_pos, (size_t)CW_N_CTX * D * 4));
+    CWCHK(c, dmalloc(c, &c->dec_pos, (size_t)TGT * D * 4));
+    CWCHK(c, dmalloc(c, &c->embed, (size_t)V * D * e));
+    CWCHK(c, dmalloc(c, &c->enc_ln_g, D * 4)); CWCHK(c, dmalloc(c, &c->enc_ln_b, D * 4));
+    CWCHK(c, dmalloc(c, &c->dec_ln_g, D * 4)); CWCHK(c, dmalloc(c, &c->dec_ln_b, D * 4));
+    c->enc.resize(d.enc_layers);
+    c->dec.resize(d.dec_layers);
+    auto alloc_common = [&](LayerW& L) -> int {
+        CWCHK(c, dmalloc(c, &L.wqkv, (size_t)3 * D * D * e)); CWCHK(c, dmalloc(c, &L.bqkv, (size_t)3 * D * 4));
+        CWCHK(c, dmalloc(c, &L.wo, (size_t)D * D * e)); CWCHK(c, dmalloc(c, &L.bo, D * 4));
+        CWCHK(c, dmalloc(c, &L.ln1_g, D * 4)); CWCHK(c, dmalloc(c, &L.ln1_b, D * 4));
+        CWCHK(c, dmalloc(c, &L.w1, (size_t)F * D * e)); CWCHK(c, dmalloc(c, &L.b1, F * 4));
+        CWCHK(c, dmalloc(c, &L.w2, (size_t)D * F * e)); CWCHK(c, dmalloc(c, &L.b2, D * 4));
+        CWCHK(c, dmalloc(c, &L.ln2_g, D * 4)); CWCHK(c, dmalloc(c, &L.ln2_b, D * 4));
+        return CW_OK;
+    };
+    for (auto& L : c->enc) CWCHK(c, alloc_common(L));
+    for (auto& L : c->dec) {
+        CWCHK(c, alloc_common(L));
+        CWCHK(c, dmalloc(c, &L.wq_c, (size_t)D * D * e)); CWCHK(c, dmalloc(c, &L.bq_c, D * 4));
+        CWCHK(c, dmalloc(c, &L.wkv_c, (size_t)2 * D * D * e)); CWCHK(c, dmalloc(c, &L.bkv_c, (size_t)2 * D * 4));
+        CWCHK(c, dmalloc(c, &L.wo_c, (size_t)D * D * e)); CWCHK(c, dmalloc(c, &L.bo_c, D * 4));
+        CWCHK(c, dmalloc(c, &L.lnc_g, D * 4)); CWCHK(c, dmalloc(c, &L.lnc_b, D * 4));
+        CWCHK(c, dmalloc(c, &L.ck, (size_t)Bm * H * CW_N_CTX * 64 * e));
+        CWCHK(c, dmalloc(c, &L.cv, (size_t)Bm * H * CW_N_CTX * 64 * e));
+        CWCHK(c, dmalloc(c, &L.sk, (size_t)Bm * H * TGT * 64 * e));
+        CWCHK(c, dmalloc(c, &L.sv, (size_t)Bm * H * TGT * 64 * e));
+    }
+
+    // ---- mel tables (host-computed: identical on every box)
+    {
+        std::vector<double> ct(400), sn(400), win(400);
+        for (int i = 0; i < 400; ++i) {
+            ct[i] = cos(2.0 * M_PI * i / 400.0);
+            sn[i] = sin(2.0 * M_PI * i / 400.0);
+            win[i] = (double)(float)(0.5 - 0.5 * cos(2.0 * M_PI * i / 400.0));  // torch.hann_window is f32
+        }
+        double *dct, *dsn, *dwin;
+        CWCHK(c, dmalloc(c, &dct, 400 * 8)); CWCHK(c, dmalloc(c, &dsn, 400 * 8)); CWCHK(c, dmalloc(c, &dwin, 400 * 8));
+        HIPCHK(c, hipMemcpy(dct, ct.data(), 400 * 8, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(dsn, sn.data(), 400 * 8, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(dwin, win.data(), 400 * 8, hipMemcpyHostToDevice));
+        // slaney mel filterbank, TF/audio_utils.py:448-560, 700-720 (float64 maths, cast to f32 at use)
+        const int nm = d.n_mels, nb = 201;
+        auto hz2mel = [](double f) { return f >= 1000.0 ? 15.0 + log(f / 1000.0) * (27.0 / log(6.4)) : 3.0 * f / 200.0; };
+        auto mel2hz = [](double m) { return m >= 15.0 ? 1000.0 * exp((log(6.4) / 27.0) * (m - 15.0)) : 200.0 * m / 3.0; };
+        std::vector<double> ff(nm + 2);
+        const double m_lo = hz2mel(0.0), m_hi = hz2mel(8000.0);
+        for (int i = 0; i < nm + 2; ++i) {
+            double step = (m_hi - m_lo) / (nm + 1);          // np.linspace
+            double mv = (i == nm + 1) ? m_hi : m_lo + step * i;
+            ff[i] = mel2hz(mv);
+        }
+        std::vector<float> fb((size_t)nb * nm);
+        for (int k = 0; k < nb; ++k) {
+            double fk = (k == nb - 1) ? 8000.0 : (8000.0 / (nb - 1)) * k;
+            for (int m = 0; m < nm; ++m) {
+                double down = -(ff[m] - fk) / (ff[m + 1] - ff[m]);
+                double up = (ff[m + 2] - fk) / (ff[m + 2] - ff[m + 1]);
+                double v = fmax(0.0, fmin(down, up));
+                v *= 2.0 / (ff[m + 2] - ff[m]);
+                fb[(size_t)k * nm + m] = (float)v;
+            }
+        }
+        float* dfb;
+        CWCHK(c, dmalloc(c, &dfb, fb.size() * 4));
+        HIPCHK(c, hipMemcpy(dfb, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
+        c->mel.cos_t = dct; c->mel.sin_t = dsn; c->mel.window = dwin; c->mel.filters = dfb;
+    }
+    CWCHK(c, dmalloc(c, &c->d_pcm, (size_t)Bm * CW_N_SAMPLES * 4));
+    CWCHK(c, dmalloc(c, &c->d_logspec, (size_t)Bm * CW_N_FRAMES * d.n_mels * 4));
+    CWCHK(c, dmalloc(c, &c->d_gmax, Bm * 4));
+    CWCHK(c, dmalloc(c, &c->d_feats_tm, (size_t)Bm * CW_N_FRAMES * d.n_mels * e));
+    c->n_frames_items.assign(Bm, CW_N_FRAMES);
+
+    // ---- encoder workspace
+    const size_t MR = (size_t)Bm * CW_N_CTX;
+    CWCHK(c, dmalloc(c, &c->c1, (size_t)Bm * CW_N_FRAMES * D * e));
+    CWCHK(c, dmalloc(c, &c->x, MR * D * 4));
+    CWCHK(c, dmalloc(c, &c->h, MR * D * e));
+    CWCHK(c, dmalloc(c, &c->ao, MR * D * e));
+    CWCHK(c, dmalloc(c, &c->enc_out, MR * D * e));
+    CWCHK(c, dmalloc(c, &c->mid, MR * F * e));
+    CWCHK(c, dmalloc(c, &c->qb, (size_t)Bm * H * c->S_pad * 64 * e));
+    CWCHK(c, dmalloc(c, &c->kb, (size_t)Bm * H * c->S_pad * 64 * e));
+    CWCHK(c, dmalloc(c, &c->vb, (size_t)Bm * H * c->S_pad * 64 * e));
+    CWCHK(c, dmalloc(c, &c->d_row_off, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_row_valid, Bm * 4));
+    CWCHK(c, dmalloc(c, &c->d_row_off2, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_row_valid2, Bm * 4));
+    {
+        std::vector<int> off2(Bm), val2(Bm, CW_N_FRAMES);
+        for (int i = 0; i < Bm; ++i) off2[i] = i * CW_N_FRAMES;
+        HIPCHK(c, hipMemcpy(c->d_row_off2, off2.data(), Bm * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_row_valid2, val2.data(), Bm * 4, hipMemcpyHostToDevice));
+    }
+
+    // ---- decoder state
+    CWCHK(c, dmalloc(c, &c->dx, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dxn, (size_t)Bm * D * 4));
+    CWCHK(c, dmalloc(c, &c->dq, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dattn, (size_t)Bm * D * 4));
+    CWCHK(c, dmalloc(c, &c->dmid, (size_t)Bm * F * 4));
+    CWCHK(c, dmalloc(c, &c->dlogits, (size_t)Bm * V * 4));
+    CWCHK(c, dmalloc(c, &c->d_ids, (size_t)Bm * TGT * 4)); CWCHK(c, dmalloc(c, &c->d_forced, (size_t)Bm * TGT * 4));
+    CWCHK(c, dmalloc(c, &c->d_argmax, (size_t)Bm * TGT * 4));
+    CWCHK(c, dmalloc(c, &c->d_last_ts, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_finished, Bm * 4));
+    CWCHK(c, dmalloc(c, &c->d_nunf, 4));
+    CWCHK(c, dmalloc(c, &c->d_mask, (size_t)V));
+    CWCHK(c, dmalloc(c, &c->d_align_slot, (size_t)d.dec_layers * H * 4));
+    {
+        std::vector<int> slot((size_t)d.dec_layers * H, -1);
+        for (int a = 0; a < d.n_align; ++a) {
+            int l = c->align_layers[a], hh = c->align_heads[a];
+            if (l < 0 || l >= d.dec_layers || hh < 0 || hh >= H) return fail(c, CW_ERR_INVALID, "bad alignment head (%d,%d)", l, hh);
+            slot[(size_t)l * H + hh] = a;
+        }
+        HIPCHK(c, hipMemcpy(c->d_align_slot, slot.data(), slot.size() * 4, hipMemcpyHostToDevice));
+    }
+    const int Ha = d.n_align > 0 ? d.n_align : 1;
+    CWCHK(c, dmalloc(c, &c->d_align, (size_t)Bm * Ha * TGT * CW_N_CTX * 4));
+
+    // ---- timestamps workspace
+    CWCHK(c, dmalloc(c, &c->d_mean, (size_t)Bm * Ha * CW_N_CTX * 4));
+    CWCHK(c, dmalloc(c, &c->d_std, (size_t)Bm * Ha * CW_N_CTX * 4));
+    CWCHK(c, dmalloc(c, &c->d_mat, (size_t)Bm * TGT * CW_N_CTX * 4));
+    CWCHK(c, dmalloc(c, &c->d_trace, (size_t)Bm * TGT * CW_N_CTX));
+    CWCHK(c, dmalloc(c, &c->d_first_col, (size_t)Bm * TGT * 4));
+    CWCHK(c, dmalloc(c, &c->d_path_text, (size_t)Bm * (TGT + CW_N_CTX + 2) * 4));
+    CWCHK(c, dmalloc(c, &c->d_path_time, (size_t)Bm * (TGT + CW_N_CTX + 2) * 4));
+    CWCHK(c, dmalloc(c, &c->d_path_len, Bm * 4));
+    CWCHK(c, dmalloc(c, &c->d_ncols, Bm * 4));
+    HIPCHK(c, hipDeviceSynchronize());
+    return CW_OK;
+}
+
+cw_ctx* cw_create(const cw_model_desc* desc, int32_t device) {
+    if (!desc) { fail(nullptr, CW_ERR_INVALID, "null desc"); return nullptr; }
+    cw_ctx* c = new cw_ctx();
+    c->d = *desc;
+    c->device = device;
+    c->align_layers.assign(desc->align_layers, desc->align_layers + desc->n_align);
+    c->align_heads.assign(desc->align_heads, desc->align_heads + desc->n_align);
+    c->d.align_layers = c->align_layers.data();
+    c->d.align_heads = c->align_heads.data();
+    int r = create_impl(c);
+    if (r != CW_OK) {
+        snprintf(g_err, sizeof(g_err), "%s", c->err);
+        cw_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void cw_destroy(cw_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->st) hipStreamSynchronize(c->st);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->h_nunf) hipHostFree(c->h_nunf);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->st) hipStreamDestroy(c->st);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+int32_t cw_load_tensor(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    const int D = c->d.d_model, F = c->d.ffn_dim, V = c->d.vocab_size, NM = c->d.n_mels;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    auto expect = [&](size_t want) -> int {
+        if (n != want) return fail(c, CW_ERR_INVALID, "tensor %s: %zu elements, expected %zu", name, n, want);
+        return CW_OK;
+    };
+    std::string s(name);
+    if (s == "proj_out.weight") return CW_OK;  // tied to embed_tokens (modeling_whisper.py:965)
+    if (s == "model.encoder.conv1.weight" || s == "model.encoder.conv2.weight") {
+        const bool first = s == "model.encoder.conv1.weight";
+        const int C = first ? NM : D;
+        CWCHK(c, expect((size_t)D * C * 3));
+        std::vector<float> re((size_t)D * 3 * C);  // [O][C][3] -> [O][3][C]
+        for (int o = 0; o < D; ++o)
+            for (int ci = 0; ci < C; ++ci)
+                for (int k = 0; k < 3; ++k) re[((size_t)o * 3 + k) * C + ci] = data[((size_t)o * C + ci) * 3 + k];
+        return upload_T(c, first ? c->conv1_w : c->conv2_w, 0, re.data(), re.size());
+    }
+    if (s == "model.encoder.conv1.bias") { CWCHK(c, expect(D)); return upload_f32(c, c->conv1_b, 0, data, n); }
+    if (s == "model.encoder.conv2.bias") { CWCHK(c, expect(D)); return upload_f32(c, c->conv2_b, 0, data, n); }
+    if (s == "model.encoder.embed_positions.weight") { CWCHK(c, expect((size_t)CW_N_CTX * D)); return upload_f32(c, c->enc_pos, 0, data, n); }
+    if (s == "model.decoder.embed_positions.weight") { CWCHK(c, expect((size_t)c->d.max_target_positions * D)); return upload_f32(c, c->dec_pos, 0, data, n); }
+    if (s == "model.decoder.embed_tokens.weight") { CWCHK(c, expect((size_t)V * D)); return upload_T(c, c->embed, 0, data, n); }
+    if (s == "model.encoder.layer_norm.weight") { CWCHK(c, expect(D)); return upload_f32(c, c->enc_ln_g, 0, data, n); }
+    if (s == "model.encoder.layer_norm.bias") { CWCHK(c, expect(D)); return upload_f32(c, c->enc_ln_b, 0, data, n); }
+    if (s == "model.decoder.layer_norm.weight") { CWCHK(c, expect(D)); return upload_f32(c, c->dec_ln_g, 0, data, n); }
+    if (s == "model.decoder.layer_norm.bias") { CWCHK(c, expect(D)); return upload_f32(c, c->dec_ln_b, 0, data, n); }
+
+    int li = -1; char rest[128] = "";
+    bool is_dec = false;
+    if (sscanf(name, "model.encoder.layers.%d.%127s", &li, rest) == 2) is_dec = false;
+    else if (sscanf(name, "model.decoder.layers.%d.%127s", &li, rest) == 2) is_dec = true;
+    else return fail(c, CW_ERR_INVALID, "unknown tensor name %s", name);
+    if (li < 0 || li >= (is_dec ? c->d.dec_layers : c->d.enc_layers)) return fail(c, CW_ERR_INVALID, "layer index out of range in %s", name);
+    LayerW& L = is_dec ? c->dec[li] : c->enc[li];
+    std::string r(rest);
+    const float qs = 0.125f;  // head_dim ** -0.5, folded into q projections (exact: power of two)
+    const size_t DD = (size_t)D * D;
+    if (r == "self_attn.q_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wqkv, 0, data, n, qs); }
+    if (r == "self_attn.k_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wqkv, DD, data, n); }
+    if (r == "self_attn.v_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wqkv, 2 * DD, data, n); }
+    if (r == "self_attn.q_proj.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.bqkv, 0, data, n, qs); }
+    if (r == "self_attn.v_proj.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.bqkv, 2 * (size_t)D, data, n); }
+    if (r == "self_attn.out_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wo, 0, data, n); }
+    if (r == "self_attn.out_proj.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.bo, 0, data, n); }
+    if (r == "self_attn_layer_norm.weight") { CWCHK(c, expect(D)); return upload_f32(c, L.ln1_g, 0, data, n); }
+    if (r == "self_attn_layer_norm.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.ln1_b, 0, data, n); }
+    if (r == "fc1.weight") { CWCHK(c, expect((size_t)F * D)); return upload_T(c, L.w1, 0, data, n); }
+    if (r == "fc1.bias") { CWCHK(c, expect(F)); return upload_f32(c, L.b1, 0, data, n); }
+    if (r == "fc2.weight") { CWCHK(c, expect((size_t)F * D)); return upload_T(c, L.w2, 0, data, n); }
+    if (r == "fc2.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.b2, 0, data, n); }
+    if (r == "final_layer_norm.weight") { CWCHK(c, expect(D)); return upload_f32(c, L.ln2_g, 0, data, n); }
+    if (r == "final_layer_norm.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.ln2_b, 0, data, n); }
+    if (is_dec) {
+        if (r == "encoder_attn.q_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wq_c, 0, data, n, qs); }
+        if (r == "encoder_attn.q_proj.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.bq_c, 0, data, n, qs); }
+        if (r == "encoder_attn.k_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wkv_c, 0, data, n); }
+        if (r == "encoder_attn.v_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wkv_c, DD, data, n); }
+        if (r == "encoder_attn.v_proj.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.bkv_c, (size_t)D, data, n); }
+        if (r == "encoder_attn.out_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wo_c, 0, data, n); }
+        if (r == "encoder_attn.out_proj.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.bo_c, 0, data, n); }
+        if (r == "encoder_attn_layer_norm.weight") { CWCHK(c, expect(D)); return upload_f32(c, L.lnc_g, 0, data, n); }
+        if (r == "encoder_attn_layer_norm.bias") { CWCHK(c, expect(D)); return upload_f32(c, L.lnc_b, 0, data, n); }
+    }
+    return fail(c, CW_ERR_INVALID, "unknown tensor name %s", name);
+}
+
+int32_t cw_set_generation(cw_ctx* c, const cw_gen_cfg* g) {
+    const int V = c->d.vocab_size;
+    std::vector<unsigned char> mask(V, 0);
+    for (int i = 0; i < g->n_suppress; ++i) {
+        int t = g->suppress_tokens[i];
+        if (t < 0 || t >= V) return fail(c, CW_ERR_INVALID, "suppress token %d out of range", t);
+        mask[t] |= 1;
+    }
+    for (int i = 0; i < g->n_begin_suppress; ++i) {
+        int t = g->begin_suppress_tokens[i];
+        if (t < 0 || t >= V) return fail(c, CW_ERR_INVALID, "begin-suppress token %d out of range", t);
+        mask[t] |= 2;
+    }
+    if (g->no_timestamps_token_id < 0 || g->no_timestamps_token_id + 1 >= V) return fail(c, CW_ERR_INVALID, "no_timestamps_token_id out of range");
+    mask[g->no_timestamps_token_id] |= 1;  // logits_process.py:2003
+    HIPCHK(c, hipMemcpy(c->d_mask, mask.data(), V, hipMemcpyHostToDevice));
+    c->gen = *g;
+    c->gen.suppress_tokens = nullptr;
+    c->gen.begin_suppress_tokens = nullptr;
+    c->gen_set = true;
+    return CW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// front end
+// ------------------------------------------------------------------------------------------------
+int32_t cw_upload_pcm(cw_ctx* c, const float* pcm, int32_t B, const int32_t* n_samples) {
+    if (B < 1 || B > c->Bm) return fail(c, CW_ERR_INVALID, "B=%d out of range (max_batch %d)", B, c->Bm);
+    HIPCHK(c, hipMemsetAsync(c->d_pcm, 0, (size_t)B * CW_N_SAMPLES * 4, c->st));
+    size_t off = 0;
+    for (int b = 0; b < B; ++b) {
+        int n = n_samples[b];
+        if (n < 0 || n > CW_N_SAMPLES) return fail(c, CW_ERR_INVALID, "n_samples[%d]=%d out of range", b, n);
+        HIPCHK(c, hipMemcpyAsync(c->d_pcm + (size_t)b * CW_N_SAMPLES, pcm + off, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
+        off += n;
+        c->n_frames_items[b] = (n + 159) / 160;  // attention_mask[:, ::hop].sum()  (feature_extraction_whisper.py:332-341)
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return CW_OK;
+}
+
+int32_t cw_mel_resident(cw_ctx* c, int32_t B) {
+    if (B < 1 || B > c->Bm) return fail(c, CW_ERR_INVALID, "B=%d out of range", B);
+    StageTimer tm(c, CW_STAGE_MEL);
+    CWCHK(c, cw_launch_mel(c->mel, c->d_pcm, B, c->d.n_mels, c->d_logspec, c->d_gmax, c->st));
+    CWCHK(c, cw_launch_mel_finish(c->d_logspec, c->d_gmax, B, c->d.n_mels, c->d_feats_tm, c->bf16 ? 1 : 0, c->d_feats_hf, c->st));
+    KCHK(c);
+    tm.stop();
+    return CW_OK;
+}
+
+int32_t cw_mel(cw_ctx* c, const float* pcm, int32_t B, const int32_t* n_samples, float* feats_out, int32_t* n_frames_out) {
+    CWCHK(c, cw_upload_pcm(c, pcm, B, n_samples));
+    if (feats_out && !c->d_feats_hf) CWCHK(c, dmalloc(c, &c->d_feats_hf, (size_t)c->Bm * CW_N_FRAMES * c->d.n_mels * 4));
+    float* keep = c->d_feats_hf;
+    if (!feats_out) c->d_feats_hf = nullptr;
+    int r = cw_mel_resident(c, B);
+    c->d_feats_hf = keep;
+    if (r != CW_OK) return r;
+    if (feats_out) HIPCHK(c, hipMemcpy(feats_out, c->d_feats_hf, (size_t)B * CW_N_FRAMES * c->d.n_mels * 4, hipMemcpyDeviceToHost));
+    if (n_frames_out) for (int b = 0; b < B; ++b) n_frames_out[b] = c->n_frames_items[b];
+    return CW_OK;
+}
+
+int32_t cw_set_features(cw_ctx* c, const float* feats, int32_t B) {
+    if (B < 1 || B > c->Bm) return fail(c, CW_ERR_INVALID, "B=%d out of range", B);
+    const int NM = c->d.n_mels;
+    std::vector<float> tmaj((size_t)B * CW_N_FRAMES * NM);
+    for (int b = 0; b < B; ++b)
+        for (int m = 0; m < NM; ++m)
+            for (int t = 0; t < CW_N_FRAMES; ++t)
+                tmaj[((size_t)b * CW_N_FRAMES + t) * NM + m] = feats[((size_t)b * NM + m) * CW_N_FRAMES + t];
+    return upload_T(c, c->d_feats_tm, 0, tmaj.data(), tmaj.size());
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------
+static EpiParams epi0() { EpiParams p; memset(&p, 0, sizeof(p)); return p; }
+
+int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* seek, const int32_t* n_frames) {
+    const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, NM = c->d.n_mels, S = CW_N_CTX;
+    if (nb < 1 || nb > c->Bm) return fail(c, CW_ERR_INVALID, "nb=%d out of range", nb);
+    std::vector<int> off(nb), val(nb);
+    for (int i = 0; i < nb; ++i) {
+        if (item[i] < 0 || item[i] >= c->Bm || seek[i] < 0 || n_frames[i] < 0 || seek[i] + n_frames[i] > CW_N_FRAMES)
+            return fail(c, CW_ERR_INVALID, "bad window %d: item=%d seek=%d n=%d", i, item[i], seek[i], n_frames[i]);
+        off[i] = item[i] * CW_N_FRAMES + seek[i];
+        val[i] = n_frames[i];
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_row_off, off.data(), nb * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->d_row_valid, val.data(), nb * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));  // host vectors go out of scope
+    const bool bf = c->bf16;
+    StageTimer tm(c, CW_STAGE_ENCODER);
+    {   // conv1 + GELU (modeling_whisper.py:618) as implicit GEMM over time-major features
+        AParams ap{c->d_feats_tm, 0, 1, CW_N_FRAMES, NM, 1, c->d_row_off, c->d_row_valid};
+        EpiParams ep = epi0(); ep.out = c->c1; ep.bias = c->conv1_b; ep.ldo = D;
+        CWCHK(c, cw_launch_gemm(bf, EPI_GELU, ap, c->conv1_w, nb * CW_N_FRAMES, D, 3 * NM, ep, c->st));
+    }
+    {   // conv2 (stride 2) + GELU + sinusoidal positions (:619-624) -> f32 residual stream
+        AParams ap{c->c1, 0, 1, S, D, 2, c->d_row_off2, c->d_row_valid2};
+        EpiParams ep = epi0(); ep.outf = c->x; ep.bias = c->conv2_b; ep.ldo = D; ep.pos = c->enc_pos; ep.T = S;
+        CWCHK(c, cw_launch_gemm(bf, EPI_GELU_POS_F32, ap, c->conv2_w, nb * S, D, 3 * D, ep, c->st));
+    }
+    const int M = nb * S;
+    for (int l = 0; l < c->d.enc_layers; ++l) {
+        LayerW& L = c->enc[l];
+        CWCHK(c, cw_launch_layernorm(bf, c->x, L.ln1_g, L.ln1_b, c->h, M, D, c->st));
+        {
+            AParams ap{c->h, D, 0, 0, 0, 0, nullptr, nullptr};
+            EpiParams ep = epi0(); ep.out = c->qb; ep.out1 = c->kb; ep.out2 = c->vb; ep.bias = L.bqkv;
+            ep.T = S; ep.S_pad = c->S_pad; ep.H = H; ep.d_model = D;
+            CWCHK(c, cw_launch_gemm(bf, EPI_HEADS, ap, L.wqkv, M, 3 * D, D, ep, c->st));
+        }
+        CWCHK(c, cw_launch_attn_encoder(bf, c->qb, c->kb, c->vb, c->ao, nb, H, S, c->S_pad, c->st));
+        {
+            AParams ap{c->ao, D, 0, 0, 0, 0, nullptr, nullptr};
+            EpiParams ep = epi0(); ep.outf = c->x; ep.resid = c->x; ep.bias = L.bo; ep.ldo = D;
+            CWCHK(c, cw_launch_gemm(bf, EPI_RESID_F32, ap, L.wo, M, D, D, ep, c->st));
+        }
+        CWCHK(c, cw_launch_layernorm(bf, c->x, L.ln2_g, L.ln2_b, c->h, M, D, c->st));
+        {
+            AParams ap{c->h, D, 0, 0, 0, 0, nullptr, nullptr};
+            EpiParams ep = epi0(); ep.out = c->mid; ep.bias = L.b1; ep.ldo = F;
+            CWCHK(c, cw_launch_gemm(bf, EPI_GELU, ap, L.w1, M, F, D, ep, c->st));
+        }
+        {
+            AParams ap{c->mid, F, 0, 0, 0, 0, nullptr, nullptr};
+            EpiParams ep = epi0(); ep.outf = c->x; ep.resid = c->x; ep.bias = L.b2; ep.ldo = D;
+            CWCHK(c, cw_launch_gemm(bf, EPI_RESID_F32, ap, L.w2, M, D, F, ep, c->st));
+        }
+    }
+    CWCHK(c, cw_launch_layernorm(bf, c->x, c->enc_ln_g, c->enc_ln_b, c->enc_out, M, D, c->st));
+    KCHK(c);
+    tm.stop();
+    StageTimer tk(c, CW_STAGE_CROSS_KV);
+    for (int l = 0; l < c->d.dec_layers; ++l) {   // cross-attention K/V, once per window (:322-335)
+        LayerW& L = c->dec[l];
+        AParams ap{c->enc_out, D, 0, 0, 0, 0, nullptr, nullptr};
+        EpiParams ep = epi0(); ep.out = L.ck; ep.out1 = L.cv; ep.bias = L.bkv_c;
+        ep.T = S; ep.S_pad = S; ep.H = H; ep.d_model = D;
+        CWCHK(c, cw_launch_gemm(bf, EPI_HEADS, ap, L.wkv_c, M, 2 * D, D, ep, c->st));
+    }
+    KCHK(c);
+    tk.stop();
+    c->nb_encoded = nb;
+    return CW_OK;
+}
+
+int32_t cw_get_encoder_output(cw_ctx* c, float* out, int32_t nb) {
+    if (nb < 1 || nb > c->nb_encoded) return fail(c, CW_ERR_STATE, "only %d windows encoded", c->nb_encoded);
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return download_T(c, c->enc_out, 0, out, (size_t)nb * CW_N_CTX * c->d.d_model);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder
+// ------------------------------------------------------------------------------------------------
+static int gemv_ln(cw_ctx* c, int epi, const float* x, int Mb, int K, const void* W, int N, const float* g,
+                   const float* b, const EpiParams& ep) {
+    if (c->bf16 || !g) return cw_launch_gemv(c->bf16, epi, x, Mb, K, W, N, g, b, ep, c->st);
+    int r = cw_launch_layernorm_f32(x, g, b, c->dxn, Mb, K, c->st);   // f32 parity mode: unfused LN
+    if (r != CW_OK) return r;
+    return cw_launch_gemv(false, epi, c->dxn, Mb, K, W, N, nullptr, nullptr, ep, c->st);
+}
+
+static int decode_step(cw_ctx* c, int nb, int pos, bool want_logits) {
+    const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, V = c->d.vocab_size;
+    const int TGT = c->d.max_target_positions;
+    for (int l = 0; l < c->d.dec_layers; ++l) {
+        LayerW& L = c->dec[l];
+        {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at `pos`
+            EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
+            ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.pos_row = pos;
+            CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, L.ln1_b, ep));
+        }
+        {
+            DecAttnParams p{c->dq, L.sk, L.sv, TGT, pos + 1, c->dattn, nullptr, nullptr, 0, 0, 0, nb, H};
+            CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
+        }
+        {
+            EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
+            CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));
+        }
+        {   // cross-attention: LN + q projection, attention over the cached encoder K/V
+            EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
+            CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, L.lnc_b, ep));
+        }
+        {
+            DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->dattn,
+                            c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_slot + (size_t)l * H,
+                            c->d.n_align, TGT, pos, nb, H};
+            CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
+        }
+        {
+            EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
+            CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo_c, D, nullptr, nullptr, ep));
+        }
+        {
+            EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
+            CWCHK(c, gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep));
+        }
+        {
+            EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.b2; ep.ldo = D;
+            CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
+        }
+    }
+    if (want_logits) {   // final LN + tied proj_out (:790, :1080), logits in f32 (utils.py:2894)
+        EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = V;
+        CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep));
+    }
+    return CW_OK;
+}
+
+int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt, int32_t max_length,
+                  int32_t min_new_tokens, const int32_t* forced, int32_t* sequences, int32_t* lengths,
+                  int32_t* argmax_out) {
+    const int D = c->d.d_model, V = c->d.vocab_size, TGT = c->d.max_target_positions;
+    if (!c->gen_set) return fail(c, CW_ERR_STATE, "cw_set_generation not called");
+    if (nb < 1 || nb > c->nb_encoded) return fail(c, CW_ERR_STATE, "nb=%d but %d windows encoded", nb, c->nb_encoded);
+    if (n_prompt < 1 || n_prompt >= TGT) return fail(c, CW_ERR_INVALID, "n_prompt=%d out of range", n_prompt);
+    if (max_length <= n_prompt || max_length > TGT) return fail(c, CW_ERR_INVALID, "max_length=%d out of range (n_prompt %d, max_target %d)", max_length, n_prompt, TGT);
+    std::vector<int> ids((size_t)nb * TGT, c->gen.pad_token_id);
+    for (int b = 0; b < nb; ++b)
+        for (int t = 0; t < n_prompt; ++t) {
+            int tok = prompt[(size_t)b * n_prompt + t];
+            if (tok < 0 || tok >= V) return fail(c, CW_ERR_INVALID, "prompt token %d out of range", tok);
+            ids[(size_t)b * TGT + t] = tok;
+        }
+    HIPCHK(c, hipMemcpyAsync(c->d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->st));
+    if (forced) HIPCHK(c, hipMemcpyAsync(c->d_forced, forced, (size_t)nb * TGT * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_finished, 0, nb * 4, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_last_ts, 0xff, nb * 4, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_argmax, 0xff, (size_t)nb * TGT * 4, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    StageTimer tm(c, CW_STAGE_DECODE);
+
+    for (int pos = 0; pos < n_prompt; ++pos) {
+        CWCHK(c, cw_launch_embed(c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
+        CWCHK(c, decode_step(c, nb, pos, pos == n_prompt - 1));
+    }
+    int t = n_prompt, step = 0;
+    for (;;) {
+        if (c->logits_capture && step < c->logits_capture_steps)
+            HIPCHK(c, hipMemcpyAsync(c->logits_capture + (size_t)step * nb * V, c->dlogits, (size_t)nb * V * 4, hipMemcpyDeviceToHost, c->st));
+        SampleParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.logits = c->dlogits; sp.V = V; sp.B = nb; sp.mask = c->d_mask;
+        sp.eos = c->gen.eos_token_id; sp.pad = c->gen.pad_token_id;
+        sp.timestamp_begin = c->gen.no_timestamps_token_id + 1;
+        sp.max_initial_timestamp_index = c->gen.max_initial_timestamp_index;
+        sp.n_prompt = n_prompt; sp.t = t; sp.min_new_tokens = min_new_tokens; sp.max_length = max_length;
+        sp.ids_stride = TGT; sp.ids = c->d_ids; sp.forced = forced ? c->d_forced : nullptr;
+        sp.argmax_trace = c->d_argmax; sp.last_ts_tok = c->d_last_ts; sp.finished = c->d_finished;
+        sp.n_unfinished = c->d_nunf;
+        sp.embed = c->embed; sp.pos_embed = c->dec_pos; sp.x_out = c->dx; sp.d = D; sp.embed_bf16 = c->bf16 ? 1 : 0;
+        CWCHK(c, cw_launch_sample(sp, c->st));
+        HIPCHK(c, hipMemcpyAsync(c->h_nunf, c->d_nunf, 4, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        ++step;
+        ++t;                               // sequence length is now t
+        if (*c->h_nunf == 0 || t >= max_length) break;
+        CWCHK(c, decode_step(c, nb, t - 1, true));
+    }
+    KCHK(c);
+    tm.stop();
+    HIPCHK(c, hipMemcpy(ids.data(), c->d_ids, ids.size() * 4, hipMemcpyDeviceToHost));
+    memcpy(sequences, ids.data(), ids.size() * 4);
+    // per-row length: up to and including the first eos among generated tokens, else t
+    for (int b = 0; b < nb; ++b) {
+        int len = t;
+        for (int k = n_prompt; k < t; ++k)
+            if (ids[(size_t)b * TGT + k] == c->gen.eos_token_id) { len = k + 1; break; }
+        lengths[b] = len;
+    }
+    if (argmax_out) HIPCHK(c, hipMemcpy(argmax_out, c->d_argmax, (size_t)nb * TGT * 4, hipMemcpyDeviceToHost));
+    c->last_L = t - 1;   // attention rows retained: one per decoder input position
+    c->last_nb = nb;
+    return CW_OK;
+}
+
+int32_t cw_get_logits(cw_ctx* c, float* out, int32_t nb) {
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipMemcpy(out, c->dlogits, (size_t)nb * c->d.vocab_size * 4, hipMemcpyDeviceToHost));
+    return CW_OK;
+}
+
+int32_t cw_set_logits_capture(cw_ctx* c, float* host_buf, int32_t max_steps) {
+    c->logits_capture = host_buf;
+    c->logits_capture_steps = host_buf ? max_steps : 0;
+    return CW_OK;
+}
+
+int32_t cw_get_alignment(cw_ctx* c, float* out, int32_t nb, int32_t L) {
+    const int Ha = c->d.n_align, TGT = c->d.max_target_positions;
+    if (Ha <= 0) return fail(c, CW_ERR_STATE, "no alignment heads configured");
+    if (nb > c->last_nb || L > c->last_L) return fail(c, CW_ERR_STATE, "only %d x %d rows retained", c->last_nb, c->last_L);
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    for (int b = 0; b < nb; ++b)
+        for (int a = 0; a < Ha; ++a)
+            HIPCHK(c, hipMemcpy(out + (((size_t)b * Ha + a) * L) * CW_N_CTX,
+                                c->d_align + (((size_t)b * Ha + a) * TGT) * CW_N_CTX, (size_t)L * CW_N_CTX * 4,
+                                hipMemcpyDeviceToHost));
+    return CW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// token timestamps
+// ------------------------------------------------------------------------------------------------
+static int run_alignment(cw_ctx* c, const float* w, int B, int Ha, int rows_cap, int S, int row0, int N,
+                         const int* d_ncols, int width, float* mean, float* stdv, float* mat) {
+    CWCHK(c, cw_launch_align_stats(w, B, Ha, rows_cap, S, row0, N, d_ncols, mean, stdv, c->st));
+    CWCHK(c, cw_launch_align_filter(w, B, Ha, rows_cap, S, row0, N, d_ncols, mean, stdv, width, mat, c->st));
+    return CW_OK;
+}
+
+int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, const int32_t* num_frames, float* ts_out) {
+    const int Ha = c->d.n_align, TGT = c->d.max_target_positions, S = CW_N_CTX;
+    if (Ha <= 0) return fail(c, CW_ERR_STATE, "no alignment heads configured");
+    if (nb < 1 || nb > c->last_nb || L != c->last_L) return fail(c, CW_ERR_STATE, "rows retained: %d x %d, asked %d x %d", c->last_nb, c->last_L, nb, L);
+    for (size_t i = 0; i < (size_t)nb * (L + 1); ++i) ts_out[i] = 0.f;
+    const int N = L - n_prompt;
+    if (N <= 0) return CW_OK;                     // generation_whisper.py:336-338
+    // Columns reaching the DTW, with HF's exact slicing semantics (:318-323 + :354): python-style
+    // `[..., : nf // 2]`, applied twice when every item has the same num_frames, once otherwise.
+    // nf <= 0 happens when the seek loop ran past the valid audio; it may leave zero columns.
+    std::vector<int> ncols(nb);
+    bool uniform = true;
+    for (int b = 1; b < nb; ++b) uniform = uniform && (num_frames[b] == num_frames[0]);
+    auto floordiv2 = [](int v) { return (v >= 0) ? v / 2 : -((-v + 1) / 2); };
+    auto slice_len = [](int n, int h) { return h >= 0 ? (h < n ? h : n) : (n + h > 0 ? n + h : 0); };
+    bool any_cols = false;
+    for (int b = 0; b < nb; ++b) {
+        int h = floordiv2(num_frames[b]);
+        int n1 = slice_len(S, h);
+        ncols[b] = uniform ? slice_len(n1, h) : n1;
+        any_cols = any_cols || ncols[b] > 0;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ncols, ncols.data(), nb * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    StageTimer tm(c, CW_STAGE_TIMESTAMPS);
+    CWCHK(c, run_alignment(c, c->d_align, nb, Ha, TGT, S, n_prompt, N, c->d_ncols, c->d.median_filter_width, c->d_mean, c->d_std, c->d_mat));
+    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->d_path_text, c->d_path_time, c->d_path_len, c->st));
+    KCHK(c);
+    tm.stop();
+    std::vector<int> fc((size_t)nb * N);
+    HIPCHK(c, hipMemcpy(fc.data(), c->d_first_col, fc.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; ++b) {
+        float* ts = ts_out + (size_t)b * (L + 1);
+        for (int i = 0; i < N; ++i) {
+            // zero columns: the reference's backtrace walks up column 0 -> time index -1 for every token
+            int col = ncols[b] > 0 ? fc[(size_t)b * N + i] : -1;
+            ts[n_prompt + i] = (float)((double)col * 0.02);                                          // :369
+        }
+        ts[L] = ts[L - 1];                                                                          // :377-379
+    }
+    return CW_OK;
+}
+
+int32_t cw_align_matrix(cw_ctx* c, const float* attn, int32_t B, int32_t Ha, int32_t N, int32_t M, const int32_t* n_cols,
+                        int32_t width, float* mat_out) {
+    float *dw = nullptr, *dmean = nullptr, *dstd = nullptr, *dmat = nullptr; int* dn = nullptr;
+    size_t nw = (size_t)B * Ha * N * M;
+    HIPCHK(c, hipMalloc((void**)&dw, nw * 4)); HIPCHK(c, hipMalloc((void**)&dmean, (size_t)B * Ha * M * 4));
+    HIPCHK(c, hipMalloc((void**)&dstd, (size_t)B * Ha * M * 4)); HIPCHK(c, hipMalloc((void**)&dmat, (size_t)B * N * M * 4));
+    HIPCHK(c, hipMalloc((void**)&dn, B * 4));
+    HIPCHK(c, hipMemcpy(dw, attn, nw * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dn, n_cols, B * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(dmat, 0, (size_t)B * N * M * 4));
+    int r = run_alignment(c, dw, B, Ha, N, M, 0, N, dn, width, dmean, dstd, dmat);
+    if (r == CW_OK) {
+        hipError_t e = hipStreamSynchronize(c->st);
+        if (e == hipSuccess) e = hipMemcpy(mat_out, dmat, (size_t)B * N * M * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) r = fail(c, CW_ERR_HIP, "align_matrix: %s", hipGetErrorString(e));
+    }
+    hipFree(dw); hipFree(dmean); hipFree(dstd); hipFree(dmat); hipFree(dn);
+    return r;
+}
+
+int32_t cw_dtw(cw_ctx* c, const float* mat, int32_t N, int32_t M, int32_t* text_idx, int32_t* time_idx, int32_t* path_len) {
+    if (N < 1 || N > 512 || M < 1) return fail(c, CW_ERR_INVALID, "dtw: N=%d M=%d unsupported", N, M);
+    float* dmat = nullptr; unsigned char* dtr = nullptr; int *dfc = nullptr, *dpt = nullptr, *dpj = nullptr, *dpl = nullptr, *dn = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dmat, (size_t)N * M * 4)); HIPCHK(c, hipMalloc((void**)&dtr, (size_t)N * M));
+    HIPCHK(c, hipMalloc((void**)&dfc, N * 4)); HIPCHK(c, hipMalloc((void**)&dpt, (size_t)(N + M + 2) * 4));
+    HIPCHK(c, hipMalloc((void**)&dpj, (size_t)(N + M + 2) * 4)); HIPCHK(c, hipMalloc((void**)&dpl, 4)); HIPCHK(c, hipMalloc((void**)&dn, 4));
+    HIPCHK(c, hipMemcpy(dmat, mat, (size_t)N * M * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dn, &M, 4, hipMemcpyHostToDevice));
+    int r = cw_launch_dtw(dmat, 1, N, M, dn, dtr, dfc, dpt, dpj, dpl, c->st);
+    if (r == CW_OK) {
+        std::vector<int> pt(N + M + 2), pj(N + M + 2);
+        int n = 0;
+        hipError_t e = hipStreamSynchronize(c->st);
+        if (e == hipSuccess) e = hipMemcpy(&n, dpl, 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(pt.data(), dpt, pt.size() * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(pj.data(), dpj, pj.size() * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) r = fail(c, CW_ERR_HIP, "dtw: %s", hipGetErrorString(e));
+        else {
+            for (int k = 0; k < n; ++k) { text_idx[k] = pt[n - 1 - k]; time_idx[k] = pj[n - 1 - k]; }
+            *path_len = n;
+        }
+    } else {
+        fail(c, r, "dtw launch rejected N=%d", N);
+    }
+    hipFree(dmat); hipFree(dtr); hipFree(dfc); hipFree(dpt); hipFree(dpj); hipFree(dpl); hipFree(dn);
+    return r;
+}
+
+int32_t cw_adjust_pauses(cw_ctx* c, double* start, double* end, int32_t W, double thr) {
+    if (W <= 0) return CW_OK;
+    double *ds = nullptr, *de = nullptr;
+    HIPCHK(c, hipMalloc((void**)&ds, (size_t)W * 16)); HIPCHK(c, hipMalloc((void**)&de, (size_t)W * 16));
+    HIPCHK(c, hipMemcpy(ds, start, (size_t)W * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(de, end, (size_t)W * 8, hipMemcpyHostToDevice));
+    int r = cw_launch_pauses(ds, de, W, thr, c->st);
+    hipError_t e = hipStreamSynchronize(c->st);
+    if (e == hipSuccess) e = hipMemcpy(start, ds + W, (size_t)W * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(end, de + W, (size_t)W * 8, hipMemcpyDeviceToHost);
+    hipFree(ds); hipFree(de);
+    if (e != hipSuccess) return fail(c, CW_ERR_HIP, "adjust_pauses: %s", hipGetErrorString(e));
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel-level test hooks
+// ------------------------------------------------------------------------------------------------
+int32_t cw_test_gemm(cw_ctx* c, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias,
+                     int32_t gelu, float* out) {
+    void *dA = nullptr, *dW = nullptr, *dO = nullptr; float* dB = nullptr;
+    const size_t e = c->esz;
+    HIPCHK(c, hipMalloc(&dA, (size_t)M * K * e)); HIPCHK(c, hipMalloc(&dW, (size_t)N * K * e));
+    HIPCHK(c, hipMalloc(&dO, (size_t)M * N * e)); HIPCHK(c, hipMalloc((void**)&dB, (size_t)N * 4));
+    CWCHK(c, upload_T(c, dA, 0, A, (size_t)M * K)); CWCHK(c, upload_T(c, dW, 0, W, (size_t)N * K));
+    if (bias) HIPCHK(c, hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    AParams ap{dA, K, 0, 0, 0, 0, nullptr, nullptr};
+    EpiParams ep = epi0(); ep.out = dO; ep.bias = bias ? dB : nullptr; ep.ldo = N;
+    int r = cw_launch_gemm(c->bf16, gelu ? EPI_GELU : EPI_STORE, ap, dW, M, N, K, ep, c->st);
+    if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemm: %s", hipGetErrorString(er)); }
+    if (r == CW_OK) r = download_T(c, dO, 0, out, (size_t)M * N);
+    hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dB);
+    return r;
+}
+
+int32_t cw_test_gemv(cw_ctx* c, int32_t Mb, int32_t N, int32_t K, const float* x, const float* W, const float* bias,
+                     const float* ln_g, const float* ln_b, int32_t gelu, float* out) {
+    float *dx = nullptr, *dB = nullptr, *dO = nullptr, *dg = nullptr, *db = nullptr, *dxn = nullptr; void* dW = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dx, (size_t)Mb * K * 4)); HIPCHK(c, hipMalloc(&dW, (size_t)N * K * c->esz));
+    HIPCHK(c, hipMalloc((void**)&dO, (size_t)Mb * N * 4)); HIPCHK(c, hipMalloc((void**)&dB, (size_t)N * 4));
+    HIPCHK(c, hipMalloc((void**)&dg, (size_t)K * 4)); HIPCHK(c, hipMalloc((void**)&db, (size_t)K * 4));
+    HIPCHK(c, hipMalloc((void**)&dxn, (size_t)Mb * K * 4));
+    HIPCHK(c, hipMemcpy(dx, x, (size_t)Mb * K * 4, hipMemcpyHostToDevice));
+    CWCHK(c, upload_T(c, dW, 0, W, (size_t)N * K));
+    if (bias) HIPCHK(c, hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (ln_g) { HIPCHK(c, hipMemcpy(dg, ln_g, (size_t)K * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(db, ln_b, (size_t)K * 4, hipMemcpyHostToDevice)); }
+    EpiParams ep = epi0(); ep.outf = dO; ep.bias = bias ? dB : nullptr; ep.ldo = N;
+    int r = CW_OK;
+    const float* xin = dx;
+    if (ln_g && !c->bf16) { r = cw_launch_layernorm_f32(dx, dg, db, dxn, Mb, K, c->st); xin = dxn; }
+    if (r == CW_OK) r = cw_launch_gemv(c->bf16, gelu ? EPI_GELU_F32 : EPI_STORE_F32, xin, Mb, K, dW, N,
+                                        (ln_g && c->bf16) ? dg : nullptr, (ln_g && c->bf16) ? db : nullptr, ep, c->st);
+    if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemv: %s", hipGetErrorString(er)); }
+    else fail(c, r, "test_gemv: launch rejected (Mb=%d N=%d K=%d)", Mb, N, K);
+    if (r == CW_OK) { hipError_t er = hipMemcpy(out, dO, (size_t)Mb * N * 4, hipMemcpyDeviceToHost); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemv copy"); }
+    hipFree(dx); hipFree(dW); hipFree(dO); hipFree(dB); hipFree(dg); hipFree(db); hipFree(dxn);
+    return r;
+}
+
+int32_t cw_test_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, const float* q, const float* k, const float* v, float* out) {
+    const int S_pad = (S + 63) & ~63;
+    const size_t e = c->esz, nh = (size_t)B * H * S_pad * 64;
+    void *dq = nullptr, *dk = nullptr, *dv = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc(&dq, nh * e)); HIPCHK(c, hipMalloc(&dk, nh * e)); HIPCHK(c, hipMalloc(&dv, nh * e));
+    HIPCHK(c, hipMalloc(&dout, (size_t)B * S * H * 64 * e));
+    HIPCHK(c, hipMemset(dq, 0, nh * e)); HIPCHK(c, hipMemset(dk, 0, nh * e)); HIPCHK(c, hipMemset(dv, 0, nh * e));
+    for (int bh = 0; bh < B * H; ++bh) {   // inputs are [B][H][S][64]
+        CWCHK(c, upload_T(c, dq, (size_t)bh * S_pad * 64, q + (size_t)bh * S * 64, (size_t)S * 64));
+        CWCHK(c, upload_T(c, dk, (size_t)bh * S_pad * 64, k + (size_t)bh * S * 64, (size_t)S * 64));
+        CWCHK(c, upload_T(c, dv, (size_t)bh * S_pad * 64, v + (size_t)bh * S * 64, (size_t)S * 64));
+    }
+    int r = cw_launch_attn_encoder(c->bf16, dq, dk, dv, dout, B, H, S, S_pad, c->st);
+    if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_attention: %s", hipGetErrorString(er)); }
+    if (r == CW_OK) r = download_T(c, dout, 0, out, (size_t)B * S * H * 64);
+    hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------------
+int32_t cw_stage_times(cw_ctx* c, float* ms, int32_t* calls, int32_t reset) {
+    for (int i = 0; i < CW_N_STAGES; ++i) {
+        if (ms) ms[i] = c->stage_ms[i];
+        if (calls) calls[i] = c->stage_calls[i];
+        if (reset) { c->stage_ms[i] = 0.f; c->stage_calls[i] = 0; }
+    }
+    return CW_OK;
+}
+
+int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, float* avg_ms, double* algo_bytes) {
+    const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim;
+    if (nb < 1 || nb > c->Bm || iters < 1) return fail(c, CW_ERR_INVALID, "time_kernel: bad args");
+    LayerW& L = c->dec[0];
+    auto launch = [&]() -> int {
+        if (which == 0) {
+            EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
+            return gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep);
+        }
+        DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->dattn, nullptr, nullptr, 0, 0, 0, nb, H};
+        return cw_launch_attn_decode(c->bf16, p, c->st);
+    };
+    for (int i = 0; i < 3; ++i) CWCHK(c, launch());
+    HIPCHK(c, hipEventRecord(c->ev0, c->st));
+    for (int i = 0; i < iters; ++i) CWCHK(c, launch());
+    HIPCHK(c, hipEventRecord(c->ev1, c->st));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = ms / iters;
+    if (which == 0) *algo_bytes = (double)F * D * c->esz + (double)nb * D * 4 + (double)nb * F * 4;
+    else *algo_bytes = 2.0 * nb * H * CW_N_CTX * 64 * c->esz + 2.0 * nb * D * 4;
+    return CW_OK;
+}
+
+}  // extern "C"

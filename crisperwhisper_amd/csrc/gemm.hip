@@ -1,0 +1,396 @@
+// GEMM family for the Whisper encoder/decoder on gfx950.
+//
+//   gemm_bf16_kernel   C[M,N] = A[M,K] * W[N,K]^T  -- 128x128x64 LDS-tiled MFMA (16x16x32 bf16) GEMM.
+//                      A rows are either plain (lda) or an im2col-free conv1d(k=3,pad=1) gather over a
+//                      time-major activation (implicit GEMM for conv1 / conv2,
+//                      TF/models/whisper/modeling_whisper.py:618-619).  Operands are swapped in the MFMA
+//                      (D = W_frag x A_frag) so every lane owns 4 *consecutive output columns* of one
+//                      row -> 8-byte bf16 / 16-byte f32 epilogue stores along N.
+//   gemm_f32_kernel    same contract in plain f32 VALU (parity mode + on-device reference).
+//   gemv_bf16_kernel   decode-time skinny GEMM (M = batch <= 64): weights streamed once from HBM
+//                      straight into MFMA B fragments (16 B / lane, 256 B contiguous per weight row per
+//                      step), activations staged in LDS as bf16 with an optional fused LayerNorm
+//                      prologue (TF modeling_whisper.py:470,485,498).  HBM-bound by design.
+//   gemv_f32_kernel    f32 parity flavour of the same.
+#include "common.h"
+#include "kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define LDS_STRIDE 72  // bf16 per LDS row: 64 + 8 pad (144 B) keeps ds_read_b128 fragment reads spread
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+__device__ inline f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                   __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+
+// Address of A row `m`, starting at K offset k0 (k0 % 64 == 0).  Returns nullptr for a zero row.
+template <typename TA>
+__device__ inline const TA* a_row_ptr(const AParams& ap, int m, int M, int k0) {
+    if (m >= M) return nullptr;
+    if (ap.amode == 0) return (const TA*)ap.A + (size_t)m * ap.lda + k0;
+    int b = m / ap.T_out, t = m - b * ap.T_out;
+    int tap = k0 / ap.C_in, c0 = k0 - tap * ap.C_in;
+    int t_in = t * ap.stride + tap - 1;
+    if (t_in < 0 || t_in >= ap.row_valid[b]) return nullptr;
+    return (const TA*)ap.A + ((size_t)(ap.row_off[b] + t_in)) * ap.C_in + c0;
+}
+
+// XCD-aware, bijective block remap (8 XCDs, block b is dispatched to XCD b % 8): consecutive logical
+// tiles, which share an A row-panel, land on the same XCD's L2.
+__device__ inline int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, slot = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(AParams ap, const bf16_t* __restrict__ W, int M, int N,
+                                                        int K, EpiParams ep, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) bf16_t sW[BN * LDS_STRIDE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    // staging: 128 rows x 64 cols bf16 = 1024 16-byte chunks per operand; 4 per thread.
+    uint4 ra[4], rw[4];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int c = tid + i * 256, row = c >> 3, col = (c & 7) * 8;
+            const bf16_t* pa = a_row_ptr<bf16_t>(ap, m0 + row, M, k0);
+            ra[i] = pa ? *(const uint4*)(pa + col) : make_uint4(0, 0, 0, 0);
+            int n = n0 + row;
+            rw[i] = (n < N) ? *(const uint4*)(W + (size_t)n * K + k0 + col) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int c = tid + i * 256, row = c >> 3, col = (c & 7) * 8;
+            *(uint4*)(sA + row * LDS_STRIDE + col) = ra[i];
+            *(uint4*)(sW + row * LDS_STRIDE + col) = rw[i];
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[4], fw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[i] = *(const bf16x8_t*)(sA + (wm * 64 + i * 16 + l15) * LDS_STRIDE + kk * 32 + g * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fw[j] = *(const bf16x8_t*)(sW + (wn * 64 + j * 16 + l15) * LDS_STRIDE + kk * 32 + g * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[j], fa[i], acc[i][j]);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: acc[i][j][r] = C[m][n], m = m0 + wm*64 + i*16 + l15, n = n0 + wn*64 + j*16 + g*4 + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + wm * 64 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + wn * 64 + j * 16 + g * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < N) epi_store1<bf16_t, EPI>(ep, m, n + r, acc[i][j][r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// f32 parity GEMM: 64x64 tile, 256 threads, 4x4 outputs per thread, BK = 16.
+// ---------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(AParams ap, const float* __restrict__ W, int M, int N, int K,
+                                                       EpiParams ep, int tiles_n) {
+    __shared__ float sA[16][65];
+    __shared__ float sW[16][65];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * 64, n0 = (tile % tiles_n) * 64;
+    const int tm = tid >> 4, tn = tid & 15;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        // each thread loads 4 A and 4 W elements: row = tid / 4, cols (tid % 4) * 4 .. +3
+        int row = tid >> 2, kc = (tid & 3) * 4;
+        const float* pa = a_row_ptr<float>(ap, m0 + row, M, (k0 / 64) * 64);
+        int koff = k0 - (k0 / 64) * 64;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            sA[kc + c][row] = pa ? pa[koff + kc + c] : 0.f;
+            int n = n0 + row;
+            sW[kc + c][row] = (n < N) ? W[(size_t)n * K + k0 + kc + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sA[k][tm * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = sW[k][tn * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + tm * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + tn * 4 + j;
+            if (n < N) epi_store1<float, EPI>(ep, m, n, acc[i][j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Decode GEMV (skinny GEMM), bf16 weights.  One block = 16 output columns; its 4 waves split the K
+// steps (128 k per step: each lane streams 64 contiguous bytes of its weight row) and reduce through
+// LDS.  x is f32 [Mb][K] in global (decode activations are tiny and kept in f32), converted to bf16
+// while being staged into LDS, with an optional LayerNorm prologue over the full row (K == d_model).
+// ---------------------------------------------------------------------------------------------------
+#define GV_MAXM 64
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(const float* __restrict__ x, int Mb, int K, int KC,
+                                                        const bf16_t* __restrict__ W, int N,
+                                                        const float* __restrict__ ln_g,
+                                                        const float* __restrict__ ln_b, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Mpad = (Mb + 15) & ~15;
+    const int xs_stride = KC + 8;                                  // bf16 elements
+    bf16_t* xs = (bf16_t*)smem;                                     // [Mpad][KC+8]
+    float* stats = (float*)(smem + (size_t)Mpad * xs_stride * 2);   // [Mpad][2] mean, rstd
+    float* red = stats + 2 * GV_MAXM;                               // [4 waves][4 mtiles][256]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int mt_n = Mpad >> 4;
+
+    if (ln_g) {  // LayerNorm statistics, two-pass, one wave per row
+        for (int m = wave; m < Mb; m += 4) {
+            const float* xr = x + (size_t)m * K;
+            float s = 0.f;
+            for (int k = lane; k < K; k += 64) s += xr[k];
+            float mean = wave_sum(s) / (float)K;
+            float v = 0.f;
+            for (int k = lane; k < K; k += 64) { float d = xr[k] - mean; v += d * d; }
+            float var = wave_sum(v) / (float)K;
+            if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = 1.0f / sqrtf(var + 1e-5f); }
+        }
+    }
+    __syncthreads();
+
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int n = n0 + l15;
+    const bf16_t* wrow = W + (size_t)(n < N ? n : 0) * K;
+    const int steps_per_chunk = KC / 128;
+
+    for (int kc0 = 0; kc0 < K; kc0 += KC) {
+        // stage x[:, kc0 : kc0+KC] -> LDS bf16 (rows >= Mb are zero)
+        for (int idx = tid; idx < Mpad * (KC / 4); idx += 256) {
+            int m = idx / (KC / 4), k4 = (idx - m * (KC / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < Mb) {
+                v = *(const float4*)(x + (size_t)m * K + kc0 + k4);
+                if (ln_g) {
+                    float mean = stats[2 * m], rstd = stats[2 * m + 1];
+                    const float4 gg = *(const float4*)(ln_g + kc0 + k4);
+                    const float4 bb = *(const float4*)(ln_b + kc0 + k4);
+                    v.x = (v.x - mean) * rstd * gg.x + bb.x;
+                    v.y = (v.y - mean) * rstd * gg.y + bb.y;
+                    v.z = (v.z - mean) * rstd * gg.z + bb.z;
+                    v.w = (v.w - mean) * rstd * gg.w + bb.w;
+                }
+            }
+            ushort4 o;
+            o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+            *(ushort4*)(xs + (size_t)m * xs_stride + k4) = o;
+        }
+        __syncthreads();
+        for (int step = wave; step < steps_per_chunk; step += 4) {
+            const int kl = step * 128 + g * 32;                     // local k of this lane's 32 weights
+            u32x4_t w4[4];
+            if (n < N) {
+                const u32x4_t* wp = (const u32x4_t*)(wrow + kc0 + kl);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w4[j] = __builtin_nontemporal_load(wp + j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w4[j] = (u32x4_t){0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < mt_n) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16x8_t a = *(const bf16x8_t*)(xs + (size_t)(t * 16 + l15) * xs_stride + kl + j * 8);
+                        acc[t] = mfma16(a, __builtin_bit_cast(bf16x8_t, w4[j]), acc[t]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // cross-wave reduction: D[row = batch m = g*4 + r][col = n = l15]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (t < mt_n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave * 4 + t) * 4 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < mt_n) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += red[((w * 4 + t) * 4 + r) * 64 + lane];
+                    int m = t * 16 + g * 4 + r;
+                    if (m < Mb && n < N) epi_store1<bf16_t, EPI>(ep, m, n, v);
+                }
+            }
+        }
+    }
+}
+
+// f32 parity GEMV: one wave per output column, x read from global (L2 resident); LN is applied by a
+// separate kernel in f32 mode (ln_g must be null here).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ x, int Mb, int K,
+                                                       const float* __restrict__ W, int N, EpiParams ep) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const float* wr = W + (size_t)n * K;
+    for (int mb = 0; mb < Mb; mb += 8) {
+        float acc[8] = {};
+        for (int k = lane; k < K; k += 64) {
+            float w = wr[k];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (mb + i < Mb) acc[i] = fmaf(x[(size_t)(mb + i) * K + k], w, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = wave_sum(acc[i]);
+            if (lane == 0 && mb + i < Mb) epi_store1<float, EPI>(ep, mb + i, n, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host launchers
+// ---------------------------------------------------------------------------------------------------
+template <int EPI>
+static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
+                            hipStream_t st) {
+    if (bf16) {
+        int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(tm * tn), dim3(256), 0, st, ap, (const bf16_t*)W, M, N, K, ep,
+                           tn);
+    } else {
+        int tm = (M + 63) / 64, tn = (N + 63) / 64;
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI>), dim3(tm * tn), dim3(256), 0, st, ap, (const float*)W, M, N, K, ep,
+                           tn);
+    }
+}
+
+int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
+                   hipStream_t st) {
+    if (K % 64 != 0 || M <= 0 || N <= 0) return CW_ERR_INVALID;
+    switch (epi) {
+        case EPI_STORE: launch_gemm_epi<EPI_STORE>(bf16, ap, W, M, N, K, ep, st); break;
+        case EPI_GELU: launch_gemm_epi<EPI_GELU>(bf16, ap, W, M, N, K, ep, st); break;
+        case EPI_RESID_F32: launch_gemm_epi<EPI_RESID_F32>(bf16, ap, W, M, N, K, ep, st); break;
+        case EPI_GELU_POS_F32: launch_gemm_epi<EPI_GELU_POS_F32>(bf16, ap, W, M, N, K, ep, st); break;
+        case EPI_HEADS: launch_gemm_epi<EPI_HEADS>(bf16, ap, W, M, N, K, ep, st); break;
+        case EPI_STORE_F32: launch_gemm_epi<EPI_STORE_F32>(bf16, ap, W, M, N, K, ep, st); break;
+        default: return CW_ERR_INVALID;
+    }
+    return CW_OK;
+}
+
+// KC: K chunk staged in LDS per pass (bf16 path).  Mpad * (KC + 8) * 2 bytes must stay <= ~48 KB.
+int cw_gemv_kc(int Mb, int K) {
+    int Mpad = (Mb + 15) & ~15;
+    for (int kc = K; kc >= 128; kc -= 128)
+        if (K % kc == 0 && (size_t)Mpad * (kc + 8) * 2 <= 46 * 1024) return kc;
+    return 128;
+}
+
+template <int EPI>
+static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
+                           const float* ln_b, const EpiParams& ep, hipStream_t st) {
+    if (bf16) {
+        int kc = cw_gemv_kc(Mb, K);
+        if (kc % 128 != 0 || K % kc != 0) return CW_ERR_INVALID;
+        int Mpad = (Mb + 15) & ~15;
+        size_t lds = (size_t)Mpad * (kc + 8) * 2 + 2 * GV_MAXM * 4 + 4 * 4 * 4 * 64 * 4;
+        hipLaunchKernelGGL((gemv_bf16_kernel<EPI>), dim3((N + 15) / 16), dim3(256), lds, st, x, Mb, K, kc,
+                           (const bf16_t*)W, N, ln_g, ln_b, ep);
+    } else {
+        if (ln_g) return CW_ERR_INVALID;
+        hipLaunchKernelGGL((gemv_f32_kernel<EPI>), dim3((N + 3) / 4), dim3(256), 0, st, x, Mb, K, (const float*)W, N,
+                           ep);
+    }
+    return CW_OK;
+}
+
+int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
+                   const float* ln_b, const EpiParams& ep, hipStream_t st) {
+    if (Mb <= 0 || Mb > GV_MAXM || K % 128 != 0) return CW_ERR_INVALID;
+    switch (epi) {
+        case EPI_GELU_F32: return launch_gemv_epi<EPI_GELU_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st);
+        case EPI_RESID_F32: return launch_gemv_epi<EPI_RESID_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st);
+        case EPI_STORE_F32: return launch_gemv_epi<EPI_STORE_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st);
+        case EPI_QKV_CACHE: return launch_gemv_epi<EPI_QKV_CACHE>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st);
+        default: return CW_ERR_INVALID;
+    }
+}

@@ -1,0 +1,89 @@
+// Internal launcher interface between the kernel translation units and the engine.
+#pragma once
+#include "common.h"
+
+// A-operand addressing for the tile GEMMs: plain row-major or implicit conv1d(k=3, pad=1) gather.
+struct AParams {
+    const void* A;
+    int lda;
+    int amode;             // 0 = plain [M][lda]; 1 = conv gather over time-major [rows][C_in]
+    int T_out, C_in, stride;
+    const int* row_off;    // [batch] first input row of each item's window
+    const int* row_valid;  // [batch] valid input rows in the window (beyond -> zeros)
+};
+
+int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
+                   hipStream_t st);
+int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
+                   const float* ln_b, const EpiParams& ep, hipStream_t st);
+
+// elementwise.hip
+int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d,
+                        hipStream_t st);
+int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d,
+                            hipStream_t st);
+
+struct SampleParams {
+    const float* logits;       // [B][V]
+    int V, B;
+    const unsigned char* mask; // [V] bit0 always suppressed, bit1 suppressed at begin
+    int eos, pad, timestamp_begin, max_initial_timestamp_index;  // max_initial < 0: none
+    int n_prompt;              // begin index
+    int t;                     // index of the token being chosen (sequence length so far)
+    int min_new_tokens;
+    int max_length;
+    int ids_stride;            // tokens per row in `ids`
+    int* ids;                  // [B][ids_stride]  (in/out)
+    const int* forced;         // [B][ids_stride] or null; value >= 0 forces that token at index t
+    int* argmax_trace;         // [B][ids_stride] or null: the un-forced choice
+    int* last_ts_tok;          // [B] last timestamp token generated (or -1)
+    int* finished;             // [B]
+    int* n_unfinished;         // [1] recomputed every call
+    // fused embedding of the chosen token for the next decoder step
+    const void* embed;         // [V][d] T
+    const float* pos_embed;    // [max_target][d] f32
+    float* x_out;              // [B][d] f32
+    int d;
+    int embed_bf16;
+};
+int cw_launch_sample(const SampleParams& p, hipStream_t st);
+int cw_launch_embed(const int* ids, int ids_stride, int t, const void* embed, int embed_bf16, const float* pos_embed,
+                    float* x_out, int B, int d, hipStream_t st);
+
+// attention.hip
+int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* V, void* out, int B, int H, int S,
+                           int S_pad, hipStream_t st);
+struct DecAttnParams {
+    const float* q;        // [B][H*64] f32, already scaled
+    const void* K;         // [B][H][cap][64] T
+    const void* V;         // [B][H][cap][64] T
+    int cap;               // rows allocated per (b,h)
+    int n_keys;            // keys to attend over
+    float* out;            // [B][H*64] f32
+    float* align_out;      // [B][n_align][align_rows][S] or null
+    const int* align_slot; // [H] slot index of each head in this layer (or -1), device
+    int n_align, align_rows, align_row; // row (= decoder position) to write
+    int B, H;
+};
+int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st);
+
+// mel.hip
+struct MelTables {
+    const double* cos_t;  // [400]
+    const double* sin_t;  // [400]
+    const double* window; // [400]
+    const float* filters; // [201][n_mels]
+};
+int cw_launch_mel(const MelTables& t, const float* pcm, int B, int n_mels, float* logspec_tm, unsigned int* gmax,
+                  hipStream_t st);
+int cw_launch_mel_finish(const float* logspec_tm, const unsigned int* gmax, int B, int n_mels, void* feats_tm,
+                         int feats_bf16, float* feats_hf, hipStream_t st);
+
+// align.hip
+int cw_launch_align_stats(const float* w, int B, int Ha, int rows_cap, int S, int row0, int N, const int* n_cols,
+                          float* mean, float* stdv, hipStream_t st);
+int cw_launch_align_filter(const float* w, int B, int Ha, int rows_cap, int S, int row0, int N, const int* n_cols,
+                           const float* mean, const float* stdv, int width, float* mat, hipStream_t st);
+int cw_launch_dtw(const float* mat, int B, int N, int S, const int* n_cols, unsigned char* trace, int* first_col,
+                  int* path_text, int* path_time, int* path_len, hipStream_t st);
+int cw_launch_pauses(double* start, double* end, int W, double thr, hipStream_t st);

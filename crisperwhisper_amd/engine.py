@@ -1,0 +1,252 @@
+"""Thin object wrapper over the C ABI: one ``Engine`` = one ``cw_ctx`` on one GPU.
+
+Host side of seam 2 of SURVEY.md section 8b: owns the context, uploads weights, and exposes the device
+stages (mel / encode / decode / token timestamps) with numpy host buffers.  No arithmetic of the
+hot path happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i32(x) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(x, dtype=np.int32))
+
+
+@dataclasses.dataclass
+class ModelSpec:
+    """The fields of WhisperConfig / generation_config the path reads."""
+    d_model: int
+    n_heads: int
+    ffn_dim: int
+    enc_layers: int
+    dec_layers: int
+    n_mels: int
+    vocab_size: int
+    max_target_positions: int = 448
+    median_filter_width: int = 7
+    alignment_heads: Sequence[Sequence[int]] = ()
+    eos_token_id: int = 0
+    pad_token_id: int = 0
+    decoder_start_token_id: int = 0
+    no_timestamps_token_id: int = 0
+    max_initial_timestamp_index: Optional[int] = 50
+    suppress_tokens: Sequence[int] = ()
+    begin_suppress_tokens: Sequence[int] = ()
+    lang_to_id: Dict[str, int] = dataclasses.field(default_factory=dict)
+    task_to_id: Dict[str, int] = dataclasses.field(default_factory=dict)
+    max_length: int = 448
+
+    @property
+    def timestamp_begin(self) -> int:
+        return self.no_timestamps_token_id + 1
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    def __init__(self, spec: ModelSpec, dtype: str = "bf16", max_batch: int = 16, device: int = 0):
+        self.lib = N.load()
+        self.spec = spec
+        self.dtype = dtype
+        self.max_batch = int(max_batch)
+        if not spec.alignment_heads:
+            raise ValueError("Model generation config has no `alignment_heads`, token-level timestamps not available.")
+        al = _i32([h[0] for h in spec.alignment_heads])
+        ah = _i32([h[1] for h in spec.alignment_heads])
+        desc = N.ModelDesc(
+            d_model=spec.d_model, n_heads=spec.n_heads, ffn_dim=spec.ffn_dim, enc_layers=spec.enc_layers,
+            dec_layers=spec.dec_layers, n_mels=spec.n_mels, vocab_size=spec.vocab_size,
+            max_target_positions=spec.max_target_positions, median_filter_width=spec.median_filter_width,
+            dtype={"f32": N.CW_DTYPE_F32, "fp32": N.CW_DTYPE_F32, "bf16": N.CW_DTYPE_BF16}[dtype],
+            max_batch=self.max_batch, n_align=len(al),
+            align_layers=al.ctypes.data_as(C.POINTER(C.c_int32)), align_heads=ah.ctypes.data_as(C.POINTER(C.c_int32)))
+        self.ctx = self.lib.cw_create(C.byref(desc), int(device))
+        if not self.ctx:
+            raise EngineError("cw_create failed: " + (self.lib.cw_last_error(None) or b"?").decode())
+        sup, bsup = _i32(list(spec.suppress_tokens)), _i32(list(spec.begin_suppress_tokens))
+        cfg = N.GenCfg(
+            eos_token_id=spec.eos_token_id, pad_token_id=spec.pad_token_id,
+            no_timestamps_token_id=spec.no_timestamps_token_id,
+            max_initial_timestamp_index=-1 if spec.max_initial_timestamp_index is None else spec.max_initial_timestamp_index,
+            suppress_tokens=sup.ctypes.data_as(C.POINTER(C.c_int32)), n_suppress=len(sup),
+            begin_suppress_tokens=bsup.ctypes.data_as(C.POINTER(C.c_int32)), n_begin_suppress=len(bsup))
+        self._chk(self.lib.cw_set_generation(self.ctx, C.byref(cfg)))
+        self._capture = None
+
+    # ------------------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise EngineError(f"native call failed ({rc}): " + (self.lib.cw_last_error(self.ctx) or b"?").decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.cw_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self.lib.cw_sync(self.ctx))
+
+    # ------------------------------------------------------------------ weights
+    def load_tensor(self, name: str, array: np.ndarray):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        self._chk(self.lib.cw_load_tensor(self.ctx, name.encode(), _ptr(a), shape, a.ndim))
+
+    def load_state_dict(self, weights: Dict[str, np.ndarray]):
+        for k, v in weights.items():
+            self.load_tensor(k, v)
+
+    # ------------------------------------------------------------------ stages
+    def mel(self, clips: List[np.ndarray], return_features: bool = False):
+        """clips: list of 1-D float32 arrays (each <= 30 s).  Returns (features or None, n_frames)."""
+        B = len(clips)
+        ns = _i32([len(c) for c in clips])
+        pcm = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.float32) for c in clips])) if B else np.zeros(0, np.float32)
+        feats = np.empty((B, self.spec.n_mels, N.N_FRAMES), dtype=np.float32) if return_features else None
+        nf = np.zeros(B, dtype=np.int32)
+        self._chk(self.lib.cw_mel(self.ctx, _ptr(pcm), B, _ptr(ns), _ptr(feats), _ptr(nf)))
+        return feats, nf
+
+    def upload_pcm(self, clips: List[np.ndarray]):
+        ns = _i32([len(c) for c in clips])
+        pcm = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.float32) for c in clips]))
+        self._chk(self.lib.cw_upload_pcm(self.ctx, _ptr(pcm), len(clips), _ptr(ns)))
+        return (ns + 159) // 160
+
+    def mel_resident(self, B: int):
+        self._chk(self.lib.cw_mel_resident(self.ctx, B))
+
+    def set_features(self, feats: np.ndarray):
+        f = np.ascontiguousarray(feats, dtype=np.float32)
+        self._chk(self.lib.cw_set_features(self.ctx, _ptr(f), f.shape[0]))
+
+    def encode(self, item, seek, n_frames):
+        item, seek, n_frames = _i32(item), _i32(seek), _i32(n_frames)
+        self._chk(self.lib.cw_encode(self.ctx, len(item), _ptr(item), _ptr(seek), _ptr(n_frames)))
+
+    def encoder_output(self, nb: int) -> np.ndarray:
+        out = np.empty((nb, N.N_CTX, self.spec.d_model), dtype=np.float32)
+        self._chk(self.lib.cw_get_encoder_output(self.ctx, _ptr(out), nb))
+        return out
+
+    def decode(self, prompt: np.ndarray, max_length: int, min_new_tokens: int = 0,
+               forced: Optional[np.ndarray] = None, want_argmax: bool = False):
+        prompt = _i32(prompt)
+        nb, n_prompt = prompt.shape
+        tgt = self.spec.max_target_positions
+        seqs = np.zeros((nb, tgt), dtype=np.int32)
+        lens = np.zeros(nb, dtype=np.int32)
+        amax = np.zeros((nb, tgt), dtype=np.int32) if want_argmax else None
+        f = None
+        if forced is not None:
+            f = np.full((nb, tgt), -1, dtype=np.int32)
+            f[:, :forced.shape[1]] = forced
+        self._chk(self.lib.cw_decode(self.ctx, nb, _ptr(prompt), n_prompt, int(max_length), int(min_new_tokens),
+                                     _ptr(f), _ptr(seqs), _ptr(lens), _ptr(amax)))
+        return seqs, lens, amax
+
+    def last_logits(self, nb: int) -> np.ndarray:
+        out = np.empty((nb, self.spec.vocab_size), dtype=np.float32)
+        self._chk(self.lib.cw_get_logits(self.ctx, _ptr(out), nb))
+        return out
+
+    def capture_logits(self, nb: int, max_steps: int) -> np.ndarray:
+        self._capture = np.zeros((max_steps, nb, self.spec.vocab_size), dtype=np.float32)
+        self._chk(self.lib.cw_set_logits_capture(self.ctx, _ptr(self._capture), max_steps))
+        return self._capture
+
+    def stop_capture(self):
+        self._chk(self.lib.cw_set_logits_capture(self.ctx, None, 0))
+        self._capture = None
+
+    def alignment(self, nb: int, L: int) -> np.ndarray:
+        out = np.empty((nb, len(self.spec.alignment_heads), L, N.N_CTX), dtype=np.float32)
+        self._chk(self.lib.cw_get_alignment(self.ctx, _ptr(out), nb, L))
+        return out
+
+    def token_timestamps(self, nb: int, L: int, n_prompt: int, num_frames) -> np.ndarray:
+        nf = _i32(num_frames)
+        out = np.zeros((nb, L + 1), dtype=np.float32)
+        self._chk(self.lib.cw_token_timestamps(self.ctx, nb, L, n_prompt, _ptr(nf), _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ stand-alone kernels
+    def align_matrix(self, attn: np.ndarray, n_cols, width: int) -> np.ndarray:
+        a = np.ascontiguousarray(attn, dtype=np.float32)
+        B, Ha, Nn, M = a.shape
+        nc = _i32(n_cols)
+        out = np.zeros((B, Nn, M), dtype=np.float32)
+        self._chk(self.lib.cw_align_matrix(self.ctx, _ptr(a), B, Ha, Nn, M, _ptr(nc), width, _ptr(out)))
+        return out
+
+    def dtw(self, mat: np.ndarray):
+        m = np.ascontiguousarray(mat, dtype=np.float32)
+        Nn, M = m.shape
+        ti = np.zeros(Nn + M + 2, dtype=np.int32)
+        tj = np.zeros(Nn + M + 2, dtype=np.int32)
+        n = C.c_int32(0)
+        self._chk(self.lib.cw_dtw(self.ctx, _ptr(m), Nn, M, _ptr(ti), _ptr(tj), C.byref(n)))
+        return ti[:n.value].copy(), tj[:n.value].copy()
+
+    def adjust_pauses(self, start: np.ndarray, end: np.ndarray, thr: float):
+        s = np.ascontiguousarray(start, dtype=np.float64).copy()
+        e = np.ascontiguousarray(end, dtype=np.float64).copy()
+        self._chk(self.lib.cw_adjust_pauses(self.ctx, _ptr(s), _ptr(e), len(s), float(thr)))
+        return s, e
+
+    def test_gemm(self, A, W, bias=None, gelu=False):
+        A = np.ascontiguousarray(A, np.float32); W = np.ascontiguousarray(W, np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        out = np.zeros((A.shape[0], W.shape[0]), np.float32)
+        self._chk(self.lib.cw_test_gemm(self.ctx, A.shape[0], W.shape[0], A.shape[1], _ptr(A), _ptr(W), _ptr(b), int(gelu), _ptr(out)))
+        return out
+
+    def test_gemv(self, x, W, bias=None, ln=None, gelu=False):
+        x = np.ascontiguousarray(x, np.float32); W = np.ascontiguousarray(W, np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        g = be = None
+        if ln is not None:
+            g, be = (np.ascontiguousarray(t, np.float32) for t in ln)
+        out = np.zeros((x.shape[0], W.shape[0]), np.float32)
+        self._chk(self.lib.cw_test_gemv(self.ctx, x.shape[0], W.shape[0], x.shape[1], _ptr(x), _ptr(W), _ptr(b),
+                                        _ptr(g), _ptr(be), int(gelu), _ptr(out)))
+        return out
+
+    def test_attention(self, q, k, v):
+        q, k, v = (np.ascontiguousarray(t, np.float32) for t in (q, k, v))
+        B, H, S, _ = q.shape
+        out = np.zeros((B, S, H * 64), np.float32)
+        self._chk(self.lib.cw_test_attention(self.ctx, B, H, S, _ptr(q), _ptr(k), _ptr(v), _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ measurement
+    def stage_times(self, reset: bool = False):
+        ms = np.zeros(len(N.STAGES), np.float32)
+        calls = np.zeros(len(N.STAGES), np.int32)
+        self._chk(self.lib.cw_stage_times(self.ctx, _ptr(ms), _ptr(calls), int(reset)))
+        return {s: (float(ms[i]), int(calls[i])) for i, s in enumerate(N.STAGES)}
+
+    def time_kernel(self, which: int, nb: int, iters: int):
+        ms = C.c_float(0.0)
+        by = C.c_double(0.0)
+        self._chk(self.lib.cw_time_kernel(self.ctx, which, nb, iters, C.byref(ms), C.byref(by)))
+        return ms.value, by.value

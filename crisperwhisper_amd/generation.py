@@ -1,0 +1,133 @@
+"""Host control flow of ``WhisperGenerationMixin.generate`` for the word-timestamp path.
+
+Mirrors (call surface, argument meaning, error behaviour) the parts of
+TF/models/whisper/generation_whisper.py the reference pipeline reaches with
+``return_timestamps="word"`` and ``num_beams=1``: init tokens (:1455-1608, explicit language/task),
+the seek loop (:785-903) with batch shrinking (:1814-1829), window slicing (:1831-1852), padding and
+eos stripping (:1060-1082), ``_retrieve_segment`` (:1977-2074) and the final assembly (:936-968 as
+consumed by TF/pipelines/automatic_speech_recognition.py:529-540).  All tensor work is delegated to
+the device through ``Engine``; this module only decides *what* to run next from the decoded ids.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Optional
+
+import numpy as np
+
+from ._native import N_FRAMES
+from .engine import Engine
+
+TIME_PRECISION = 0.02          # seconds per encoder frame (30 / 1500)
+INPUT_STRIDE = 2               # conv1.stride * conv2.stride
+
+
+@dataclasses.dataclass
+class Segment:
+    tokens: np.ndarray             # int64
+    token_timestamps: np.ndarray   # float32, absolute seconds within the 30 s chunk
+    idxs: tuple
+
+
+def init_tokens(spec, language: Optional[str], task: Optional[str]) -> List[int]:
+    """<|startoftranscript|><|lang|><|task|> (no <|notimestamps|>: return_timestamps=True)."""
+    if language is None:
+        raise ValueError("language detection is not implemented on the native path: pass "
+                         "generate_kwargs={'language': '<|en|>'} (the parity policy fixes it, SURVEY.md 8c)")
+    lang = language if language in spec.lang_to_id else f"<|{language}|>"
+    if lang not in spec.lang_to_id:
+        raise ValueError(f"Unsupported language: {language}. Language should be one of: {sorted(spec.lang_to_id)}.")
+    task = task or "transcribe"
+    if task not in spec.task_to_id:
+        raise ValueError(f"The `{task}` task is not supported. The task should be one of `{sorted(spec.task_to_id)}`")
+    return [spec.decoder_start_token_id, spec.lang_to_id[lang], spec.task_to_id[task]]
+
+
+def split_segments(seq: np.ndarray, token_ts: np.ndarray, time_offset: float, timestamp_begin: int,
+                   seek_num_frames: int, idx_offset: int):
+    """Slice one decoded window at paired timestamp tokens; returns (segments, frames to advance)."""
+    is_ts = seq >= timestamp_begin
+    single_ending = len(seq) >= 2 and (not is_ts[-2]) and bool(is_ts[-1])
+    if len(seq) == 1:
+        single_ending = False                                   # tolist() == [True] != [False, True]
+    pair_ends = np.nonzero(is_ts[:-1] & is_ts[1:])[0] + 1
+    off32 = np.float32(time_offset)
+    out: List[Segment] = []
+    if len(pair_ends):
+        cuts = pair_ends.tolist()
+        if single_ending:
+            cuts.append(len(seq))
+        else:
+            cuts[-1] += 1
+        prev = 0
+        for cut in cuts:
+            out.append(Segment(seq[prev:cut], (token_ts[idx_offset + prev: idx_offset + cut] + off32).astype(np.float32),
+                               (idx_offset + prev, idx_offset + cut)))
+            prev = cut
+        if single_ending:
+            advance = seek_num_frames
+        else:
+            advance = (int(seq[prev - 2]) - timestamp_begin) * INPUT_STRIDE
+    else:
+        out.append(Segment(seq, (token_ts[idx_offset: idx_offset + len(seq)] + off32).astype(np.float32),
+                           (idx_offset, idx_offset + len(seq))))
+        advance = seek_num_frames
+    return out, advance
+
+
+def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str], task: Optional[str] = None,
+             max_new_tokens: Optional[int] = None, min_new_tokens: Optional[int] = None,
+             num_beams: Optional[int] = 1, stats: Optional[dict] = None):
+    """Transcribe the ``n_items`` 30 s feature windows resident in the engine (items 0..n-1).
+
+    Returns {"sequences": [B, Lmax] int64 (pad-right), "token_timestamps": list of float32 arrays,
+    "segments": list of list of Segment} -- the fields the pipeline consumes."""
+    spec = engine.spec
+    if num_beams not in (None, 1):
+        raise ValueError("the native path implements greedy decoding only: pass generate_kwargs={'num_beams': 1} "
+                         "(transformers 5.x pipelines default to 5 beams; the 2024 reference was greedy)")
+    init = np.asarray(init_tokens(spec, language, task), dtype=np.int32)
+    n_prompt = len(init)
+    if max_new_tokens is not None and max_new_tokens + n_prompt > spec.max_target_positions:
+        max_new_tokens = spec.max_target_positions - n_prompt     # :1937-1942
+    tb = spec.timestamp_begin
+    num_frames = np.asarray(num_frames, dtype=np.int64)
+    seek = np.zeros(n_items, dtype=np.int64)
+    max_frames = np.full(n_items, N_FRAMES, dtype=np.int64)
+    segments: List[List[Segment]] = [[] for _ in range(n_items)]
+    n_calls = 0
+    while True:
+        active = [i for i in range(n_items) if seek[i] < max_frames[i]]
+        if not active:
+            break
+        seek_num = np.minimum(max_frames - seek, N_FRAMES)
+        engine.encode(active, seek[active], seek_num[active])
+        max_length = (n_prompt + max_new_tokens) if max_new_tokens is not None else min(spec.max_length, spec.max_target_positions)
+        seqs, lens, _ = engine.decode(np.tile(init, (len(active), 1)), max_length, min_new_tokens or 0)
+        total = int(lens.max())
+        L = total - 1
+        token_ts = engine.token_timestamps(len(active), L, n_prompt, (num_frames - seek)[active])
+        n_calls += 1
+        for row, i in enumerate(active):
+            s = seqs[row, n_prompt:total].astype(np.int64)
+            if s[-1] == spec.pad_token_id:                        # strip right padding, keep one eos
+                npad = int((s == spec.pad_token_id).sum())
+                if spec.pad_token_id == spec.eos_token_id:
+                    npad -= 1
+                if npad:
+                    s = s[:-npad]
+            if s[-1] == spec.eos_token_id:
+                s = s[:-1]
+            segs, advance = split_segments(s, token_ts[row], float(seek[i]) * TIME_PRECISION / INPUT_STRIDE, tb,
+                                           int(seek_num[i]), n_prompt)
+            seek[i] += advance
+            segments[i].extend(segs)
+    if stats is not None:
+        stats["generate_calls"] = stats.get("generate_calls", 0) + n_calls
+    seq_list = [np.concatenate([s.tokens for s in segs]) if segs else np.zeros(0, np.int64) for segs in segments]
+    width = max((len(s) for s in seq_list), default=0)
+    sequences = np.full((n_items, width), spec.pad_token_id, dtype=np.int64)
+    for i, s in enumerate(seq_list):
+        sequences[i, :len(s)] = s
+    tts = [np.concatenate([s.token_timestamps for s in segs]) if segs else np.zeros(0, np.float32) for segs in segments]
+    return {"sequences": sequences, "token_timestamps": tts, "segments": segments}

@@ -1,0 +1,206 @@
+"""Drop-in call surface of ``transformers.pipeline("automatic-speech-recognition", ...)`` for the
+CrisperWhisper word-timestamp path (REF/transcribe.py:21-33, REF/app.py:51-61,102).
+
+    pipe = crisperwhisper_amd.pipeline("automatic-speech-recognition", model=model, tokenizer=tok,
+                                       feature_extractor=fe, chunk_length_s=30, batch_size=16,
+                                       return_timestamps="word", torch_dtype=dtype, device="cuda:0")
+    result = pipe(path_or_array)     # {"text": str, "chunks": [{"text", "timestamp": (start, end)}]}
+
+Same argument names, accepted input forms, error types and output schema as
+``AutomaticSpeechRecognitionPipeline`` (TF/pipelines/automatic_speech_recognition.py:190-247, 345-481,
+600-710); the device work goes through libcrisperwhisper.so.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from . import audio, collate, dist, generation, utils
+from ._native import N_SAMPLES
+from .engine import Engine, ModelSpec
+
+logger = logging.getLogger("crisperwhisper_amd")
+
+
+class ModelBundle:
+    """Geometry + generation settings + weights (HF state_dict names -> float32 numpy)."""
+
+    def __init__(self, spec: ModelSpec, weights: Dict[str, np.ndarray]):
+        self.spec = spec
+        self.weights = weights
+
+    @classmethod
+    def from_hf(cls, model) -> "ModelBundle":
+        cfg, gc = model.config, model.generation_config
+        if not hasattr(gc, "alignment_heads"):
+            raise ValueError("Model generation config has no `alignment_heads`, token-level timestamps not available. "
+                             "See https://gist.github.com/hollance/42e32852f24243b748ae6bc1f985b13a on how to add this "
+                             "property to the generation config.")
+        if not hasattr(gc, "no_timestamps_token_id"):
+            raise ValueError("The generation config is outdated: `no_timestamps_token_id` is missing.")
+        spec = ModelSpec(
+            d_model=cfg.d_model, n_heads=cfg.encoder_attention_heads, ffn_dim=cfg.encoder_ffn_dim,
+            enc_layers=cfg.encoder_layers, dec_layers=cfg.decoder_layers, n_mels=cfg.num_mel_bins,
+            vocab_size=cfg.vocab_size, max_target_positions=cfg.max_target_positions,
+            median_filter_width=cfg.median_filter_width,
+            alignment_heads=[list(h) for h in gc.alignment_heads],
+            eos_token_id=gc.eos_token_id if isinstance(gc.eos_token_id, int) else gc.eos_token_id[0],
+            pad_token_id=gc.pad_token_id, decoder_start_token_id=gc.decoder_start_token_id,
+            no_timestamps_token_id=gc.no_timestamps_token_id,
+            max_initial_timestamp_index=getattr(gc, "max_initial_timestamp_index", None),
+            suppress_tokens=list(gc.suppress_tokens or []), begin_suppress_tokens=list(gc.begin_suppress_tokens or []),
+            lang_to_id=dict(getattr(gc, "lang_to_id", {}) or {}), task_to_id=dict(getattr(gc, "task_to_id", {}) or {}),
+            max_length=gc.max_length or cfg.max_target_positions)
+        weights = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items() if k != "proj_out.weight"}
+        return cls(spec, weights)
+
+
+def _dtype_name(dtype) -> str:
+    if dtype is None:
+        return "bf16"
+    s = str(dtype)
+    if "float32" in s or s in ("f32", "fp32"):
+        return "f32"
+    return "bf16"          # float16 / bfloat16 requests run the bf16 MFMA path
+
+
+def _device_index(device) -> int:
+    if device is None:
+        return 0
+    if isinstance(device, int):
+        if device < 0:
+            raise ValueError("crisperwhisper_amd has no CPU path: device must be a GPU (e.g. 'cuda:0')")
+        return device
+    s = str(device)
+    if s == "cpu":
+        raise ValueError("crisperwhisper_amd has no CPU path: device must be a GPU (e.g. 'cuda:0')")
+    return int(s.split(":")[1]) if ":" in s else 0
+
+
+class CrisperWhisperPipeline:
+    def __init__(self, model, tokenizer=None, feature_extractor=None, chunk_length_s=0, stride_length_s=None,
+                 batch_size=1, return_timestamps=None, torch_dtype=None, dtype=None, device=None,
+                 shard: Optional[dist.Shard] = None, **kwargs):
+        self.bundle = model if isinstance(model, ModelBundle) else ModelBundle.from_hf(model)
+        if tokenizer is None:
+            raise ValueError("a tokenizer (WhisperTokenizer or crisperwhisper_amd.collate.Vocabulary) is required")
+        self.vocab = tokenizer if isinstance(tokenizer, collate.Vocabulary) else collate.Vocabulary.from_hf_tokenizer(tokenizer)
+        self.sampling_rate = getattr(feature_extractor, "sampling_rate", audio.SAMPLING_RATE)
+        if feature_extractor is not None and getattr(feature_extractor, "feature_size", self.bundle.spec.n_mels) != self.bundle.spec.n_mels:
+            raise ValueError("feature_extractor.feature_size does not match model.config.num_mel_bins")
+        self.chunk_length_s = chunk_length_s
+        self.stride_length_s = stride_length_s
+        self.batch_size = int(batch_size or 1)
+        self.return_timestamps = return_timestamps
+        self.shard = shard or dist.Shard()
+        self.engine = Engine(self.bundle.spec, dtype=_dtype_name(dtype if dtype is not None else torch_dtype),
+                             max_batch=self.batch_size, device=_device_index(device))
+        self.engine.load_state_dict(self.bundle.weights)
+        utils.bind_engine(self.engine)
+        self.stats: Dict[str, Any] = {}
+
+    # -- input forms (TF/pipelines/automatic_speech_recognition.py:345-430) ------------------------
+    def _load(self, inputs) -> np.ndarray:
+        if isinstance(inputs, str):
+            if inputs.startswith("http://") or inputs.startswith("https://"):
+                raise ValueError("remote URLs are not fetched by the native pipeline; pass a local path or an array")
+            inputs = audio.read_audio(inputs, self.sampling_rate)
+        elif isinstance(inputs, bytes):
+            inputs = audio.decode_wav_bytes(inputs, self.sampling_rate)
+        if hasattr(inputs, "detach") and hasattr(inputs, "cpu"):       # torch.Tensor
+            inputs = inputs.detach().cpu().numpy()
+        if isinstance(inputs, dict):
+            inputs = dict(inputs)
+            inputs.pop("stride", None)
+            if not ("sampling_rate" in inputs and ("raw" in inputs or "array" in inputs)):
+                raise ValueError(
+                    "When passing a dictionary to AutomaticSpeechRecognitionPipeline, the dict needs to contain a "
+                    '"raw" key containing the numpy array or torch tensor representing the audio and a "sampling_rate" key, '
+                    "containing the sampling_rate associated with that array")
+            arr = inputs.pop("raw", None)
+            if arr is None:
+                arr = inputs.pop("array", None)
+            if hasattr(arr, "detach"):
+                arr = arr.detach().cpu().numpy()
+            inputs = audio.resample(np.asarray(arr, dtype=np.float32), int(inputs["sampling_rate"]), self.sampling_rate)
+        if not isinstance(inputs, np.ndarray):
+            raise TypeError(f"We expect a numpy ndarray or torch tensor as input, got `{type(inputs)}`")
+        if inputs.ndim != 1:
+            logger.warning("We expect a single channel audio input for AutomaticSpeechRecognitionPipeline, got %d. "
+                           "Taking the mean of the channels for mono conversion.", inputs.ndim)
+            inputs = inputs.mean(axis=0)
+        return np.ascontiguousarray(inputs, dtype=np.float32)
+
+    def __call__(self, inputs, **kwargs):
+        if isinstance(inputs, (list, tuple)):
+            return [self._run_one(x, **kwargs) for x in inputs]
+        return self._run_one(inputs, **kwargs)
+
+    def _run_one(self, inputs, return_timestamps=None, generate_kwargs=None, chunk_length_s=None,
+                 stride_length_s=None, return_language=None, **unused):
+        rt = return_timestamps if return_timestamps is not None else self.return_timestamps
+        if rt not in ("word",):
+            raise ValueError("crisperwhisper_amd implements the word-timestamp path: pass return_timestamps='word' "
+                             "(CrisperWhisper's purpose, REF/transcribe.py:28)")
+        if return_language:
+            raise ValueError("return_language is not supported on the native path")
+        gk = dict(generate_kwargs or {})
+        pcm = self._load(inputs)
+        cl = self.chunk_length_s if chunk_length_s is None else chunk_length_s
+        sl = self.stride_length_s if stride_length_s is None else stride_length_s
+        sr = self.sampling_rate
+        if cl:
+            if sl is None:
+                sl = cl / 6
+            if isinstance(sl, (int, float)):
+                sl = [sl, sl]
+            chunk_len = int(round(cl * sr))
+            windows = audio.chunk_windows(len(pcm), chunk_len, int(round(sl[0] * sr)), int(round(sl[1] * sr)))
+            if chunk_len > N_SAMPLES:
+                raise ValueError("chunk_length_s must be <= 30 for Whisper")
+            with_stride = True
+        else:
+            if len(pcm) > N_SAMPLES:
+                raise ValueError("audio longer than 30 s needs chunk_length_s=30 (the reference call, REF/transcribe.py:26); "
+                                 "sequential long-form decoding is not implemented on the native path")
+            windows = [(0, len(pcm), (len(pcm), 0, 0), True)]
+            with_stride = False
+
+        lo, hi = dist.shard_bounds(len(windows), self.shard.world)[self.shard.rank]
+        mine = list(range(lo, hi))
+        recs = []
+        for b0 in range(0, len(mine), self.batch_size):
+            idxs = mine[b0:b0 + self.batch_size]
+            clips = [pcm[windows[i][0]: windows[i][0] + windows[i][1]] for i in idxs]
+            _, nf = self.engine.mel(clips)
+            out = generation.generate(
+                self.engine, len(idxs), nf, language=gk.get("language"), task=gk.get("task"),
+                max_new_tokens=gk.get("max_new_tokens"), min_new_tokens=gk.get("min_new_tokens"),
+                num_beams=gk.get("num_beams", 1), stats=self.stats)
+            for k, i in enumerate(idxs):
+                n_tok = len(out["token_timestamps"][k])
+                stride = tuple(x / sr for x in windows[i][2])
+                recs.append(dist.pack_record(i, out["sequences"][k][:n_tok], out["token_timestamps"][k], stride))
+        recs = np.stack(recs) if recs else np.zeros((0, dist.REC_WORDS), np.int32)
+        max_per_rank = max(h - l for l, h in dist.shard_bounds(len(windows), self.shard.world))
+        allr = self.shard.all_gather_records(recs, max_per_rank)
+        outputs = []
+        for r in allr:
+            _, toks, ts, stride = dist.unpack_record(r)
+            o = {"tokens": toks, "token_timestamps": ts}
+            if with_stride:
+                o["stride"] = stride
+            outputs.append(o)
+        text, words = collate.decode_asr(self.vocab, outputs, time_precision=0.02, warn=logger.warning)
+        return {"text": text, "chunks": words}
+
+
+def pipeline(task: str = "automatic-speech-recognition", model=None, tokenizer=None, feature_extractor=None, **kwargs):
+    """Factory with the signature the reference uses (REF/transcribe.py:21-31)."""
+    if task != "automatic-speech-recognition":
+        raise KeyError(f"Unknown task {task}, available tasks are ['automatic-speech-recognition']")
+    if model is None:
+        raise ValueError("a model (WhisperForConditionalGeneration or ModelBundle) is required")
+    return CrisperWhisperPipeline(model, tokenizer=tokenizer, feature_extractor=feature_extractor, **kwargs)

@@ -206,30 +206,65 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.
     return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
 
 
-def random_weights(g: Geometry, seed: int = 0, gain: float = 1.0, dtype=np.float32) -> Dict[str, np.ndarray]:
-    """Seeded random weights with fan-in scaling so activations stay O(1) through the stack and
-    logits / attention rows are *not* near-uniform (HF's N(0, 0.02) init makes a random model
-    degenerate, which would hide argmax / softmax bugs).  numpy's Generator stream is stable, so
-    the golden generator and the GPU-side tests rebuild identical tensors from the seed."""
+def _unit_uniform(rng, shape):
+    """Zero-mean, unit-variance uniform noise in float32 (fast enough for 1.5 B parameters)."""
+    return (rng.random(shape, dtype=np.float32) - np.float32(0.5)) * np.float32(np.sqrt(12.0))
+
+
+def random_tensor(g: Geometry, name: str, shape, seed: int = 0, gain: float = 1.0) -> np.ndarray:
+    """One seeded random tensor.  Fan-in scaling keeps activations O(1) through the stack and makes
+    logits / attention rows *not* near-uniform (HF's N(0, 0.02) init gives a degenerate random model
+    that would hide argmax / softmax bugs).  The stream depends only on (seed, name): numpy's
+    Generator is stable, so the golden generator (build container) and the GPU-side tests rebuild
+    identical tensors."""
+    import zlib
+    rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+    if name == "model.encoder.embed_positions.weight":
+        return sinusoids(*shape)
+    if name.endswith("layer_norm.weight"):
+        return (1.0 + 0.1 * _unit_uniform(rng, shape)).astype(np.float32)
+    if name.endswith(".bias"):
+        return (0.1 * _unit_uniform(rng, shape)).astype(np.float32)
+    if name == "model.decoder.embed_tokens.weight":
+        return (_unit_uniform(rng, shape) * np.float32(2.0 * gain / np.sqrt(shape[1]))).astype(np.float32)
+    if name == "model.decoder.embed_positions.weight":
+        return (_unit_uniform(rng, shape) * np.float32(0.1)).astype(np.float32)
+    s = gain / np.sqrt(float(np.prod(shape[1:])))
+    if ".q_proj." in name or ".k_proj." in name:
+        s *= 2.0  # sharper attention rows
+    return (_unit_uniform(rng, shape) * np.float32(s)).astype(np.float32)
+
+
+def random_weights(g: Geometry, seed: int = 0, gain: float = 1.0) -> Dict[str, np.ndarray]:
+    return {name: random_tensor(g, name, shape, seed, gain) for name, shape in weight_shapes(g).items()}
+
+
+def model_spec(g: Geometry, v: SynthVocab, n_align: int = 15):
+    """ModelSpec (crisperwhisper_amd.engine) for a synthetic geometry/vocabulary."""
+    from .engine import ModelSpec
+    return ModelSpec(
+        d_model=g.d_model, n_heads=g.heads, ffn_dim=g.ffn, enc_layers=g.enc_layers, dec_layers=g.dec_layers,
+        n_mels=g.n_mels, vocab_size=g.vocab, max_target_positions=g.max_target_positions,
+        median_filter_width=g.median_filter_width, alignment_heads=alignment_heads(g, n_align),
+        eos_token_id=v.eos, pad_token_id=v.eos, decoder_start_token_id=v.sot,
+        no_timestamps_token_id=v.notimestamps, max_initial_timestamp_index=50,
+        suppress_tokens=v.suppress_tokens(), begin_suppress_tokens=v.begin_suppress_tokens(),
+        lang_to_id={f"<|{l}|>": v.lang_id(l) for l in SYNTH_LANGS},
+        task_to_id={"translate": v.translate, "transcribe": v.transcribe}, max_length=g.max_target_positions)
+
+
+def synth_audio(seed: int, n: int, kind: str = "noise") -> np.ndarray:
+    """Synthetic 16 kHz mono audio (noise, hard-zero spans, chirp)."""
     rng = np.random.default_rng(seed)
-    out: Dict[str, np.ndarray] = {}
-    for name, shape in weight_shapes(g).items():
-        if name == "model.encoder.embed_positions.weight":
-            out[name] = sinusoids(*shape)
-            continue
-        if name.endswith("layer_norm.weight"):
-            w = 1.0 + 0.1 * rng.standard_normal(shape)
-        elif name.endswith(".bias"):
-            w = 0.1 * rng.standard_normal(shape)
-        elif name == "model.decoder.embed_tokens.weight":
-            w = rng.standard_normal(shape) * (2.0 * gain / np.sqrt(shape[1]))
-        elif name == "model.decoder.embed_positions.weight":
-            w = rng.standard_normal(shape) * 0.1
-        else:
-            fan_in = int(np.prod(shape[1:]))
-            s = gain / np.sqrt(fan_in)
-            if ".q_proj." in name or ".k_proj." in name:
-                s *= 2.0  # sharper attention rows
-            w = rng.standard_normal(shape) * s
-        out[name] = w.astype(dtype)
-    return out
+    if kind == "noise":
+        return (rng.standard_normal(n) * 0.1).astype(np.float32)
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    if kind == "chirp":
+        return (0.3 * np.sin(2 * np.pi * (100.0 * t + 0.5 * 250.0 * t * t))).astype(np.float32)
+    if kind == "mixed":
+        x = rng.standard_normal(n) * 0.05
+        x += 0.2 * np.sin(2 * np.pi * 440.0 * t) * (np.sin(2 * np.pi * 0.7 * t) > 0)
+        k = n // 5
+        x[k:2 * k] = 0.0  # hard silence: exercises clamp 1e-10 and the max-8 floor
+        return x.astype(np.float32)
+    raise ValueError(kind)

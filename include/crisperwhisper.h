@@ -1,0 +1,143 @@
+/*
+ * crisperwhisper.h -- C ABI of the MI355X-native CrisperWhisper inference-and-alignment path.
+ *
+ * The reference (nyrahealth/CrisperWhisper @ 2024-10-22) has no FFI layer: its hot path is reached
+ * through the HuggingFace pipeline object protocol (REF/transcribe.py:21-33).  This header declares
+ * the device-side replacement for each internal seam of that protocol; the
+ * Python shim in crisperwhisper_amd/ binds it with ctypes and re-implements the
+ * pipeline call surface on top.  "TF/" = site-packages/transformers 5.15.0, "REF/" = the reference.
+ *
+ * Conventions: every function returns 0 on success or a negative errno-style code (cw_last_error()
+ * gives the message); no exceptions cross the ABI; all pointer arguments are caller-owned HOST
+ * buffers unless the name ends in _dev; the context owns all device memory and one HIP stream; one
+ * context per device per process; a context is not re-entrant (external locking).
+ */
+#ifndef CRISPERWHISPER_H
+#define CRISPERWHISPER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cw_ctx cw_ctx;
+
+#define CW_DTYPE_F32 0   /* parity mode: f32 weights, activations and arithmetic                       */
+#define CW_DTYPE_BF16 1  /* performance mode: bf16 weights/activations, f32 accumulation + residuals   */
+
+#define CW_N_SAMPLES 480000  /* 30 s @ 16 kHz  (TF/models/whisper/feature_extraction_whisper.py:88-93) */
+#define CW_N_FRAMES 3000     /* mel frames per window                                                  */
+#define CW_N_CTX 1500        /* encoder frames (max_source_positions)                                  */
+
+/* Model geometry: the fields of WhisperConfig the path reads (TF/models/whisper/configuration_whisper.py). */
+typedef struct {
+    int32_t d_model, n_heads, ffn_dim, enc_layers, dec_layers, n_mels, vocab_size;
+    int32_t max_target_positions;   /* 448                                                             */
+    int32_t median_filter_width;    /* config.median_filter_width, read at generation_whisper.py:346   */
+    int32_t dtype;                  /* CW_DTYPE_*                                                      */
+    int32_t max_batch;              /* chunks in flight (pipeline batch_size, REF/transcribe.py:27)    */
+    int32_t n_align;                /* generation_config.alignment_heads                               */
+    const int32_t* align_layers;    /* [n_align]                                                       */
+    const int32_t* align_heads;     /* [n_align]                                                       */
+} cw_model_desc;
+
+/* Generation settings: what WhisperGenerationMixin.generate derives from generation_config
+ * (TF/models/whisper/generation_whisper.py:650-722, 1774-1812).                                       */
+typedef struct {
+    int32_t eos_token_id, pad_token_id;
+    int32_t no_timestamps_token_id;          /* timestamp_begin = this + 1                              */
+    int32_t max_initial_timestamp_index;     /* < 0: unset                                              */
+    const int32_t* suppress_tokens; int32_t n_suppress;
+    const int32_t* begin_suppress_tokens; int32_t n_begin_suppress;
+} cw_gen_cfg;
+
+int32_t cw_abi_version(void);
+cw_ctx* cw_create(const cw_model_desc* desc, int32_t device);
+void cw_destroy(cw_ctx* ctx);
+const char* cw_last_error(cw_ctx* ctx);          /* ctx may be NULL after a failed cw_create           */
+int32_t cw_sync(cw_ctx* ctx);
+
+/* Weights: one call per tensor of WhisperForConditionalGeneration.state_dict() (HF names, f32 host data,
+ * replaces AutoModelForSpeechSeq2Seq.from_pretrained + model.to(device), REF/transcribe.py:14-17).
+ * The context fuses q/k/v projections, folds the 1/8 query scale (modeling_whisper.py:309) and re-lays
+ * the conv kernels for implicit GEMM.  proj_out.weight is tied to embed_tokens (:965) and ignored.     */
+int32_t cw_load_tensor(cw_ctx* ctx, const char* hf_name, const float* data, const int64_t* shape, int32_t ndim);
+int32_t cw_set_generation(cw_ctx* ctx, const cw_gen_cfg* cfg);
+
+/* ---- seam 1: feature extractor (WhisperFeatureExtractor.__call__, feature_extraction_whisper.py:193-346)
+ * pcm: [B][n_samples[b]] packed back to back (each <= CW_N_SAMPLES; zero-padded to 30 s on device).
+ * feats_out (nullable): [B][n_mels][3000] f32, HF layout.  n_frames_out (nullable): attention_mask.sum(-1).
+ * Features stay resident in the context as items 0..B-1 for cw_encode.                                 */
+int32_t cw_mel(cw_ctx* ctx, const float* pcm, int32_t B, const int32_t* n_samples, float* feats_out,
+               int32_t* n_frames_out);
+/* Same, split so a benchmark can keep the PCM resident in HBM and time only device work.               */
+int32_t cw_upload_pcm(cw_ctx* ctx, const float* pcm, int32_t B, const int32_t* n_samples);
+int32_t cw_mel_resident(cw_ctx* ctx, int32_t B);
+/* Test hook: install externally computed features ([B][n_mels][3000] f32) as items 0..B-1.             */
+int32_t cw_set_features(cw_ctx* ctx, const float* feats, int32_t B);
+
+/* ---- seam 2: model.generate, split into its device stages ------------------------------------------
+ * cw_encode: WhisperEncoder.forward (modeling_whisper.py:590-646) on the 3000-frame windows
+ *   features[item[i]][:, seek[i] : seek[i] + n_frames[i]] zero-padded to 3000 (generation_whisper.py:1831-1852),
+ *   followed by the cross-attention K/V projection of all decoder layers (:322-335).                   */
+int32_t cw_encode(cw_ctx* ctx, int32_t nb, const int32_t* item, const int32_t* seek, const int32_t* n_frames);
+int32_t cw_get_encoder_output(cw_ctx* ctx, float* out /* [nb][1500][d_model] */, int32_t nb);
+
+/* cw_decode: one greedy GenerationMixin.generate call (TF/generation/utils.py:2783-2973) over the nb
+ * encoded windows: decoder forward with KV caches, logits processors (logits_process.py:203-260,
+ * 1816-2047), argmax, eos/pad bookkeeping, until every row is finished.  Alignment-head cross-attention
+ * rows are retained on device for cw_token_timestamps.
+ *   prompt [nb][n_prompt]; max_new_tokens < 0: bounded by max_length; forced (nullable) [nb][max_target]:
+ *   entries >= 0 teacher-force that sequence position (the un-forced choice still goes to argmax_out).
+ *   sequences [nb][max_target] (prompt included), lengths [nb] = prompt + generated,
+ *   argmax_out (nullable) [nb][max_target].                                                            */
+int32_t cw_decode(cw_ctx* ctx, int32_t nb, const int32_t* prompt, int32_t n_prompt, int32_t max_length,
+                  int32_t min_new_tokens, const int32_t* forced, int32_t* sequences, int32_t* lengths,
+                  int32_t* argmax_out);
+int32_t cw_get_logits(cw_ctx* ctx, float* out /* [nb][vocab] */, int32_t nb);       /* last sampled step */
+int32_t cw_set_logits_capture(cw_ctx* ctx, float* host_buf, int32_t max_steps);    /* [steps][nb][vocab] */
+int32_t cw_get_alignment(cw_ctx* ctx, float* out /* [nb][n_align][L][1500] */, int32_t nb, int32_t L);
+
+/* cw_token_timestamps: _extract_token_timestamps (generation_whisper.py:241-381) on the retained rows:
+ * crop to num_frames[b]//2 encoder frames, drop the n_prompt prompt rows, z-score over tokens, median
+ * filter, head mean, DTW, jump times.  L = rows retained = max(lengths) - 1.  ts_out [nb][L+1] seconds. */
+int32_t cw_token_timestamps(cw_ctx* ctx, int32_t nb, int32_t L, int32_t n_prompt, const int32_t* num_frames,
+                            float* ts_out);
+
+/* ---- stand-alone differential-test entry points for the alignment kernels ---------------------------- */
+/* attn [B][Ha][N][M] -> mat [B][N][M] (z-score, median(width), head mean); n_cols[b] <= M columns used.  */
+int32_t cw_align_matrix(cw_ctx* ctx, const float* attn, int32_t B, int32_t Ha, int32_t N, int32_t M,
+                        const int32_t* n_cols, int32_t width, float* mat_out);
+/* _dynamic_time_warping(-mat) (generation_whisper.py:64-115): text_idx/time_idx [N+M] forward order.    */
+int32_t cw_dtw(cw_ctx* ctx, const float* mat, int32_t N, int32_t M, int32_t* text_idx, int32_t* time_idx,
+               int32_t* path_len);
+/* ---- seam 4: adjust_pauses_for_hf_pipeline_output (REF/utils.py:1-29) on word start/end arrays, in place */
+int32_t cw_adjust_pauses(cw_ctx* ctx, double* start, double* end, int32_t W, double split_threshold);
+
+/* ---- kernel-level hooks used by the parity tests (host f32 in/out, run in the context's dtype) -------- */
+int32_t cw_test_gemm(cw_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, const float* W,
+                     const float* bias, int32_t gelu, float* out);
+int32_t cw_test_gemv(cw_ctx* ctx, int32_t Mb, int32_t N, int32_t K, const float* x, const float* W,
+                     const float* bias, const float* ln_g, const float* ln_b, int32_t gelu, float* out);
+int32_t cw_test_attention(cw_ctx* ctx, int32_t B, int32_t H, int32_t S, const float* q, const float* k,
+                          const float* v, float* out /* [B][S][H*64] */);
+
+/* ---- measurement -------------------------------------------------------------------------------------- */
+#define CW_STAGE_MEL 0
+#define CW_STAGE_ENCODER 1
+#define CW_STAGE_CROSS_KV 2
+#define CW_STAGE_DECODE 3
+#define CW_STAGE_TIMESTAMPS 4
+#define CW_N_STAGES 5
+/* Accumulated HIP-event time per stage (ms) and number of timed invocations since the last reset.        */
+int32_t cw_stage_times(cw_ctx* ctx, float* ms /* [CW_N_STAGES] */, int32_t* calls /* [CW_N_STAGES] */, int32_t reset);
+/* Times `iters` back-to-back launches of one decode-step kernel on the context's stream with HIP events:
+ * which = 0 decode GEMV (fc1 of decoder layer 0, LN fused), 1 cross-attention decode (layer 0).
+ * Returns average ms per launch and the algorithmic bytes one launch must move.                          */
+int32_t cw_time_kernel(cw_ctx* ctx, int32_t which, int32_t nb, int32_t iters, float* avg_ms, double* algo_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

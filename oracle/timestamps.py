@@ -98,23 +98,45 @@ def normalise_filter_mean(w: np.ndarray, median_width: int) -> np.ndarray:
     return z.mean(axis=0, dtype=np.float32)
 
 
+def effective_cols(num_frames, S: int):
+    """Columns of the [.., S] attention map that reach the DTW, with HF's exact slicing semantics:
+    when every item has the same ``num_frames`` the map is cropped to ``[..., :nf // 2]`` for the whole
+    batch (:318-323) *and again* per item inside the loop (:354); otherwise only per item.  With a
+    positive ``nf // 2 <= S`` both give nf // 2; for ``nf <= 0`` (seek ran past the audio: a random
+    model can emit a 29 s timestamp in a 12 s clip) Python's negative-stop slicing applies, possibly
+    twice, and may leave zero columns."""
+    nf = np.asarray(num_frames, dtype=np.int64)
+    half = nf // 2                                   # floor division, like torch / Python
+    uniform = len(np.unique(nf)) == 1
+    out = []
+    for h in half.tolist():
+        n1 = len(range(S)[:h])
+        out.append(len(range(n1)[:h]) if uniform else n1)
+    return out
+
+
 def extract_token_timestamps(weights: np.ndarray, num_frames, num_input_ids: int, median_width: int,
                              time_precision: float = 0.02) -> np.ndarray:
     """weights [B, H_a, L, S] f32 (alignment-head rows, prompt rows included) -> [B, L+1] f32.
 
-    num_frames: per-item mel-frame counts (array) or None.  Mirrors :304-381 for the
-    greedy (no beam_indices) path; the per-item branch (:352-363) and the uniform branch
-    (:341-349) compute the same values, so one code path is used."""
+    num_frames: per-item mel-frame counts (array) or None.  Mirrors :304-381 for the greedy
+    (no beam_indices) path, including the double crop of the uniform case (see effective_cols)."""
     B, H, L, S = weights.shape
     ts = np.zeros((B, L + 1), dtype=np.float32)
     w = weights[:, :, num_input_ids:, :]
-    if w.shape[2] == 0:
+    N = w.shape[2]
+    if N == 0:
         return ts
+    cols = [S] * B if num_frames is None else effective_cols(num_frames, S)
     for b in range(B):
-        nf = S if num_frames is None else int(num_frames[b]) // 2
-        mat = normalise_filter_mean(w[b, :, :, :nf], median_width)
-        ti, tj = dtw(-mat.astype(np.float64))
-        jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
-        jump_times = (tj[jumps] * time_precision)
+        nf = cols[b]
+        if nf == 0:
+            # _dynamic_time_warping on an [N, 0] matrix: backtrace walks up column 0, time index -1
+            jump_times = np.full(N, -1 * time_precision)
+        else:
+            mat = normalise_filter_mean(w[b, :, :, :nf], median_width)
+            ti, tj = dtw(-mat.astype(np.float64))
+            jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+            jump_times = (tj[jumps] * time_precision)
         ts[b] = np.concatenate([np.zeros(num_input_ids), jump_times, jump_times[-1:]]).astype(np.float32)
     return ts

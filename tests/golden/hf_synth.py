@@ -99,19 +99,4 @@ def state_dict_numpy(model):
             if k != "proj_out.weight"}
 
 
-def synth_audio(seed: int, n: int, kind: str = "noise") -> np.ndarray:
-    """Synthetic 16 kHz mono audio (noise, hard-zero spans, chirp)."""
-    rng = np.random.default_rng(seed)
-    if kind == "noise":
-        return (rng.standard_normal(n) * 0.1).astype(np.float32)
-    t = np.arange(n, dtype=np.float64) / 16000.0
-    if kind == "chirp":
-        x = 0.3 * np.sin(2 * np.pi * (100.0 * t + 0.5 * 250.0 * t * t))
-        return x.astype(np.float32)
-    if kind == "mixed":
-        x = rng.standard_normal(n) * 0.05
-        x += 0.2 * np.sin(2 * np.pi * 440.0 * t) * (np.sin(2 * np.pi * 0.7 * t) > 0)
-        k = n // 5
-        x[k:2 * k] = 0.0  # hard silence: exercises clamp 1e-10 and the max-8 floor
-        return x.astype(np.float32)
-    raise ValueError(kind)
+synth_audio = syn.synth_audio

@@ -1,0 +1,103 @@
+"""Shared test scaffolding (test infrastructure: may import oracle/)."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from crisperwhisper_amd import collate, synthetic as syn
+from oracle import collate as OC
+from oracle import generate as OG
+from oracle import timestamps as OT
+from oracle.model import WhisperOracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GEN_KW = {"num_beams": 1, "language": "<|en|>", "task": "transcribe"}
+
+
+def gold_npz(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def gold_json(name):
+    return json.load(open(os.path.join(GOLD, name)))
+
+
+def tiny_setup(seed=0, n_align=3):
+    g, v = syn.tiny_geometry()
+    W = syn.random_weights(g, seed=seed)
+    spec = syn.model_spec(g, v, n_align)
+    return g, v, W, spec
+
+
+def oracle_spec(g, v, spec):
+    return OG.GenSpec(eos=v.eos, pad=v.eos, sot=v.sot, no_timestamps=v.notimestamps, lang_to_id=spec.lang_to_id,
+                      task_to_id=spec.task_to_id, alignment_heads=[list(h) for h in spec.alignment_heads],
+                      suppress=v.suppress_tokens(), begin_suppress=v.begin_suppress_tokens(),
+                      max_initial_timestamp_index=50, max_length=g.max_target_positions,
+                      median_filter_width=g.median_filter_width)
+
+
+def oracle_vocab(v):
+    return OC.ByteVocab(v.token_bytes(), v.special_names(), v.eos, v.timestamp_begin, v.startofprev, v.sot)
+
+
+def words_equal(got, want, tol=0.0):
+    """word-for-word text equality, |dt| <= tol."""
+    if len(got) != len(want):
+        return False, f"{len(got)} words vs {len(want)}"
+    for i, (a, b) in enumerate(zip(got, want)):
+        if a["text"] != b["text"]:
+            return False, f"word {i}: {a['text']!r} vs {b['text']!r}"
+        for x, y in zip(a["timestamp"], b["timestamp"]):
+            if abs(x - y) > tol + 1e-9:
+                return False, f"word {i} ({a['text']!r}): {a['timestamp']} vs {b['timestamp']}"
+    return True, ""
+
+
+class OracleBackedEngine:
+    """Stands in for crisperwhisper_amd.engine.Engine in CPU tests of the *host* control flow
+    (generation.generate / pipeline): same method contract, arithmetic done by the oracle."""
+
+    def __init__(self, g, v, W, spec):
+        from oracle import mel as OM
+        self.OM = OM
+        self.spec = spec
+        self.g = g
+        self.model = WhisperOracle(W, g)
+        self.ospec = oracle_spec(g, v, spec)
+        self.max_batch = 64
+
+    def mel(self, clips, return_features=False):
+        pcm = np.zeros((len(clips), self.OM.N_SAMPLES), np.float32)
+        nf = np.zeros(len(clips), np.int32)
+        for i, c in enumerate(clips):
+            pcm[i], nv = self.OM.pad_or_trim(c)
+            nf[i] = self.OM.attention_mask_frames(nv)
+        self.feats = self.OM.log_mel(pcm, self.g.n_mels)
+        return (self.feats if return_features else None), nf
+
+    def encode(self, item, seek, n_frames):
+        seg = np.zeros((len(item), self.g.n_mels, 3000), np.float32)
+        for i, (it, s, n) in enumerate(zip(item, seek, n_frames)):
+            seg[i, :, :n] = self.feats[it, :, s:s + n]
+        self.enc = self.model.encode(seg)
+
+    def decode(self, prompt, max_length, min_new_tokens=0, forced=None, want_argmax=False):
+        prompt = np.asarray(prompt, dtype=np.int64)
+        n_prompt = prompt.shape[1]
+        seqs, weights = OG.greedy(self.model, self.ospec, self.enc, prompt, begin_index=n_prompt,
+                                  max_new_tokens=max_length - n_prompt, min_new_tokens=min_new_tokens)
+        self.weights = weights
+        out = np.full((seqs.shape[0], self.spec.max_target_positions), self.spec.pad_token_id, np.int32)
+        out[:, :seqs.shape[1]] = seqs
+        lens = np.full(seqs.shape[0], seqs.shape[1], np.int32)
+        return out, lens, None
+
+    def token_timestamps(self, nb, L, n_prompt, num_frames):
+        assert self.weights.shape[2] == L
+        return OT.extract_token_timestamps(self.weights, num_frames, n_prompt, self.g.median_filter_width)
+
+    def adjust_pauses(self, start, end, thr):
+        raise AssertionError("pause splitting must run on the device in product code")

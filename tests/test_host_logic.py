@@ -1,0 +1,117 @@
+"""CPU tests of the product's host-side logic (no GPU): chunk scheduling, seek-loop control flow,
+word collation, record packing, C-ABI surface.  Device arithmetic is stood in by an oracle-backed
+engine double (tests/helpers.py) so that only the *host* code under test is the product's."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from crisperwhisper_amd import _native, audio, collate, dist, generation, synthetic as syn
+from oracle import collate as OC
+from oracle import pipeline as OPIPE
+from tests import helpers as Hh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "crisperwhisper.h")).read()
+    declared = sorted(set(re.findall(r"\b(cw_[a-z_0-9]+)\s*\(", hdr)))
+    lib = _native.load()                      # loads without a GPU: no compute call is made here
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/crisperwhisper.h but not exported"
+    assert sorted(_native.exported_symbols()) == declared
+    assert lib.cw_abi_version() == 1
+
+
+def w_eq(a, b):
+    return [tuple(x) for x in a] == [tuple(x) for x in b]
+
+
+def test_chunk_windows_match_oracle_and_survey():
+    # 10-minute stream -> 30 chunks, hop 20 s, last is 20 s
+    w = audio.chunk_windows(9_600_000, 480_000, 80_000, 80_000)
+    assert len(w) == 30 and w[0][2] == (480000, 0, 80000) and w[-1][1] == 320000 and w[-1][2] == (320000, 80000, 0)
+    for n in (1, 79_999, 80_001, 480_000, 480_001, 1_120_000, 9_600_000):
+        assert w_eq(audio.chunk_windows(n, 480_000, 80_000, 80_000), OPIPE.chunk_iter(n, 480_000, 80_000, 80_000))
+    with pytest.raises(ValueError):
+        audio.chunk_windows(100, 10, 6, 6)
+
+
+def test_shard_bounds_and_records():
+    assert [h - l for l, h in dist.shard_bounds(30, 8)] == [4, 4, 4, 4, 4, 4, 3, 3]
+    assert dist.shard_bounds(3, 8)[3] == (3, 3)
+    rec = dist.pack_record(7, np.array([1, 2, 300]), np.array([0.5, 1.25], np.float32), (30.0, 5.0, 0.0))
+    idx, toks, ts, stride = dist.unpack_record(rec)
+    assert idx == 7 and toks.tolist() == [1, 2, 300] and ts.tolist() == [0.5, 1.25] and stride == (30.0, 5.0, 0.0)
+
+
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24"])
+def test_host_control_flow_word_for_word(name):
+    """generation.generate + collate.decode_asr (product host code) over the oracle-backed engine
+    reproduce the reference pipeline output word for word."""
+    g, v, W, spec = Hh.tiny_setup()
+    meta = Hh.gold_json("e2e_golden.json")[name]
+    z = Hh.gold_npz("e2e_golden.npz")
+    x = syn.synth_audio(meta["seed"], meta["secs"] * 16000, meta["kind"])
+    eng = Hh.OracleBackedEngine(g, v, W, spec)
+    vocab = collate.Vocabulary.from_synthetic(v)
+    windows = audio.chunk_windows(len(x), 480000, 80000, 80000)
+    outputs, call = [], 0
+    for b0 in range(0, len(windows), meta["batch_size"]):
+        batch = windows[b0:b0 + meta["batch_size"]]
+        _, nf = eng.mel([x[s:s + n] for s, n, _, _ in batch])
+        out = generation.generate(eng, len(batch), nf, language="<|en|>", task="transcribe",
+                                  max_new_tokens=meta["extra"].get("max_new_tokens"),
+                                  min_new_tokens=meta["extra"].get("min_new_tokens"))
+        assert np.array_equal(out["sequences"], z[f"{name}/call{call}/sequences"])
+        for k, (_, _, st, _) in enumerate(batch):
+            assert np.array_equal(out["token_timestamps"][k], z[f"{name}/call{call}/tts{k}"])
+            n = len(out["token_timestamps"][k])
+            outputs.append({"tokens": out["sequences"][k][:n], "token_timestamps": out["token_timestamps"][k],
+                            "stride": tuple(t / 16000 for t in st)})
+        call += 1
+    text, words = collate.decode_asr(vocab, outputs)
+    assert text == meta["text"]
+    ok, why = Hh.words_equal(words, meta["chunks"])
+    assert ok, why
+
+
+def test_collation_matches_oracle_on_random_token_streams():
+    """Random byte/timestamp streams with strides: product collation == oracle restatement
+    (itself pinned to transformers by the e2e goldens)."""
+    g, v = syn.tiny_geometry()
+    pv, ov = collate.Vocabulary.from_synthetic(v), Hh.oracle_vocab(v)
+    rng = np.random.default_rng(11)
+    tb = v.timestamp_begin
+    for trial in range(60):
+        outs = []
+        n_chunks = int(rng.integers(1, 4))
+        for c in range(n_chunks):
+            toks, t = [], 0
+            for _ in range(int(rng.integers(1, 5))):
+                t0 = t + int(rng.integers(0, 200)); t1 = t0 + int(rng.integers(1, 300)); t = min(t1, 1500)
+                body = rng.choice([32, 32, 46, 44, 39, 40, 65, 66, 97, 98, 99, 0xc3, 0xa9, 0xe2, 0x82, 0xac], size=int(rng.integers(1, 12))).tolist()
+                toks += [tb + min(t0, 1500)] + body + [tb + t]
+                if rng.random() < 0.3:
+                    toks = toks[:-1]                       # unterminated segment
+            ts = np.round(np.sort(rng.random(len(toks)) * 30), 2).astype(np.float32)
+            sl = 0.0 if c == 0 else 5.0
+            sr = 0.0 if c == n_chunks - 1 else 5.0
+            outs.append({"tokens": np.array(toks), "token_timestamps": ts, "stride": (30.0, sl, sr)})
+        a = collate.decode_asr(pv, [dict(o) for o in outs])
+        b = OC.decode_asr(ov, [dict(o) for o in outs])
+        assert a[0] == b[0], trial
+        ok, why = Hh.words_equal(a[1], b[1])
+        assert ok, (trial, why)
+
+
+def test_init_tokens_errors_mirror_reference():
+    g, v, W, spec = Hh.tiny_setup()
+    assert generation.init_tokens(spec, "<|en|>", "transcribe") == [v.sot, v.lang_id("en"), v.transcribe]
+    assert generation.init_tokens(spec, "de", None) == [v.sot, v.lang_id("de"), v.transcribe]
+    with pytest.raises(ValueError):
+        generation.init_tokens(spec, "<|xx|>", "transcribe")
+    with pytest.raises(ValueError):
+        generation.init_tokens(spec, "<|en|>", "summarize")

@@ -1,0 +1,82 @@
+"""Pins oracle/ against the golden fixtures produced by the reference's dependency
+(tests/golden/gen_golden.py, transformers 5.15.0) and REF/utils.py.  CPU only."""
+import numpy as np
+import pytest
+
+from crisperwhisper_amd import synthetic as syn
+from oracle import mel as OM
+from oracle import pauses as OP
+from oracle import pipeline as OPIPE
+from oracle import timestamps as OT
+from oracle.model import WhisperOracle
+from tests import helpers as Hh
+
+MEL_TOL = 1e-4   # abs, SURVEY.md 8c (HF's own torch-vs-numpy paths differ by 6e-5 on these clips)
+
+
+@pytest.mark.parametrize("kind,n", [("noise", 480000), ("mixed", 320000), ("chirp", 480000), ("noise_short", 12345)])
+def test_mel_matches_hf(kind, n):
+    g = Hh.gold_npz("mel_golden.npz")
+    x = syn.synth_audio(1, n, kind.split("_")[0])
+    xp, nv = OM.pad_or_trim(x)
+    f = OM.log_mel(xp[None], 128)[0]
+    assert np.abs(f[:, ::5] - g[f"{kind}_feats_sub"]).max() < MEL_TOL
+    assert OM.attention_mask_frames(nv) == int(g[f"{kind}_nframes"])
+    assert abs(f.astype(np.float64).sum() - float(g[f"{kind}_checksum"])) < 1e-4 * f.size * 1e-2
+
+
+def test_dtw_matches_hf_exactly():
+    g = Hh.gold_npz("align_golden.npz")
+    for ci in range(6):
+        m = g[f"dtw{ci}_m"]
+        for fn in (OT.dtw, OT.dtw_python):
+            ti, tj = fn(-m.astype(np.float64))
+            assert np.array_equal(ti, g[f"dtw{ci}_ti"]) and np.array_equal(tj, g[f"dtw{ci}_tj"]), (ci, fn.__name__)
+    ti, tj = OT.dtw(np.zeros((3, 4)))
+    assert ti.tolist() == [0, 1, 2, 2, 2, 2] and tj.tolist() == [0, 0, 0, 1, 2, 3]   # SURVEY appendix A probe
+    assert np.array_equal(ti, g["dtw_zero_ti"]) and np.array_equal(tj, g["dtw_zero_tj"])
+
+
+def test_median_and_matrix_match_hf():
+    g = Hh.gold_npz("align_golden.npz")
+    for ci in range(4):
+        a, w = g[f"am{ci}_a"], int(g[f"am{ci}_w"])
+        assert np.array_equal(OT.median_filter(a, w), g[f"am{ci}_med"])
+        mat = OT.normalise_filter_mean(a, w)
+        assert np.allclose(mat, g[f"am{ci}_mat"], rtol=1e-5, atol=2e-5), ci
+
+
+def test_pauses_match_reference():
+    for case in Hh.gold_json("pauses_golden.json"):
+        inp = {"text": "x", "chunks": [{"text": c["text"], "timestamp": tuple(c["timestamp"])} for c in case["in"]]}
+        out = OP.adjust_pauses_for_hf_pipeline_output(inp, split_threshold=case["thr"])
+        assert [list(c["timestamp"]) for c in out["chunks"]] == [c["timestamp"] for c in case["out"]]
+
+
+def test_teacher_forced_logits_and_cross_attention():
+    g, v, W, spec = Hh.tiny_setup()
+    z = Hh.gold_npz("e2e_golden.npz")
+    x = syn.synth_audio(0, 70 * 16000, "mixed")[:480000]
+    feats = OM.log_mel(x[None], g.n_mels)
+    assert np.abs(feats[0][:, ::5] - z["tf/feats_sub"]).max() < MEL_TOL
+    orc = WhisperOracle(W, g)
+    enc = orc.encode(feats)
+    assert np.abs(enc[0][::10] - z["tf/enc_sub"]).max() < 2e-4
+    cache = orc.new_cache(enc)
+    logits, cross = orc.decode(z["tf/ids"], cache, want_heads=[list(h) for h in spec.alignment_heads], all_logits=True)
+    assert np.abs(logits[0] - z["tf/logits"]).max() < 2e-3
+    assert (logits[0].argmax(-1) == z["tf/logits"].argmax(-1)).all()
+    assert np.abs(cross[0] - z["tf/cross"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24"])
+def test_pipeline_word_for_word(name):
+    g, v, W, spec = Hh.tiny_setup()
+    meta = Hh.gold_json("e2e_golden.json")[name]
+    x = syn.synth_audio(meta["seed"], meta["secs"] * 16000, meta["kind"])
+    orc = WhisperOracle(W, g)
+    out = OPIPE.transcribe(orc, Hh.oracle_spec(g, v, spec), Hh.oracle_vocab(v), x, n_mels=g.n_mels,
+                           batch_size=meta["batch_size"], **meta["extra"])
+    assert out["text"] == meta["text"]
+    ok, why = Hh.words_equal(out["chunks"], meta["chunks"], tol=0.0)
+    assert ok, why
