@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric on MI355X: RTF + aligned words/s for the full CrisperWhisper path
+(log-mel -> Whisper large-v3-geometry encoder/decoder -> alignment-head capture -> z-score/median/DTW
+-> word collation -> pause split) on batches of 30 s synthetic 16 kHz clips.
+
+    python bench.py --gpus 1 --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the whole path over one batch of B x 30 s clips per GPU (weak scaling: every
+rank processes its own B clips; the only collective is the all-gather of per-chunk word records).
+PCM is resident in HBM before the timed region (PCIe-inclusive rate: see DESIGN.md).  Weights are
+seeded random tensors of the large-v3 geometry (no checkpoint is available offline): data="synthetic".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="30 s chunks in flight per GPU (BASELINE config[1]: 8)")
+    ap.add_argument("--tokens", type=int, default=128, help="generated tokens per chunk (SURVEY.md 8d)")
+    ap.add_argument("--geometry", default="large-v3", choices=["large-v3", "tiny"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=12)
+    ap.add_argument("--kernel-iters", type=int, default=200)
+    return ap.parse_args()
+
+
+def cpu_baseline(g, v, spec, weights, n_tok_gpu, words_per_chunk, cpu_tokens):
+    """Reference algorithm on the host cores: the numpy/C oracle (kind="port") on a bounded sample --
+    one 30 s clip, `cpu_tokens` new tokens -- extrapolated to the GPU workload's token count."""
+    from oracle import generate as OG
+    from oracle import mel as OM
+    from oracle import timestamps as OT
+    from oracle.model import WhisperOracle
+    from crisperwhisper_amd import synthetic as syn
+    x = syn.synth_audio(0, 480000, "noise")
+    t0 = time.perf_counter()
+    feats = OM.log_mel(x[None], g.n_mels)
+    t_mel = time.perf_counter() - t0
+    orc = WhisperOracle(weights, g)
+    t0 = time.perf_counter()
+    enc = orc.encode(feats)
+    t_enc = time.perf_counter() - t0
+    ospec = OG.GenSpec(eos=v.eos, pad=v.eos, sot=v.sot, no_timestamps=v.notimestamps, lang_to_id=spec.lang_to_id,
+                       task_to_id=spec.task_to_id, alignment_heads=[list(h) for h in spec.alignment_heads],
+                       suppress=v.suppress_tokens(), begin_suppress=v.begin_suppress_tokens(),
+                       max_initial_timestamp_index=50, max_length=g.max_target_positions,
+                       median_filter_width=g.median_filter_width)
+    prompt = np.array([[v.sot, v.lang_id("en"), v.transcribe]], dtype=np.int64)
+    t0 = time.perf_counter()
+    seqs, weights_rows = OG.greedy(orc, ospec, enc, prompt, begin_index=3, max_new_tokens=cpu_tokens, min_new_tokens=cpu_tokens)
+    t_dec = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    # alignment stage on the full-size matrix (N = n_tok_gpu rows) so it is not under-counted
+    reps = int(np.ceil((n_tok_gpu + 2) / weights_rows.shape[2]))
+    wfull = np.tile(weights_rows, (1, 1, reps, 1))[:, :, :n_tok_gpu + 2]
+    OT.extract_token_timestamps(wfull, np.array([3000]), 3, g.median_filter_width)
+    t_ts = time.perf_counter() - t0
+    per_step = t_dec / (cpu_tokens + 2)               # prompt positions are fed too
+    total = t_mel + t_enc + per_step * (n_tok_gpu + 2) + t_ts
+    return {"value": words_per_chunk / total, "unit": "aligned words/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 x 30 s clip on numpy/C oracle (fp32): mel {t_mel:.2f}s + encoder {t_enc:.2f}s + "
+                      f"{cpu_tokens}+2 decoder steps {t_dec:.2f}s + alignment(N={n_tok_gpu}) {t_ts:.2f}s, decoder "
+                      f"extrapolated to {n_tok_gpu} tokens -> {total:.1f}s per chunk (RTF {total / 30:.3f})",
+            "rtf": total / 30.0}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch  # imported before the native library so that one HIP runtime serves both
+    import torch.distributed as td
+    if world > 1:
+        torch.cuda.set_device(local)
+        td.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    from crisperwhisper_amd import collate, dist, generation, synthetic as syn, utils
+    from crisperwhisper_amd.engine import Engine
+
+    g, v = syn.large_v3_geometry() if a.geometry == "large-v3" else syn.tiny_geometry()
+    spec = syn.model_spec(g, v, n_align=15 if a.geometry == "large-v3" else 3)
+    B = a.batch
+    eng = Engine(spec, dtype=a.dtype, max_batch=B, device=local)
+    keep = (not a.no_cpu_baseline) and world == 1 and rank == 0
+    weights = {}
+    t0 = time.perf_counter()
+    for name, shape in syn.weight_shapes(g).items():
+        w = syn.random_tensor(g, name, shape, seed=0)
+        eng.load_tensor(name, w)
+        if keep:
+            weights[name] = w
+    t_load = time.perf_counter() - t0
+    vocab = collate.Vocabulary.from_synthetic(v)
+    utils.bind_engine(eng)
+    shard = dist.Shard(rank, world, device=f"cuda:{local}" if world > 1 else None)
+
+    clips = [syn.synth_audio(rank * B + i, 480000, "noise") for i in range(B)]
+    nf = eng.upload_pcm(clips)                       # inputs resident in HBM before the timed region
+    audio_s = 30.0 * B
+
+    def step():
+        eng.mel_resident(B)
+        out = generation.generate(eng, B, nf, language="<|en|>", task="transcribe", max_new_tokens=a.tokens,
+                                  min_new_tokens=a.tokens)
+        recs = []
+        for k in range(B):
+            n = len(out["token_timestamps"][k])
+            recs.append(dist.pack_record(rank * B + k, out["sequences"][k][:n], out["token_timestamps"][k], (30.0, 0.0, 0.0)))
+        allr = shard.all_gather_records(np.stack(recs), B)
+        n_words = n_tokens = 0
+        if rank == 0:                                 # rank-0 merge: every chunk is an independent clip here
+            for r in allr:
+                _, toks, ts, stride = dist.unpack_record(r)
+                text, words = collate.decode_asr(vocab, [{"tokens": toks, "token_timestamps": ts, "stride": stride}])
+                res = utils.adjust_pauses_for_hf_pipeline_output({"text": text, "chunks": words})
+                n_words += len(res["chunks"])
+                n_tokens += len(toks)
+        return n_words, n_tokens
+
+    def fence():
+        eng.sync()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    eng.stage_times(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    words = tokens = 0
+    for _ in range(a.steps):
+        w, t = step()
+        words += w
+        tokens += t
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+    stages = eng.stage_times()
+
+    # roofline of the decode-step kernels, HIP events on the engine's own stream
+    roof = {}
+    for which, kname in ((0, "gemv_bf16_kernel<EPI_GELU_F32> (decoder fc1 + fused LayerNorm)"),
+                         (1, "attn_decode_kernel<bf16> (cross-attention, 1500 frames)")):
+        ms, by = eng.time_kernel(which, B, a.kernel_iters)
+        roof[which] = {"kernel": kname, "avg_ms": ms, "algo_bytes": by, "achieved": by / (ms * 1e-3) / 1e9}
+
+    if rank == 0:
+        total_audio = audio_s * world * a.steps
+        dec_ms = stages["decode"][0]
+        # per decode step: one cross-attention launch and ~one fc1-sized share of weight GEMVs per layer
+        dom = 1 if roof[1]["avg_ms"] * 1.0 >= roof[0]["avg_ms"] * (1.0) else 0
+        r = roof[dom]
+        line = {
+            "metric": "aligned words/s (RTF alongside), CrisperWhisper large-v3 geometry, 30 s chunks, full mel->encoder->decoder->DTW->words path",
+            "value": words / dt, "unit": "aligned words/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "rtf": dt / total_audio, "tokens_per_s": tokens / dt,
+            "config": {"workload": f"BASELINE configs[1]: batch={B} x 30 s synthetic 16 kHz audio per GPU, {a.dtype}, "
+                                   f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, greedy, word timestamps",
+                       "chunks_per_gpu": B, "tokens_per_chunk": a.tokens, "parallelism": f"chunk-dp{world}",
+                       "weight_load_s": round(t_load, 1)},
+            "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1), 3) for k, val in stages.items()},
+            "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
+                         "frac": r["achieved"] / 8000.0, "traffic": None, "kernel": r["kernel"],
+                         "avg_launch_ms": r["avg_ms"], "algorithmic_bytes_per_launch": r["algo_bytes"]},
+            "roofline_other": [{"kernel": roof[k]["kernel"], "achieved_GBps": roof[k]["achieved"],
+                                "avg_launch_ms": roof[k]["avg_ms"], "algorithmic_bytes_per_launch": roof[k]["algo_bytes"]}
+                               for k in roof if k != dom],
+        }
+        if keep:
+            try:
+                line["cpu_baseline"] = cpu_baseline(g, v, spec, weights, a.tokens, words / max(a.steps * B * world, 1), a.cpu_tokens)
+            except Exception as e:  # the baseline leg must never take the GPU number down with it
+                line["cpu_baseline"] = {"value": None, "unit": "aligned words/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {e!r}"}
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""GPU parity tests, path level: encoder / teacher-forced decoder / full pipeline through the C ABI
+against the golden fixtures (transformers 5.15.0) and the oracle."""
+import numpy as np
+import pytest
+
+import crisperwhisper_amd as cw
+from crisperwhisper_amd import collate, synthetic as syn
+from crisperwhisper_amd.engine import Engine
+from oracle import mel as OM
+from oracle.model import WhisperOracle
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    g, v, W, spec = Hh.tiny_setup()
+    return g, v, W, spec
+
+
+@pytest.fixture(scope="module")
+def eng_f32(tiny):
+    g, v, W, spec = tiny
+    e = Engine(spec, dtype="f32", max_batch=4)
+    e.load_state_dict(W)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_bf16(tiny):
+    g, v, W, spec = tiny
+    e = Engine(spec, dtype="bf16", max_batch=4)
+    e.load_state_dict(W)
+    yield e
+    e.close()
+
+
+def _first_window_feats(g):
+    x = syn.synth_audio(0, 70 * 16000, "mixed")[:480000]
+    return OM.log_mel(x[None], g.n_mels)
+
+
+def test_encoder_f32_vs_golden(tiny, eng_f32):
+    g, v, W, spec = tiny
+    z = Hh.gold_npz("e2e_golden.npz")
+    eng_f32.set_features(_first_window_feats(g))
+    eng_f32.encode([0], [0], [3000])
+    enc = eng_f32.encoder_output(1)
+    err = np.abs(enc[0][::10] - z["tf/enc_sub"]).max()
+    assert err < 1e-3, err            # f32 mode: <= 1e-3 abs on O(1) activations
+
+
+def test_encoder_seek_window_matches_oracle(tiny, eng_f32):
+    """Window slicing inside the conv gather: seek/zero-pad semantics of _get_input_segment."""
+    g, v, W, spec = tiny
+    feats = _first_window_feats(g)
+    eng_f32.set_features(feats)
+    eng_f32.encode([0, 0], [0, 1000], [3000, 700])
+    enc = eng_f32.encoder_output(2)
+    seg = np.zeros((1, g.n_mels, 3000), np.float32); seg[0, :, :700] = feats[0, :, 1000:1700]
+    ref = WhisperOracle(W, g).encode(seg)
+    assert np.abs(enc[1] - ref[0]).max() < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_teacher_forced_decoder(tiny, eng_f32, eng_bf16, mode):
+    g, v, W, spec = tiny
+    eng = eng_f32 if mode == "f32" else eng_bf16
+    z = Hh.gold_npz("e2e_golden.npz")
+    ids = z["tf/ids"]                                   # [1, 3 + 12]
+    T = ids.shape[1]
+    eng.set_features(_first_window_feats(g))
+    eng.encode([0], [0], [3000])
+    cap = eng.capture_logits(1, T)
+    forced = np.full((1, T), -1, np.int32); forced[0, 3:] = ids[0, 3:]
+    seqs, lens, amax = eng.decode(ids[:, :3], max_length=T, forced=forced, want_argmax=True)
+    eng.stop_capture()
+    assert seqs[0, :T].tolist() == ids[0].tolist()
+    ref_logits = z["tf/logits"]                         # row t = logits after feeding ids[:t+1]
+    got = cap[:T - 3, 0]                                # step s = logits used to choose token 3+s
+    want = ref_logits[2:T - 1]
+    if mode == "f32":
+        assert np.abs(got - want).max() < 2e-3
+    else:
+        assert np.abs(got - want).max() < 0.25          # bf16 weights/activations, logits std ~2
+        assert (got.argmax(-1) == want.argmax(-1)).mean() >= 0.9
+    al = eng.alignment(1, T - 1)                        # [1, Ha, T-1, 1500]
+    # probability rows: f32 mode to 1e-5 abs; bf16 mode (bf16 q/K, f32 softmax) to 2e-2 abs on rows
+    # whose peaks are O(0.1-1) -- the DTW input is z-scored so this is ~1e-2 relative
+    tol = 1e-5 if mode == "f32" else 2e-2
+    assert np.abs(al[0] - z["tf/cross"][:, :T - 1]).max() < tol
+    assert np.abs(al[0].sum(-1) - 1).max() < 1e-3       # rows are probability vectors
+
+
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24"])
+def test_pipeline_f32_word_for_word_vs_reference(tiny, name):
+    """The drop-in call of REF/transcribe.py:21-33 + REF/README pause split, f32 engine, against the
+    transformers CPU output: identical text/words, timestamps within +-0.02 s (one encoder frame)."""
+    g, v, W, spec = tiny
+    meta = Hh.gold_json("e2e_golden.json")[name]
+    x = syn.synth_audio(meta["seed"], meta["secs"] * 16000, meta["kind"])
+    pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30,
+                       batch_size=meta["batch_size"], return_timestamps="word", torch_dtype="float32", device="cuda:0")
+    out = pipe(x, generate_kwargs={**Hh.GEN_KW, **meta["extra"]})
+    assert out["text"] == meta["text"]
+    ok, why = Hh.words_equal(out["chunks"], meta["chunks"], tol=0.02)
+    assert ok, why
+    pipe.engine.close()
+
+
+def test_pipeline_bf16_runs_and_is_well_formed(tiny):
+    g, v, W, spec = tiny
+    x = syn.synth_audio(9, 50 * 16000, "mixed")
+    pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30, batch_size=2,
+                       return_timestamps="word", device="cuda:0")
+    out = pipe(x, generate_kwargs={**Hh.GEN_KW, "max_new_tokens": 32, "min_new_tokens": 32})
+    assert isinstance(out["text"], str) and len(out["chunks"]) > 0
+    assert "".join(c["text"] for c in out["chunks"]) == out["text"]
+    adj = cw.adjust_pauses_for_hf_pipeline_output(out)
+    for a, b in zip(adj["chunks"][:-1], adj["chunks"][1:]):
+        assert np.isfinite(a["timestamp"]).all() and np.isfinite(b["timestamp"]).all()
+    pipe.engine.close()

@@ -1,0 +1,147 @@
+"""GPU parity tests, kernel level: every HIP kernel family against the oracle (numpy) on seeded
+inputs, through the C ABI.  Integer outputs (DTW paths) must match exactly; floating point within the
+tolerance written next to each check."""
+import numpy as np
+import pytest
+
+from crisperwhisper_amd import synthetic as syn
+from crisperwhisper_amd.engine import Engine
+from oracle import mel as OM
+from oracle import model as OMOD
+from oracle import pauses as OP
+from oracle import timestamps as OT
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines():
+    g, v, W, spec = Hh.tiny_setup()
+    out = {}
+    for dt in ("f32", "bf16"):
+        out[dt] = Engine(spec, dtype=dt, max_batch=4)
+    yield out
+    for e in out.values():
+        e.close()
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1000, 384, 256), (77, 51, 64)])
+def test_gemm(engines, dt, tol, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    if dt == "bf16":   # compare against the same bf16-rounded operands
+        import struct
+        A = (A.view(np.uint32) & 0xFFFF0000).view(np.float32); W = (W.view(np.uint32) & 0xFFFF0000).view(np.float32)
+    for gelu in (False, True):
+        ref = A.astype(np.float64) @ W.astype(np.float64).T + b
+        if gelu:
+            ref = OMOD.gelu(ref.astype(np.float32)).astype(np.float64)
+        got = engines[dt].test_gemm(A, W, b, gelu)
+        assert rel_err(got, ref) < tol, (dt, M, N, K, gelu, rel_err(got, ref))
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("Mb,N,K", [(1, 128, 128), (3, 200, 256), (8, 1769, 128), (16, 64, 1280), (20, 128, 512)])
+def test_gemv_with_layernorm(engines, dt, tol, Mb, N, K):
+    rng = np.random.default_rng(Mb * 7 + N + K)
+    x = (rng.standard_normal((Mb, K)) * 2 + 0.5).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32); bet = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    if dt == "bf16":
+        W = (W.view(np.uint32) & 0xFFFF0000).view(np.float32)
+    for ln in (None, (gam, bet)):
+        for gelu in (False, True):
+            xin = x if ln is None else OMOD.layer_norm(x, gam, bet)
+            ref = xin.astype(np.float64) @ W.astype(np.float64).T + b
+            if gelu:
+                ref = OMOD.gelu(ref.astype(np.float32)).astype(np.float64)
+            got = engines[dt].test_gemv(x, W, b, ln, gelu)
+            assert rel_err(got, ref) < tol, (dt, Mb, N, K, ln is not None, gelu, rel_err(got, ref))
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 200), (1, 2, 1500)])
+def test_encoder_attention(engines, dt, tol, B, H, S):
+    rng = np.random.default_rng(B + H + S)
+    q = (rng.standard_normal((B, H, S, 64)) * 0.3).astype(np.float32)
+    k = rng.standard_normal((B, H, S, 64)).astype(np.float32)
+    v = rng.standard_normal((B, H, S, 64)).astype(np.float32)
+    k[0, 0, S // 2] *= 6.0     # one dominant key: forces a running-max jump mid-stream
+    if dt == "bf16":
+        q, k, v = ((t.view(np.uint32) & 0xFFFF0000).view(np.float32) for t in (q, k, v))
+    s = np.einsum("bhqd,bhkd->bhqk", q.astype(np.float64), k.astype(np.float64))
+    p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bhqk,bhkd->bhqd", p, v.astype(np.float64)).transpose(0, 2, 1, 3).reshape(B, S, H * 64)
+    got = engines[dt].test_attention(q, k, v)
+    assert rel_err(got, ref) < tol, (dt, B, H, S, rel_err(got, ref))
+
+
+@pytest.mark.parametrize("kind,n", [("noise", 480000), ("mixed", 320000), ("chirp", 480000), ("noise_short", 12345)])
+def test_mel_vs_golden_and_oracle(engines, kind, n):
+    g = Hh.gold_npz("mel_golden.npz")
+    x = syn.synth_audio(1, n, kind.split("_")[0])
+    feats, nf = engines["f32"].mel([x], return_features=True)
+    assert int(nf[0]) == int(g[f"{kind}_nframes"])
+    assert np.abs(feats[0][:, ::5] - g[f"{kind}_feats_sub"]).max() < 1e-4          # vs transformers (golden)
+    xp, _ = OM.pad_or_trim(x)
+    assert np.abs(feats[0] - OM.log_mel(xp[None], 128)[0]).max() < 1e-4               # vs oracle, full tensor
+
+
+def test_mel_batch_and_linearity_property(engines):
+    """Batch of ragged clips == each clip alone; scaling the waveform by 10 shifts log-mel by 2*log10(10)/4
+    away from the floor (size-independent property)."""
+    e = engines["f32"]
+    clips = [syn.synth_audio(s, n, "noise") for s, n in ((3, 480000), (4, 100000), (5, 1))]
+    fb, nfb = e.mel(clips, return_features=True)
+    for i, c in enumerate(clips):
+        f1, nf1 = e.mel([c], return_features=True)
+        assert np.array_equal(f1[0], fb[i]) and nf1[0] == nfb[i]
+    f10, _ = e.mel([clips[0] * 10.0], return_features=True)
+    d = (f10[0] - fb[0])
+    assert np.abs(d - 0.5).max() < 2e-4
+
+
+def test_align_matrix_vs_golden(engines):
+    g = Hh.gold_npz("align_golden.npz")
+    for ci in range(4):
+        a, w = g[f"am{ci}_a"], int(g[f"am{ci}_w"])
+        got = engines["f32"].align_matrix(a[None], [a.shape[-1]], w)[0]
+        assert np.allclose(got, g[f"am{ci}_mat"], rtol=1e-5, atol=2e-5), ci
+
+
+def test_dtw_exact_vs_golden_and_oracle(engines):
+    g = Hh.gold_npz("align_golden.npz")
+    e = engines["f32"]
+    for ci in range(6):
+        ti, tj = e.dtw(g[f"dtw{ci}_m"])
+        assert np.array_equal(ti, g[f"dtw{ci}_ti"]) and np.array_equal(tj, g[f"dtw{ci}_tj"]), ci
+    ti, tj = e.dtw(np.zeros((3, 4), np.float32))
+    assert ti.tolist() == [0, 1, 2, 2, 2, 2] and tj.tolist() == [0, 0, 0, 1, 2, 3]
+    rng = np.random.default_rng(5)
+    for N, M in ((128, 1500), (445, 1500), (1, 1), (64, 3), (445, 2)):
+        m = rng.standard_normal((N, M)).astype(np.float32)
+        if N == 64:
+            m = np.round(m)                      # heavy ties
+        ti, tj = e.dtw(m)
+        oi, oj = OT.dtw(-m.astype(np.float64))
+        assert np.array_equal(ti, oi) and np.array_equal(tj, oj), (N, M)
+        assert ti[0] == 0 and tj[0] == 0 and ti[-1] == N - 1 and tj[-1] == M - 1          # path properties
+        assert (np.diff(ti) >= 0).all() and (np.diff(tj) >= 0).all() and ((np.diff(ti) + np.diff(tj)) >= 1).all()
+
+
+def test_pauses_vs_reference_golden(engines):
+    from crisperwhisper_amd import utils
+    for case in Hh.gold_json("pauses_golden.json"):
+        inp = {"text": "x", "chunks": [{"text": c["text"], "timestamp": tuple(c["timestamp"])} for c in case["in"]]}
+        out = utils.adjust_pauses_for_hf_pipeline_output(inp, split_threshold=case["thr"], engine=engines["f32"])
+        assert out is inp
+        assert [list(c["timestamp"]) for c in out["chunks"]] == [c["timestamp"] for c in case["out"]]
