@@ -253,47 +253,70 @@ template <> struct Row8<bf16_t> {
 
 template <typename T>
 __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams p) {
-    extern __shared__ float dsm[];          // scores [n_keys] | red [DEC_GROUPS][64] | scratch [64]
+    extern __shared__ float dsm[];          // scores [cap rounded] | red [DEC_GROUPS][64] | scratch [64]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int n_keys = p.pos ? (p.n_keys > 0 ? p.n_keys : p.pos[b] + 1) : p.n_keys;
     float* sc = dsm;
-    float* red = dsm + ((p.n_keys + 63) & ~63);
+    float* red = dsm + ((p.cap + 63) & ~63);
     float* scratch = red + DEC_GROUPS * 64;
     const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
-    const int h = blockIdx.x, b = blockIdx.y;
     const T* Kh = (const T*)p.K + ((size_t)b * p.H + h) * p.cap * 64;
     const T* Vh = (const T*)p.V + ((size_t)b * p.H + h) * p.cap * 64;
     float qv[8];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
 
+    // scores: 4 key rows per thread in flight (unrolled by 4 x DEC_GROUPS keys)
     float mx = -INFINITY;
-    for (int k = grp; k < p.n_keys; k += DEC_GROUPS) {
-        float kv[8];
-        Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv);
-        float d = 0.f;
+    for (int k0 = grp; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
+        float kv[4][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[e], d);
-        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-        if (sub == 0) sc[k] = d;
-        mx = fmaxf(mx, d);
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * DEC_GROUPS;
+            if (k < n_keys) Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * DEC_GROUPS;
+            if (k < n_keys) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[u][e], d);
+                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+                if (sub == 0) sc[k] = d;
+                mx = fmaxf(mx, d);
+            }
+        }
     }
     mx = block_max(mx, scratch);
     float sum = 0.f;
-    for (int k = tid; k < p.n_keys; k += DEC_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
+    for (int k = tid; k < n_keys; k += DEC_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
     sum = block_sum(sum, scratch);      // includes the barriers that publish sc[]
     const float inv = 1.0f / sum;
 
     const int slot = p.align_out ? p.align_slot[h] : -1;
     if (slot >= 0) {
-        float* dst = p.align_out + (((size_t)b * p.n_align + slot) * p.align_rows + p.align_row) * p.n_keys;
-        for (int k = tid; k < p.n_keys; k += DEC_THREADS) dst[k] = sc[k] * inv;
+        const int arow = p.pos[b];
+        float* dst = p.align_out + (((size_t)b * p.n_align + slot) * p.align_rows + arow) * n_keys;
+        for (int k = tid; k < n_keys; k += DEC_THREADS) dst[k] = sc[k] * inv;
     }
 
     float acc[8] = {};
-    for (int k = grp; k < p.n_keys; k += DEC_GROUPS) {
-        float vv[8];
-        Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv);
-        const float pk = sc[k] * inv;
+    for (int k0 = grp; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
+        float vv[4][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * DEC_GROUPS;
+            if (k < n_keys) Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * DEC_GROUPS;
+            if (k < n_keys) {
+                const float pk = sc[k] * inv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[u][e], acc[e]);
+            }
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[grp * 64 + sub * 8 + e] = acc[e];
@@ -306,7 +329,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
 }
 
 int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
-    size_t lds = ((size_t)((p.n_keys + 63) & ~63) + DEC_GROUPS * 64 + 64) * sizeof(float);
+    size_t lds = ((size_t)((p.cap + 63) & ~63) + DEC_GROUPS * 64 + 64) * sizeof(float);
     if (bf16)
         hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
     else

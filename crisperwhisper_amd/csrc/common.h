@@ -101,7 +101,7 @@ struct EpiParams {
     int S_pad;            // padded per-head sequence capacity (EPI_HEADS / cache capacity)
     int H;                // heads
     int d_model;          // columns per `which`
-    int pos_row;          // EPI_QKV_CACHE: cache position to write
+    const int* row_pos;   // EPI_QKV_CACHE: [batch] device array, cache row to write for each batch row
 };
 
 template <typename T, int MODE>
@@ -133,7 +133,7 @@ __device__ inline void epi_store1(const EpiParams& p, int m, int n, float acc) {
         } else {
             int h = r >> 6, dd = r & 63;
             T* base = (T*)(which == 1 ? p.out1 : p.out2);
-            Act<T>::st(base + (((size_t)m * p.H + h) * p.S_pad + p.pos_row) * 64 + dd, v);
+            Act<T>::st(base + (((size_t)m * p.H + h) * p.S_pad + p.row_pos[m]) * 64 + dd, v);
         }
     }
 }

@@ -63,6 +63,14 @@ __global__ void embed_kernel(const int* __restrict__ ids, int ids_stride, int t,
         x_out[(size_t)b * d + k] = Act<T>::ld(embed + (size_t)tok * d + k) + pos_embed[(size_t)t * d + k];
 }
 
+__global__ void set_pos_kernel(int* pos, int value, int B) {
+    if ((int)threadIdx.x < B) pos[threadIdx.x] = value;
+}
+int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st) {
+    hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(64), 0, st, pos, value, B);
+    return CW_OK;
+}
+
 int cw_launch_embed(const int* ids, int ids_stride, int t, const void* embed, int embed_bf16, const float* pos_embed,
                     float* x_out, int B, int d, hipStream_t st) {
     if (embed_bf16)
@@ -105,11 +113,12 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const float* lg = p.logits + (size_t)b * p.V;
     int* ids = p.ids + (size_t)b * p.ids_stride;
-    const int t = p.t, tb = p.timestamp_begin;
-    const int n_gen = t - p.n_prompt;
+    const int n_prompt = p.cfg[0], min_new_tokens = p.cfg[1], max_length = p.cfg[2], use_forced = p.cfg[3];
+    const int t = p.pos[b] + 1, tb = p.timestamp_begin;
+    const int n_gen = t - n_prompt;
 
     const bool was_finished = p.finished[b] != 0;
-    int forced = p.forced ? p.forced[(size_t)b * p.ids_stride + t] : -1;
+    int forced = (p.forced && use_forced) ? p.forced[(size_t)b * p.ids_stride + t] : -1;
 
     // timestamp grammar state from the generated suffix
     const bool last_ts = n_gen >= 1 && ids[t - 1] >= tb;
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
     auto score = [&](int v) -> float {
         unsigned char mk = p.mask[v];
         bool dead = (mk & 1) || (at_begin && (mk & 2));
-        dead |= (v == p.eos && n_gen < p.min_new_tokens);
+        dead |= (v == p.eos && n_gen < min_new_tokens);
         if (last_ts) dead |= penult_ts ? (v >= tb) : (v < p.eos);
         dead |= (v >= tb && v < ts_floor);
         if (at_begin) dead |= (v < tb) || (v > ts_cap);
@@ -165,15 +174,16 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
         if (was_finished) tok = p.pad;                                  // utils.py:2928-2929
         ids[t] = tok;
         if (tok >= tb && n_gen >= 0) p.last_ts_tok[b] = tok;
-        int fin = was_finished || (n_gen >= 0 && tok == p.eos) || (t + 1 >= p.max_length);
+        int fin = was_finished || (n_gen >= 0 && tok == p.eos) || (t + 1 >= max_length);
         p.finished[b] = fin;
         if (!fin) atomicAdd(p.n_unfinished, 1);
         s_tok = tok;
+        p.pos[b] = t;                                                   // next decoder input position
     }
     __syncthreads();
     // embedding for the next decoder step: token at sequence index t is fed at position t
     const int tok = s_tok;
-    if (p.x_out && t < p.max_length) {
+    if (p.x_out && t < max_length) {
         const T* e = (const T*)p.embed + (size_t)tok * p.d;
         const float* pe = p.pos_embed + (size_t)t * p.d;
         for (int k = tid; k < p.d; k += blockDim.x) p.x_out[(size_t)b * p.d + k] = Act<T>::ld(e + k) + pe[k];

@@ -66,6 +66,9 @@ struct cw_ctx {
     unsigned char* d_mask = nullptr;
     float* d_align = nullptr;
     int* h_nunf = nullptr;  // pinned
+    int *d_pos = nullptr, *d_cfg = nullptr;   // per-row decoder input position; [n_prompt, min_new, max_length, use_forced]
+    hipGraphExec_t step_graph[65] = {};       // captured decode step (layers + logits + sampling) per batch size
+    bool use_graph = true;
     cw_gen_cfg gen{};
     bool gen_set = false;
     float* logits_capture = nullptr;
@@ -191,6 +194,7 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipEventCreate(&c->ev1));
     HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 64, hipHostMallocDefault));
     c->bf16 = d.dtype == CW_DTYPE_BF16;
+    if (getenv("CW_NO_GRAPH")) c->use_graph = false;
     c->esz = c->bf16 ? 2 : 4;
     c->Bm = Bm;
     c->S_pad = 1536;
@@ -306,6 +310,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_argmax, (size_t)Bm * TGT * 4));
     CWCHK(c, dmalloc(c, &c->d_last_ts, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_finished, Bm * 4));
     CWCHK(c, dmalloc(c, &c->d_nunf, 4));
+    CWCHK(c, dmalloc(c, &c->d_pos, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_cfg, 4 * 4));
     CWCHK(c, dmalloc(c, &c->d_mask, (size_t)V));
     CWCHK(c, dmalloc(c, &c->d_align_slot, (size_t)d.dec_layers * H * 4));
     {
@@ -356,6 +361,7 @@ void cw_destroy(cw_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
+    for (auto& ge : c->step_graph) if (ge) hipGraphExecDestroy(ge);
     for (void* p : c->allocs) hipFree(p);
     if (c->h_nunf) hipHostFree(c->h_nunf);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -603,18 +609,19 @@ static int gemv_ln(cw_ctx* c, int epi, const float* x, int Mb, int K, const void
     return cw_launch_gemv(false, epi, c->dxn, Mb, K, W, N, nullptr, nullptr, ep, c->st);
 }
 
-static int decode_step(cw_ctx* c, int nb, int pos, bool want_logits) {
+// One decoder forward for the nb rows at the positions held in c->d_pos (device): 8 launches per layer.
+static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, V = c->d.vocab_size;
     const int TGT = c->d.max_target_positions;
     for (int l = 0; l < c->d.dec_layers; ++l) {
         LayerW& L = c->dec[l];
-        {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at `pos`
+        {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
             EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
-            ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.pos_row = pos;
+            ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
             CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, L.ln1_b, ep));
         }
         {
-            DecAttnParams p{c->dq, L.sk, L.sv, TGT, pos + 1, c->dattn, nullptr, nullptr, 0, 0, 0, nb, H};
+            DecAttnParams p{c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nullptr, nullptr, 0, 0, nb, H};
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
         }
         {
@@ -626,9 +633,9 @@ static int decode_step(cw_ctx* c, int nb, int pos, bool want_logits) {
             CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, L.lnc_b, ep));
         }
         {
-            DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->dattn,
+            DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn,
                             c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_slot + (size_t)l * H,
-                            c->d.n_align, TGT, pos, nb, H};
+                            c->d.n_align, TGT, nb, H};
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
         }
         {
@@ -648,6 +655,46 @@ static int decode_step(cw_ctx* c, int nb, int pos, bool want_logits) {
         EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = V;
         CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep));
     }
+    return CW_OK;
+}
+
+static int launch_sample(cw_ctx* c, int nb, bool forced) {
+    SampleParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.logits = c->dlogits; sp.V = c->d.vocab_size; sp.B = nb; sp.mask = c->d_mask;
+    sp.eos = c->gen.eos_token_id; sp.pad = c->gen.pad_token_id;
+    sp.timestamp_begin = c->gen.no_timestamps_token_id + 1;
+    sp.max_initial_timestamp_index = c->gen.max_initial_timestamp_index;
+    sp.cfg = c->d_cfg; sp.pos = c->d_pos;
+    sp.ids_stride = c->d.max_target_positions; sp.ids = c->d_ids; sp.forced = c->d_forced;
+    sp.argmax_trace = c->d_argmax; sp.last_ts_tok = c->d_last_ts; sp.finished = c->d_finished;
+    sp.n_unfinished = c->d_nunf;
+    sp.embed = c->embed; sp.pos_embed = c->dec_pos; sp.x_out = c->dx; sp.d = c->d.d_model; sp.embed_bf16 = c->bf16 ? 1 : 0;
+    (void)forced;
+    return cw_launch_sample(sp, c->st);
+}
+
+// decoder forward + logits + sampling for one position, captured once per batch size as a hipGraph
+// (~260 launches -> one replay; every per-step value lives in device memory: d_pos, d_cfg).
+static int run_step(cw_ctx* c, int nb) {
+    const bool graph_ok = c->use_graph && !c->logits_capture;
+    if (!graph_ok) {
+        CWCHK(c, decode_step(c, nb, true));
+        return launch_sample(c, nb, false);
+    }
+    if (!c->step_graph[nb]) {
+        hipGraph_t g = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+        int r = decode_step(c, nb, true);
+        if (r == CW_OK) r = launch_sample(c, nb, false);
+        hipError_t e = hipStreamEndCapture(c->st, &g);
+        if (r != CW_OK) { if (g) hipGraphDestroy(g); return r; }
+        if (e != hipSuccess) return fail(c, CW_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&c->step_graph[nb], g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) return fail(c, CW_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    HIPCHK(c, hipGraphLaunch(c->step_graph[nb], c->st));
     return CW_OK;
 }
 
@@ -671,35 +718,30 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
     HIPCHK(c, hipMemsetAsync(c->d_finished, 0, nb * 4, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_last_ts, 0xff, nb * 4, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_argmax, 0xff, (size_t)nb * TGT * 4, c->st));
+    const int cfg[4] = {n_prompt, min_new_tokens, max_length, forced ? 1 : 0};
+    HIPCHK(c, hipMemcpyAsync(c->d_cfg, cfg, sizeof(cfg), hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     StageTimer tm(c, CW_STAGE_DECODE);
 
-    for (int pos = 0; pos < n_prompt; ++pos) {
+    // prompt positions 0 .. n_prompt-2: forward only (their alignment rows are recorded, :254-256)
+    for (int pos = 0; pos + 1 < n_prompt; ++pos) {
+        CWCHK(c, cw_launch_set_pos(c->d_pos, pos, nb, c->st));
         CWCHK(c, cw_launch_embed(c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
-        CWCHK(c, decode_step(c, nb, pos, pos == n_prompt - 1));
+        CWCHK(c, decode_step(c, nb, false));
     }
+    CWCHK(c, cw_launch_set_pos(c->d_pos, n_prompt - 1, nb, c->st));
+    CWCHK(c, cw_launch_embed(c->d_ids, TGT, n_prompt - 1, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
     int t = n_prompt, step = 0;
     for (;;) {
+        // forward at position t-1, logits, fused processors + argmax -> ids[t], x for position t, pos := t
+        CWCHK(c, run_step(c, nb));
         if (c->logits_capture && step < c->logits_capture_steps)
             HIPCHK(c, hipMemcpyAsync(c->logits_capture + (size_t)step * nb * V, c->dlogits, (size_t)nb * V * 4, hipMemcpyDeviceToHost, c->st));
-        SampleParams sp;
-        memset(&sp, 0, sizeof(sp));
-        sp.logits = c->dlogits; sp.V = V; sp.B = nb; sp.mask = c->d_mask;
-        sp.eos = c->gen.eos_token_id; sp.pad = c->gen.pad_token_id;
-        sp.timestamp_begin = c->gen.no_timestamps_token_id + 1;
-        sp.max_initial_timestamp_index = c->gen.max_initial_timestamp_index;
-        sp.n_prompt = n_prompt; sp.t = t; sp.min_new_tokens = min_new_tokens; sp.max_length = max_length;
-        sp.ids_stride = TGT; sp.ids = c->d_ids; sp.forced = forced ? c->d_forced : nullptr;
-        sp.argmax_trace = c->d_argmax; sp.last_ts_tok = c->d_last_ts; sp.finished = c->d_finished;
-        sp.n_unfinished = c->d_nunf;
-        sp.embed = c->embed; sp.pos_embed = c->dec_pos; sp.x_out = c->dx; sp.d = D; sp.embed_bf16 = c->bf16 ? 1 : 0;
-        CWCHK(c, cw_launch_sample(sp, c->st));
         HIPCHK(c, hipMemcpyAsync(c->h_nunf, c->d_nunf, 4, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
         ++step;
         ++t;                               // sequence length is now t
         if (*c->h_nunf == 0 || t >= max_length) break;
-        CWCHK(c, decode_step(c, nb, t - 1, true));
     }
     KCHK(c);
     tm.stop();
@@ -943,7 +985,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
             EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
             return gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep);
         }
-        DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->dattn, nullptr, nullptr, 0, 0, 0, nb, H};
+        DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, nullptr, c->dattn, nullptr, nullptr, 0, 0, nb, H};
         return cw_launch_attn_decode(c->bf16, p, c->st);
     };
     for (int i = 0; i < 3; ++i) CWCHK(c, launch());

@@ -300,6 +300,150 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Decode GEMV v2 (Mb <= 16, K slice per block <= 1280).  Latency-oriented rewrite of the kernel above:
+//   phase 0  every wave issues ALL of its weight loads (<= 3 steps x 64 B per lane, non-temporal) first;
+//   phase 1  while they fly, each wave pulls its 2-4 activation rows straight into registers (all loads in
+//            flight at once), does the LayerNorm statistics wave-locally (a row lives in one wave: no block
+//            barrier), normalises, rounds to bf16 and parks the rows in LDS;
+//   phase 2  one barrier, then MFMA 16x16x32 over the wave's K steps;
+//   phase 3  cross-wave reduction through LDS, epilogue spread over all 256 threads.
+// grid = (ceil(N/16), KSPLIT).  KSPLIT > 1 is only used with the in-place residual epilogue, where the
+// partial sums are accumulated with f32 atomics straight into the residual stream.
+// ---------------------------------------------------------------------------------------------------
+template <int EPI, int RPW, bool ATOMIC>
+__global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict__ x, int Mb, int K, int Kb,
+                                                         const bf16_t* __restrict__ W, int N,
+                                                         const float* __restrict__ ln_g,
+                                                         const float* __restrict__ ln_b, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    const int xs_stride = Kb + 8;
+    bf16_t* xs = (bf16_t*)smem2;                              // [16][Kb+8]
+    float* red = (float*)(smem2 + (size_t)16 * xs_stride * 2); // [4 waves][4][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kbase = blockIdx.y * Kb;
+    const int steps = Kb >> 7;
+    const int n = n0 + l15;
+
+    // phase 0: weights for steps wave, wave+4, wave+8
+    u32x4_t wq[3][4];
+    {
+        const bf16_t* wrow = W + (size_t)(n < N ? n : 0) * K + kbase + g * 8;   // MFMA j covers k = j*32 + g*8 .. +7
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int step = wave + 4 * s;
+            if (step < steps && n < N) {
+                const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wq[s][j] = __builtin_nontemporal_load(wp + j * 4);   // +32 bf16
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wq[s][j] = (u32x4_t){0u, 0u, 0u, 0u};
+            }
+        }
+    }
+
+    // phase 1: activation rows wave, wave+4, ... -> registers -> (LayerNorm) -> bf16 -> LDS
+    const int per_lane = 5;                                   // ceil(1280 / 4 / 64)
+    const int nvec = Kb >> 2;                                 // float4 per row slice
+    float4 xv[RPW][per_lane];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int row = wave + 4 * i;
+#pragma unroll
+        for (int c = 0; c < per_lane; ++c) {
+            const int v4 = lane + 64 * c;
+            xv[i][c] = (row < Mb && v4 < nvec) ? *(const float4*)(x + (size_t)row * K + kbase + v4 * 4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (ln_g) {   // only launched with Kb == K
+        float4 gv[per_lane], bv[per_lane];
+#pragma unroll
+        for (int c = 0; c < per_lane; ++c) {
+            const int v4 = lane + 64 * c;
+            gv[c] = v4 < nvec ? *(const float4*)(ln_g + v4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[c] = v4 < nvec ? *(const float4*)(ln_b + v4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < per_lane; ++c) s += (xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w);
+            const float mean = wave_sum(s) / (float)K;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < per_lane; ++c) {
+                if (lane + 64 * c < nvec) {
+                    float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
+                    q += (a * a + b * b) + (cc * cc + d * d);
+                }
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+#pragma unroll
+            for (int c = 0; c < per_lane; ++c) {
+                xv[i][c].x = (xv[i][c].x - mean) * rstd * gv[c].x + bv[c].x;
+                xv[i][c].y = (xv[i][c].y - mean) * rstd * gv[c].y + bv[c].y;
+                xv[i][c].z = (xv[i][c].z - mean) * rstd * gv[c].z + bv[c].z;
+                xv[i][c].w = (xv[i][c].w - mean) * rstd * gv[c].w + bv[c].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                              // rows wave + 4*i cover 0..15
+        const int row = wave + 4 * i;
+#pragma unroll
+        for (int c = 0; c < per_lane; ++c) {
+            const int v4 = lane + 64 * c;
+            if (v4 < nvec) {
+                ushort4 o = make_ushort4(0, 0, 0, 0);
+                if (i < RPW && row < Mb) {
+                    const float4 v = xv[i < RPW ? i : 0][c];
+                    o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+                }
+                *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 2
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int step = wave + 4 * s;
+        if (step < steps) {
+            const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
+                acc = mfma16(a, __builtin_bit_cast(bf16x8_t, wq[s][j]), acc);
+            }
+        }
+    }
+    // phase 3: D[row = batch g*4 + r][col = l15]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    {
+        const int r = tid >> 6;
+        float v = red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane] + red[(2 * 4 + r) * 64 + lane] +
+                  red[(3 * 4 + r) * 64 + lane];
+        const int m = g * 4 + r;
+        if (m < Mb && n < N) {
+            if (ATOMIC) {
+                const float bias = (blockIdx.y == 0 && ep.bias) ? ep.bias[n] : 0.f;
+                atomicAdd(ep.outf + (size_t)m * ep.ldo + n, v + bias);
+            } else {
+                epi_store1<bf16_t, EPI>(ep, m, n, v);
+            }
+        }
+    }
+}
+
 // f32 parity GEMV: one wave per output column, x read from global (L2 resident); LN is applied by a
 // separate kernel in f32 mode (ln_g must be null here).
 template <int EPI>
@@ -365,10 +509,47 @@ int cw_gemv_kc(int Mb, int K) {
     return 128;
 }
 
+template <int EPI, int RPW>
+static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b,
+                         const EpiParams& ep, hipStream_t st) {
+    // K split: only for the in-place residual epilogue (f32 atomics into the residual stream), sized so that
+    // (N/16) * KSPLIT lands near the CU count and every block streams <= 1280 weights per column.
+    int ksplit = 1;
+    if (EPI == EPI_RESID_F32 && !ln_g && ep.outf == ep.resid) {
+        const int tiles = (N + 15) / 16, steps = K / 128;
+        while (tiles * ksplit < 256 && steps % (ksplit * 2) == 0 && steps / (ksplit * 2) >= 4) ksplit *= 2;
+    }
+    while (K / ksplit > 1280) ksplit *= 2;
+    const int Kb = K / ksplit;
+    const size_t lds = (size_t)16 * (Kb + 8) * 2 + 4 * 4 * 64 * 4;
+    dim3 grid((N + 15) / 16, ksplit);
+    if (ksplit > 1)
+        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, true>), grid, dim3(256), lds, st, x, Mb, K, Kb, (const bf16_t*)W,
+                           N, ln_g, ln_b, ep);
+    else
+        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false>), grid, dim3(256), lds, st, x, Mb, K, Kb,
+                           (const bf16_t*)W, N, ln_g, ln_b, ep);
+}
+
+static bool gemv2_ok(int epi, int Mb, int K, const float* ln_g, const EpiParams& ep) {
+    if (Mb > 16 || K % 128 != 0) return false;
+    if (K <= 1280) return true;
+    // larger K needs the K split, i.e. the in-place residual epilogue without LayerNorm
+    if (epi != EPI_RESID_F32 || ln_g || ep.outf != ep.resid) return false;
+    int ks = 1;
+    while (K / ks > 1280) ks *= 2;
+    return (K % ks == 0) && ((K / ks) % 128 == 0);
+}
+
 template <int EPI>
 static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
                            const float* ln_b, const EpiParams& ep, hipStream_t st) {
     if (bf16) {
+        if (gemv2_ok(EPI, Mb, K, ln_g, ep)) {
+            if (Mb <= 8) launch_gemv2<EPI, 2>(x, Mb, K, W, N, ln_g, ln_b, ep, st);
+            else launch_gemv2<EPI, 4>(x, Mb, K, W, N, ln_g, ln_b, ep, st);
+            return CW_OK;
+        }
         int kc = cw_gemv_kc(Mb, K);
         if (kc % 128 != 0 || K % kc != 0) return CW_ERR_INVALID;
         int Mpad = (Mb + 15) & ~15;

@@ -28,10 +28,8 @@ struct SampleParams {
     int V, B;
     const unsigned char* mask; // [V] bit0 always suppressed, bit1 suppressed at begin
     int eos, pad, timestamp_begin, max_initial_timestamp_index;  // max_initial < 0: none
-    int n_prompt;              // begin index
-    int t;                     // index of the token being chosen (sequence length so far)
-    int min_new_tokens;
-    int max_length;
+    const int* cfg;            // device [4]: n_prompt (begin index), min_new_tokens, max_length, use_forced
+    int* pos;                  // device [B]: position of the last decoder input; token pos+1 is being chosen
     int ids_stride;            // tokens per row in `ids`
     int* ids;                  // [B][ids_stride]  (in/out)
     const int* forced;         // [B][ids_stride] or null; value >= 0 forces that token at index t
@@ -47,6 +45,7 @@ struct SampleParams {
     int embed_bf16;
 };
 int cw_launch_sample(const SampleParams& p, hipStream_t st);
+int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st);
 int cw_launch_embed(const int* ids, int ids_stride, int t, const void* embed, int embed_bf16, const float* pos_embed,
                     float* x_out, int B, int d, hipStream_t st);
 
@@ -58,11 +57,12 @@ struct DecAttnParams {
     const void* K;         // [B][H][cap][64] T
     const void* V;         // [B][H][cap][64] T
     int cap;               // rows allocated per (b,h)
-    int n_keys;            // keys to attend over
+    int n_keys;            // keys to attend over when `pos` is null
+    const int* pos;        // device [B]: decoder input position; self-attention uses n_keys = pos[b] + 1
     float* out;            // [B][H*64] f32
     float* align_out;      // [B][n_align][align_rows][S] or null
     const int* align_slot; // [H] slot index of each head in this layer (or -1), device
-    int n_align, align_rows, align_row; // row (= decoder position) to write
+    int n_align, align_rows;            // alignment row written = pos[b]
     int B, H;
 };
 int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st);
