@@ -336,3 +336,121 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
         hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
     return CW_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Cross-attention decode, split over keys.  grid (H, B, ATT_NS), 512 threads.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSplitParams p) {
+    __shared__ float sc[512];
+    __shared__ float red[DEC_GROUPS * 64];
+    __shared__ float scratch[64];
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
+    const int k_lo = sp * per, k_hi = min(p.n_keys, k_lo + per), nk = k_hi - k_lo;
+    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
+    const T* Kh = (const T*)p.K + (((size_t)b * p.H + h) * p.n_keys + k_lo) * 64;
+    const T* Vh = (const T*)p.V + (((size_t)b * p.H + h) * p.n_keys + k_lo) * 64;
+    float qv[8];
+    Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
+
+    float mx = -INFINITY;
+    for (int k0 = grp; k0 < nk; k0 += 4 * DEC_GROUPS) {
+        float kv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * DEC_GROUPS;
+            if (k < nk) Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * DEC_GROUPS;
+            if (k < nk) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[u][e], d);
+                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+                if (sub == 0) sc[k] = d;
+                mx = fmaxf(mx, d);
+            }
+        }
+    }
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int k = tid; k < nk; k += DEC_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
+    sum = block_sum(sum, scratch);
+
+    const int slot = p.align_out ? p.align_slot[h] : -1;
+    if (slot >= 0) {
+        const int arow = p.pos[b];
+        const size_t rowi = ((size_t)b * p.n_align + slot) * p.align_rows + arow;
+        float* dst = p.align_out + rowi * p.n_keys + k_lo;
+        for (int k = tid; k < nk; k += DEC_THREADS) dst[k] = sc[k];
+        if (tid == 0) { p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = sum; }
+    }
+    if (tid == 0) {
+        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp) * 2;
+        ml[0] = mx; ml[1] = sum;
+    }
+
+    float acc[8] = {};
+    for (int k0 = grp; k0 < nk; k0 += 4 * DEC_GROUPS) {
+        float vv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * DEC_GROUPS;
+            if (k < nk) Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * DEC_GROUPS;
+            if (k < nk) {
+                const float pk = sc[k];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[u][e], acc[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[grp * 64 + sub * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        float r = 0.f;
+        for (int gI = 0; gI < DEC_GROUPS; ++gI) r += red[gI * 64 + tid];
+        p.part_o[((size_t)sp * p.B + b) * p.H * 64 + h * 64 + tid] = r;
+    }
+}
+
+int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
+    if ((p.n_keys + ATT_NS - 1) / ATT_NS > 512) return CW_ERR_INVALID;
+    dim3 grid(p.H, p.B, ATT_NS);
+    if (bf16) hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t>), grid, dim3(DEC_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((attn_cross_split_kernel<float>), grid, dim3(DEC_THREADS), 0, st, p);
+    return CW_OK;
+}
+
+// p[k] = e[k] * exp(m_s - M) / sum_s l_s exp(m_s - M) for the key range of split s.  grid (L, n_align, B).
+__global__ void align_normalize_kernel(float* __restrict__ align, const float* __restrict__ align_ml, int n_align,
+                                       int align_rows, int n_keys) {
+    const int row = blockIdx.x, a = blockIdx.y, b = blockIdx.z;
+    const size_t rowi = ((size_t)b * n_align + a) * align_rows + row;
+    const float* ml = align_ml + rowi * ATT_NS * 2;
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < ATT_NS; ++s) M = fmaxf(M, ml[2 * s]);
+    float L = 0.f, w[ATT_NS];
+#pragma unroll
+    for (int s = 0; s < ATT_NS; ++s) { w[s] = expf(ml[2 * s] - M); L += ml[2 * s + 1] * w[s]; }
+    const float inv = 1.0f / L;
+    const int per = (n_keys + ATT_NS - 1) / ATT_NS;
+    float* dst = align + rowi * n_keys;
+    for (int k = threadIdx.x; k < n_keys; k += blockDim.x) dst[k] = dst[k] * (w[k / per] * inv);
+}
+
+int cw_launch_align_normalize(float* align, const float* align_ml, int B, int n_align, int align_rows, int L,
+                              int n_keys, hipStream_t st) {
+    if (L <= 0) return CW_OK;
+    hipLaunchKernelGGL(align_normalize_kernel, dim3(L, n_align, B), dim3(256), 0, st, align, align_ml, n_align,
+                       align_rows, n_keys);
+    return CW_OK;
+}

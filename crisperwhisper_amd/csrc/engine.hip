@@ -65,6 +65,8 @@ struct cw_ctx {
         *d_nunf = nullptr, *d_align_slot = nullptr;
     unsigned char* d_mask = nullptr;
     float* d_align = nullptr;
+    float *d_part_o = nullptr, *d_part_ml = nullptr, *d_align_ml = nullptr;   // split cross-attention partials
+    bool align_unnormalized = false;
     int* h_nunf = nullptr;  // pinned
     int *d_pos = nullptr, *d_cfg = nullptr;   // per-row decoder input position; [n_prompt, min_new, max_length, use_forced]
     hipGraphExec_t step_graph[65] = {};       // captured decode step (layers + logits + sampling) per batch size
@@ -324,6 +326,9 @@ static int create_impl(cw_ctx* c) {
     }
     const int Ha = d.n_align > 0 ? d.n_align : 1;
     CWCHK(c, dmalloc(c, &c->d_align, (size_t)Bm * Ha * TGT * CW_N_CTX * 4));
+    CWCHK(c, dmalloc(c, &c->d_part_o, (size_t)ATT_NS * Bm * D * 4));
+    CWCHK(c, dmalloc(c, &c->d_part_ml, (size_t)Bm * H * ATT_NS * 2 * 4));
+    CWCHK(c, dmalloc(c, &c->d_align_ml, (size_t)Bm * Ha * TGT * ATT_NS * 2 * 4));
 
     // ---- timestamps workspace
     CWCHK(c, dmalloc(c, &c->d_mean, (size_t)Bm * Ha * CW_N_CTX * 4));
@@ -632,13 +637,20 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
             CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, L.lnc_b, ep));
         }
-        {
+        if (c->bf16 && nb <= 16) {
+            // keys split over ATT_NS blocks per (row, head); the out-projection GEMV combines the partials
+            CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml,
+                               c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_ml, c->d_align_slot + (size_t)l * H,
+                               c->d_pos, c->d.n_align, TGT, nb, H};
+            CWCHK(c, cw_launch_attn_cross_split(true, p, c->st));
+            EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
+            CombineParams cb{c->d_part_ml, H, nb * D};
+            CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb));
+        } else {
             DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn,
                             c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_slot + (size_t)l * H,
                             c->d.n_align, TGT, nb, H};
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
-        }
-        {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo_c, D, nullptr, nullptr, ep));
         }
@@ -756,6 +768,7 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
     }
     if (argmax_out) HIPCHK(c, hipMemcpy(argmax_out, c->d_argmax, (size_t)nb * TGT * 4, hipMemcpyDeviceToHost));
     c->last_L = t - 1;   // attention rows retained: one per decoder input position
+    c->align_unnormalized = c->bf16 && nb <= 16 && c->d.n_align > 0;
     c->last_nb = nb;
     return CW_OK;
 }
@@ -772,10 +785,19 @@ int32_t cw_set_logits_capture(cw_ctx* c, float* host_buf, int32_t max_steps) {
     return CW_OK;
 }
 
+static int normalize_alignment(cw_ctx* c) {
+    if (!c->align_unnormalized) return CW_OK;
+    CWCHK(c, cw_launch_align_normalize(c->d_align, c->d_align_ml, c->last_nb, c->d.n_align, c->d.max_target_positions,
+                                       c->last_L, CW_N_CTX, c->st));
+    c->align_unnormalized = false;
+    return CW_OK;
+}
+
 int32_t cw_get_alignment(cw_ctx* c, float* out, int32_t nb, int32_t L) {
     const int Ha = c->d.n_align, TGT = c->d.max_target_positions;
     if (Ha <= 0) return fail(c, CW_ERR_STATE, "no alignment heads configured");
     if (nb > c->last_nb || L > c->last_L) return fail(c, CW_ERR_STATE, "only %d x %d rows retained", c->last_nb, c->last_L);
+    CWCHK(c, normalize_alignment(c));
     HIPCHK(c, hipStreamSynchronize(c->st));
     for (int b = 0; b < nb; ++b)
         for (int a = 0; a < Ha; ++a)
@@ -820,6 +842,7 @@ int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, 
     HIPCHK(c, hipMemcpyAsync(c->d_ncols, ncols.data(), nb * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     StageTimer tm(c, CW_STAGE_TIMESTAMPS);
+    CWCHK(c, normalize_alignment(c));
     CWCHK(c, run_alignment(c, c->d_align, nb, Ha, TGT, S, n_prompt, N, c->d_ncols, c->d.median_filter_width, c->d_mean, c->d_std, c->d_mat));
     CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->d_path_text, c->d_path_time, c->d_path_len, c->st));
     KCHK(c);
@@ -980,14 +1003,53 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim;
     if (nb < 1 || nb > c->Bm || iters < 1) return fail(c, CW_ERR_INVALID, "time_kernel: bad args");
     LayerW& L = c->dec[0];
+    const int TGT = c->d.max_target_positions, V = c->d.vocab_size;
     auto launch = [&]() -> int {
-        if (which == 0) {
-            EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
-            return gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep);
+        switch (which) {
+            case 0: {   // fc1: LN + GEMV + GELU
+                EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
+                return gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep);
+            }
+            case 1: {   // cross-attention
+                if (c->bf16 && nb <= 16) {
+                    CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml, nullptr, c->d_align_ml, nullptr,
+                                       c->d_pos, 0, 0, nb, H};
+                    return cw_launch_attn_cross_split(true, p, c->st);
+                }
+                DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, nullptr, c->dattn, nullptr, nullptr, 0, 0, nb, H};
+                return cw_launch_attn_decode(c->bf16, p, c->st);
+            }
+            case 2: {   // self-attention out projection (in-place residual, K split)
+                EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
+                return gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep);
+            }
+            case 3: {   // LN + qkv + cache append
+                EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
+                ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
+                return gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, L.ln1_b, ep);
+            }
+            case 4: {   // LN + cross q
+                EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
+                return gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, L.lnc_b, ep);
+            }
+            case 5: {   // fc2
+                EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.b2; ep.ldo = D;
+                return gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep);
+            }
+            case 6: {   // self-attention at the positions in d_pos
+                DecAttnParams p{c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nullptr, nullptr, 0, 0, nb, H};
+                return cw_launch_attn_decode(c->bf16, p, c->st);
+            }
+            case 7: {   // logits
+                EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = V;
+                return gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep);
+            }
+            case 8:     // near-empty kernel: launch/boundary floor
+                return cw_launch_set_pos(c->d_pos, 64, nb, c->st);
+            default: return CW_ERR_INVALID;
         }
-        DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, nullptr, c->dattn, nullptr, nullptr, 0, 0, nb, H};
-        return cw_launch_attn_decode(c->bf16, p, c->st);
     };
+    if (which == 6 || which == 3) { CWCHK(c, cw_launch_set_pos(c->d_pos, 64, nb, c->st)); }
     for (int i = 0; i < 3; ++i) CWCHK(c, launch());
     HIPCHK(c, hipEventRecord(c->ev0, c->st));
     for (int i = 0; i < iters; ++i) CWCHK(c, launch());
@@ -996,8 +1058,17 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *avg_ms = ms / iters;
-    if (which == 0) *algo_bytes = (double)F * D * c->esz + (double)nb * D * 4 + (double)nb * F * 4;
-    else *algo_bytes = 2.0 * nb * H * CW_N_CTX * 64 * c->esz + 2.0 * nb * D * 4;
+    const double e = (double)c->esz;
+    switch (which) {
+        case 0: *algo_bytes = (double)F * D * e + (double)nb * D * 4 + (double)nb * F * 4; break;
+        case 1: *algo_bytes = 2.0 * nb * H * CW_N_CTX * 64 * e + 2.0 * nb * D * 4; break;
+        case 2: case 4: *algo_bytes = (double)D * D * e + 2.0 * nb * D * 4; break;
+        case 3: *algo_bytes = 3.0 * D * D * e + 4.0 * nb * D * 4; break;
+        case 5: *algo_bytes = (double)F * D * e + (double)nb * (D + F) * 4; break;
+        case 6: *algo_bytes = 2.0 * nb * H * 65 * 64 * e + 2.0 * nb * D * 4; break;
+        case 7: *algo_bytes = (double)V * D * e + (double)nb * (D + V) * 4; break;
+        default: *algo_bytes = 0; break;
+    }
     return CW_OK;
 }
 

@@ -311,11 +311,12 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const float* __restrict_
 // grid = (ceil(N/16), KSPLIT).  KSPLIT > 1 is only used with the in-place residual epilogue, where the
 // partial sums are accumulated with f32 atomics straight into the residual stream.
 // ---------------------------------------------------------------------------------------------------
-template <int EPI, int RPW, bool ATOMIC>
+template <int EPI, int RPW, bool ATOMIC, bool COMBINE>
 __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict__ x, int Mb, int K, int Kb,
                                                          const bf16_t* __restrict__ W, int N,
                                                          const float* __restrict__ ln_g,
-                                                         const float* __restrict__ ln_b, EpiParams ep) {
+                                                         const float* __restrict__ ln_b, EpiParams ep,
+                                                         CombineParams cb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const int xs_stride = Kb + 8;
     bf16_t* xs = (bf16_t*)smem2;                              // [16][Kb+8]
@@ -328,6 +329,60 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     const int steps = Kb >> 7;
     const int n = n0 + l15;
 
+    // Issue order matters: vmcnt retires in order, so the small activation / LayerNorm-parameter loads go
+    // first and the (long) weight stream last -- the LayerNorm math then overlaps the weight fetch.
+    const float bias_v = (ep.bias && n < N) ? ep.bias[n] : 0.f;
+    // phase 1a: activation rows wave, wave+4, ... -> registers -> (LayerNorm) -> bf16 -> LDS
+    const int per_lane = 5;                                   // ceil(1280 / 4 / 64)
+    const int nvec = Kb >> 2;                                 // float4 per row slice
+    float4 xv[RPW][per_lane];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int row = wave + 4 * i;
+#pragma unroll
+        for (int c = 0; c < per_lane; ++c) {
+            const int v4 = lane + 64 * c;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < Mb && v4 < nvec) {
+                const size_t off = (size_t)row * K + kbase + v4 * 4;
+                if (!COMBINE) {
+                    r = *(const float4*)(x + off);
+                } else {   // x = sum_s w_s o_s over the ATT_NS attention partials of head (k / 64)
+                    const int head = (kbase + v4 * 4) >> 6;
+                    const float* ml = cb.part_ml + ((size_t)row * cb.H + head) * ATT_NS * 2;
+                    float m[ATT_NS], l[ATT_NS];
+                    float4 o[ATT_NS];
+#pragma unroll
+                    for (int sI = 0; sI < ATT_NS; ++sI) {
+                        const float2 t = *(const float2*)(ml + 2 * sI);
+                        m[sI] = t.x; l[sI] = t.y;
+                        o[sI] = *(const float4*)(x + (size_t)sI * cb.plane + off);
+                    }
+                    float M = m[0];
+#pragma unroll
+                    for (int sI = 1; sI < ATT_NS; ++sI) M = fmaxf(M, m[sI]);
+                    float L = 0.f;
+#pragma unroll
+                    for (int sI = 0; sI < ATT_NS; ++sI) {
+                        const float w = __expf(m[sI] - M);
+                        L += l[sI] * w;
+                        r.x += w * o[sI].x; r.y += w * o[sI].y; r.z += w * o[sI].z; r.w += w * o[sI].w;
+                    }
+                    const float inv = 1.0f / L;
+                    r.x *= inv; r.y *= inv; r.z *= inv; r.w *= inv;
+                }
+            }
+            xv[i][c] = r;
+        }
+    }
+    const bool has_ln = ln_g != nullptr;
+    float4 gv[per_lane], bv[per_lane];
+#pragma unroll
+    for (int c = 0; c < per_lane; ++c) {
+        const int v4 = lane + 64 * c;
+        gv[c] = (has_ln && v4 < nvec) ? *(const float4*)(ln_g + v4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[c] = (has_ln && v4 < nvec) ? *(const float4*)(ln_b + v4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // phase 0: weights for steps wave, wave+4, wave+8
     u32x4_t wq[3][4];
     {
@@ -338,7 +393,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
             if (step < steps && n < N) {
                 const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wq[s][j] = __builtin_nontemporal_load(wp + j * 4);   // +32 bf16
+                for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * 4];   // +32 bf16
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wq[s][j] = (u32x4_t){0u, 0u, 0u, 0u};
@@ -346,28 +401,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
         }
     }
 
-    // phase 1: activation rows wave, wave+4, ... -> registers -> (LayerNorm) -> bf16 -> LDS
-    const int per_lane = 5;                                   // ceil(1280 / 4 / 64)
-    const int nvec = Kb >> 2;                                 // float4 per row slice
-    float4 xv[RPW][per_lane];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int row = wave + 4 * i;
-#pragma unroll
-        for (int c = 0; c < per_lane; ++c) {
-            const int v4 = lane + 64 * c;
-            xv[i][c] = (row < Mb && v4 < nvec) ? *(const float4*)(x + (size_t)row * K + kbase + v4 * 4)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    if (ln_g) {   // only launched with Kb == K
-        float4 gv[per_lane], bv[per_lane];
-#pragma unroll
-        for (int c = 0; c < per_lane; ++c) {
-            const int v4 = lane + 64 * c;
-            gv[c] = v4 < nvec ? *(const float4*)(ln_g + v4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bv[c] = v4 < nvec ? *(const float4*)(ln_b + v4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    if (has_ln) {   // only launched with Kb == K
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             float s = 0.f;
@@ -435,10 +469,11 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
         const int m = g * 4 + r;
         if (m < Mb && n < N) {
             if (ATOMIC) {
-                const float bias = (blockIdx.y == 0 && ep.bias) ? ep.bias[n] : 0.f;
-                atomicAdd(ep.outf + (size_t)m * ep.ldo + n, v + bias);
+                atomicAdd(ep.outf + (size_t)m * ep.ldo + n, v + (blockIdx.y == 0 ? bias_v : 0.f));
             } else {
-                epi_store1<bf16_t, EPI>(ep, m, n, v);
+                EpiParams e2 = ep;
+                e2.bias = nullptr;                       // bias was prefetched at kernel entry
+                epi_store1<bf16_t, EPI>(e2, m, n, v + bias_v);
             }
         }
     }
@@ -511,7 +546,9 @@ int cw_gemv_kc(int Mb, int K) {
 
 template <int EPI, int RPW>
 static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b,
-                         const EpiParams& ep, hipStream_t st) {
+                         const EpiParams& ep, hipStream_t st, const CombineParams* comb) {
+    CombineParams cb{nullptr, 0, 0};
+    if (comb) cb = *comb;
     // K split: only for the in-place residual epilogue (f32 atomics into the residual stream), sized so that
     // (N/16) * KSPLIT lands near the CU count and every block streams <= 1280 weights per column.
     int ksplit = 1;
@@ -523,12 +560,19 @@ static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, co
     const int Kb = K / ksplit;
     const size_t lds = (size_t)16 * (Kb + 8) * 2 + 4 * 4 * 64 * 4;
     dim3 grid((N + 15) / 16, ksplit);
-    if (ksplit > 1)
-        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, true>), grid, dim3(256), lds, st, x, Mb, K, Kb, (const bf16_t*)W,
-                           N, ln_g, ln_b, ep);
+    if (EPI == EPI_RESID_F32 && cb.part_ml) {
+        if (ksplit > 1)
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, true>), grid, dim3(256), lds, st, x, Mb, K, Kb,
+                               (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+        else
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, false, true>), grid, dim3(256), lds, st, x, Mb, K, Kb,
+                               (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+    } else if (ksplit > 1)
+        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, true, false>), grid, dim3(256), lds, st, x, Mb, K, Kb,
+                           (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
     else
-        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false>), grid, dim3(256), lds, st, x, Mb, K, Kb,
-                           (const bf16_t*)W, N, ln_g, ln_b, ep);
+        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false>), grid, dim3(256), lds, st, x, Mb, K, Kb,
+                           (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
 }
 
 static bool gemv2_ok(int epi, int Mb, int K, const float* ln_g, const EpiParams& ep) {
@@ -543,11 +587,12 @@ static bool gemv2_ok(int epi, int Mb, int K, const float* ln_g, const EpiParams&
 
 template <int EPI>
 static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
-                           const float* ln_b, const EpiParams& ep, hipStream_t st) {
+                           const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb) {
+    if (comb && !(bf16 && gemv2_ok(EPI, Mb, K, ln_g, ep) && EPI == EPI_RESID_F32)) return CW_ERR_INVALID;
     if (bf16) {
         if (gemv2_ok(EPI, Mb, K, ln_g, ep)) {
-            if (Mb <= 8) launch_gemv2<EPI, 2>(x, Mb, K, W, N, ln_g, ln_b, ep, st);
-            else launch_gemv2<EPI, 4>(x, Mb, K, W, N, ln_g, ln_b, ep, st);
+            if (Mb <= 8) launch_gemv2<EPI, 2>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
+            else launch_gemv2<EPI, 4>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
             return CW_OK;
         }
         int kc = cw_gemv_kc(Mb, K);
@@ -565,13 +610,13 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
 }
 
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
-                   const float* ln_b, const EpiParams& ep, hipStream_t st) {
+                   const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb) {
     if (Mb <= 0 || Mb > GV_MAXM || K % 128 != 0) return CW_ERR_INVALID;
     switch (epi) {
-        case EPI_GELU_F32: return launch_gemv_epi<EPI_GELU_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st);
-        case EPI_RESID_F32: return launch_gemv_epi<EPI_RESID_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st);
-        case EPI_STORE_F32: return launch_gemv_epi<EPI_STORE_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st);
-        case EPI_QKV_CACHE: return launch_gemv_epi<EPI_QKV_CACHE>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st);
+        case EPI_GELU_F32: return launch_gemv_epi<EPI_GELU_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
+        case EPI_RESID_F32: return launch_gemv_epi<EPI_RESID_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
+        case EPI_STORE_F32: return launch_gemv_epi<EPI_STORE_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
+        case EPI_QKV_CACHE: return launch_gemv_epi<EPI_QKV_CACHE>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
         default: return CW_ERR_INVALID;
     }
 }

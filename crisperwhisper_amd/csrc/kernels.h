@@ -14,8 +14,9 @@ struct AParams {
 
 int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
                    hipStream_t st);
+struct CombineParams;
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
-                   const float* ln_b, const EpiParams& ep, hipStream_t st);
+                   const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr);
 
 // elementwise.hip
 int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d,
@@ -66,6 +67,32 @@ struct DecAttnParams {
     int B, H;
 };
 int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st);
+
+// Cross-attention decode split over the 1500 keys (flash-decoding): ATT_NS blocks per (batch, head) write
+// un-normalised partial outputs + (max, sum); the consumer GEMV combines them while loading its activations,
+// alignment rows are normalised once per generate call by cw_launch_align_normalize.
+#define ATT_NS 4
+struct CrossSplitParams {
+    const float* q;        // [B][H*64]
+    const void* K;         // [B][H][1500][64]
+    const void* V;
+    int n_keys;            // 1500
+    float* part_o;         // [ATT_NS][B][H*64] un-normalised sum_k exp(s_k - m) v_k
+    float* part_ml;        // [B][H][ATT_NS][2]  (m, l)
+    float* align_out;      // [B][n_align][align_rows][n_keys] (un-normalised exp) or null
+    float* align_ml;       // [B][n_align][align_rows][ATT_NS][2]
+    const int* align_slot; // [H]
+    const int* pos;        // [B] alignment row to write
+    int n_align, align_rows, B, H;
+};
+int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st);
+int cw_launch_align_normalize(float* align, const float* align_ml, int B, int n_align, int align_rows, int L,
+                              int n_keys, hipStream_t st);
+struct CombineParams {     // activations of a GEMV = combination of ATT_NS attention partials
+    const float* part_ml;  // null: plain activations
+    int H;                 // heads
+    int plane;             // elements per partial plane (B * K)
+};
 
 // mel.hip
 struct MelTables {

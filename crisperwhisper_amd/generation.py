@@ -29,11 +29,32 @@ class Segment:
     idxs: tuple
 
 
-def init_tokens(spec, language: Optional[str], task: Optional[str]) -> List[int]:
+def detect_language(engine: Engine, n_items: int) -> np.ndarray:
+    """``WhisperGenerationMixin.detect_language`` (:1610-1673): one decoder step on <|startoftranscript|>
+    over the already-encoded windows, argmax restricted to the language tokens.  Returns [n_items] ids.
+    (HF runs a second encoder pass for this; the native path reuses the encoder output of the first
+    seek iteration, which covers the same 3000-frame window.)"""
+    spec = engine.spec
+    if not spec.lang_to_id:
+        raise ValueError("Cannot detect language for an English-only checkpoint: the generation config has no `lang_to_id`.")
+    prompt = np.full((n_items, 1), spec.decoder_start_token_id, dtype=np.int32)
+    engine.decode(prompt, max_length=2)
+    logits = engine.last_logits(n_items)
+    lang_ids = np.array(sorted(set(spec.lang_to_id.values())), dtype=np.int64)
+    return lang_ids[np.argmax(logits[:, lang_ids], axis=-1)]
+
+
+def init_tokens(spec, language: Optional[str], task: Optional[str], lang_id: Optional[int] = None) -> List[int]:
     """<|startoftranscript|><|lang|><|task|> (no <|notimestamps|>: return_timestamps=True)."""
     if language is None:
-        raise ValueError("language detection is not implemented on the native path: pass "
-                         "generate_kwargs={'language': '<|en|>'} (the parity policy fixes it, SURVEY.md 8c)")
+        if lang_id is None:
+            raise ValueError("language is None and no detected language id was supplied")
+        # with a detected language HF appends the task token only when `task` was given (:1575-1590)
+        if task is None:
+            return [spec.decoder_start_token_id, int(lang_id)]
+        if task not in spec.task_to_id:
+            raise ValueError(f"The `{task}` task is not supported. The task should be one of `{sorted(spec.task_to_id)}`")
+        return [spec.decoder_start_token_id, int(lang_id), spec.task_to_id[task]]
     lang = language if language in spec.lang_to_id else f"<|{language}|>"
     if lang not in spec.lang_to_id:
         raise ValueError(f"Unsupported language: {language}. Language should be one of: {sorted(spec.lang_to_id)}.")
@@ -86,12 +107,20 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
     if num_beams not in (None, 1):
         raise ValueError("the native path implements greedy decoding only: pass generate_kwargs={'num_beams': 1} "
                          "(transformers 5.x pipelines default to 5 beams; the 2024 reference was greedy)")
-    init = np.asarray(init_tokens(spec, language, task), dtype=np.int32)
-    n_prompt = len(init)
+    num_frames = np.asarray(num_frames, dtype=np.int64)
+    pre_encoded = False
+    if language is None:
+        # language auto-detection (the reference does not pass `language`, REF/transcribe.py:33)
+        engine.encode(list(range(n_items)), np.zeros(n_items, np.int64), np.full(n_items, N_FRAMES, np.int64))
+        langs = detect_language(engine, n_items)
+        init = np.asarray([init_tokens(spec, None, task, lang_id=l) for l in langs], dtype=np.int32)
+        pre_encoded = True
+    else:
+        init = np.tile(np.asarray(init_tokens(spec, language, task), dtype=np.int32), (n_items, 1))
+    n_prompt = init.shape[1]
     if max_new_tokens is not None and max_new_tokens + n_prompt > spec.max_target_positions:
         max_new_tokens = spec.max_target_positions - n_prompt     # :1937-1942
     tb = spec.timestamp_begin
-    num_frames = np.asarray(num_frames, dtype=np.int64)
     seek = np.zeros(n_items, dtype=np.int64)
     max_frames = np.full(n_items, N_FRAMES, dtype=np.int64)
     segments: List[List[Segment]] = [[] for _ in range(n_items)]
@@ -101,9 +130,10 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
         if not active:
             break
         seek_num = np.minimum(max_frames - seek, N_FRAMES)
-        engine.encode(active, seek[active], seek_num[active])
+        if not (pre_encoded and n_calls == 0):            # first pass: windows already encoded for detection
+            engine.encode(active, seek[active], seek_num[active])
         max_length = (n_prompt + max_new_tokens) if max_new_tokens is not None else min(spec.max_length, spec.max_target_positions)
-        seqs, lens, _ = engine.decode(np.tile(init, (len(active), 1)), max_length, min_new_tokens or 0)
+        seqs, lens, _ = engine.decode(init[active], max_length, min_new_tokens or 0)
         total = int(lens.max())
         L = total - 1
         token_ts = engine.token_timestamps(len(active), L, n_prompt, (num_frames - seek)[active])

@@ -106,8 +106,18 @@ def _retrieve_segment(seq: np.ndarray, token_ts: np.ndarray, time_offset: float,
     return segments, seg_off
 
 
-def generate(model, spec: GenSpec, input_features: np.ndarray, num_frames: np.ndarray, *, language: str,
-             task: str = "transcribe", max_new_tokens: Optional[int] = None,
+def detect_language(model, spec: GenSpec, input_features: np.ndarray) -> np.ndarray:
+    """:1610-1673: encoder on the first 3000 frames + one decoder step on <|startoftranscript|>,
+    argmax over the language ids."""
+    enc = model.encode(input_features[:, :, :3000])
+    cache = model.new_cache(enc)
+    logits, _ = model.decode(np.full((enc.shape[0], 1), spec.sot, dtype=np.int64), cache)
+    lang_ids = np.array(sorted(set(spec.lang_to_id.values())), dtype=np.int64)
+    return lang_ids[np.argmax(logits[:, lang_ids], axis=-1)]
+
+
+def generate(model, spec: GenSpec, input_features: np.ndarray, num_frames: np.ndarray, *, language: Optional[str],
+             task: Optional[str] = "transcribe", max_new_tokens: Optional[int] = None,
              min_new_tokens: Optional[int] = None, trace: Optional[list] = None):
     """input_features [B, n_mels, 3000]; num_frames [B] = attention_mask.sum(-1) (:1694).
 
@@ -116,7 +126,12 @@ def generate(model, spec: GenSpec, input_features: np.ndarray, num_frames: np.nd
     B, _, total = input_features.shape
     nseg = 3000
     tb = spec.timestamp_begin
-    init = np.array([[spec.sot, spec.lang_to_id[language], spec.task_to_id[task]]] * B, dtype=np.int64)
+    if language is None:      # :1558-1590: detected language; the task token only if a task was passed
+        langs = detect_language(model, spec, input_features)
+        init = np.array([[spec.sot, int(l)] + ([spec.task_to_id[task]] if task is not None else []) for l in langs],
+                        dtype=np.int64)
+    else:
+        init = np.array([[spec.sot, spec.lang_to_id[language], spec.task_to_id[task or "transcribe"]]] * B, dtype=np.int64)
     begin_index = init.shape[1]
     seek = np.zeros(B, dtype=np.int64)
     max_frames = np.full(B, total, dtype=np.int64)

@@ -31,7 +31,7 @@ def chunk_iter(n: int, chunk_len: int, stride_left: int, stride_right: int):
 
 
 def transcribe(model, spec: G.GenSpec, vocab: C.ByteVocab, pcm: np.ndarray, *, n_mels: int, batch_size: int = 16,
-               chunk_length_s: float = 30.0, language: str = "<|en|>", task: str = "transcribe",
+               chunk_length_s: float = 30.0, language: Optional[str] = "<|en|>", task: Optional[str] = "transcribe",
                max_new_tokens: Optional[int] = None, min_new_tokens: Optional[int] = None,
                sampling_rate: int = 16000, trace: Optional[list] = None):
     """The ``pipe(array)`` call of REF/transcribe.py:33 on a mono float array -> {"text","chunks"}."""

@@ -100,6 +100,9 @@ def gen_e2e():
         "mixed70_b2_n40": ("mixed", 70, 0, 2, {"max_new_tokens": 40}),
         "noise35_b4_free": ("noise", 35, 5, 4, {}),
         "chirp12_b1_n24": ("chirp", 12, 2, 1, {"max_new_tokens": 24, "min_new_tokens": 24}),
+        # language auto-detection, as the reference calls it (REF/transcribe.py:33 passes no language)
+        "noise40_b2_autolang": ("noise", 40, 8, 2, {"max_new_tokens": 20, "language": None, "task": "transcribe"}),
+        "mixed20_b1_autolang_notask": ("mixed", 20, 4, 1, {"max_new_tokens": 20, "language": None, "task": None}),
     }
     meta = {}
     arrays = {}
@@ -117,7 +120,9 @@ def gen_e2e():
 
         model.generate = spy
         try:
-            res = pipe(x.copy(), generate_kwargs={**GEN_KW, **extra})
+            gk = {**GEN_KW, **extra}
+            gk = {k: val for k, val in gk.items() if val is not None}     # None = do not pass (auto-detect)
+            res = pipe(x.copy(), generate_kwargs=gk)
         finally:
             model.generate = orig
         meta[name] = {"kind": kind, "secs": secs, "seed": seed, "batch_size": bs, "extra": extra,

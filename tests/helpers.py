@@ -86,14 +86,22 @@ class OracleBackedEngine:
 
     def decode(self, prompt, max_length, min_new_tokens=0, forced=None, want_argmax=False):
         prompt = np.asarray(prompt, dtype=np.int64)
+        self._last_prompt = prompt
         n_prompt = prompt.shape[1]
         seqs, weights = OG.greedy(self.model, self.ospec, self.enc, prompt, begin_index=n_prompt,
                                   max_new_tokens=max_length - n_prompt, min_new_tokens=min_new_tokens)
         self.weights = weights
+        self._last_logits = getattr(self.model, "_dbg_last_logits", None)
         out = np.full((seqs.shape[0], self.spec.max_target_positions), self.spec.pad_token_id, np.int32)
         out[:, :seqs.shape[1]] = seqs
         lens = np.full(seqs.shape[0], seqs.shape[1], np.int32)
         return out, lens, None
+
+    def last_logits(self, nb):
+        """logits after feeding the prompt (used by language detection: prompt = <|startoftranscript|>)."""
+        cache = self.model.new_cache(self.enc)
+        logits, _ = self.model.decode(self._last_prompt, cache)
+        return logits[:nb]
 
     def token_timestamps(self, nb, L, n_prompt, num_frames):
         assert self.weights.shape[2] == L

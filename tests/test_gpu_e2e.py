@@ -94,7 +94,7 @@ def test_teacher_forced_decoder(tiny, eng_f32, eng_bf16, mode):
     assert np.abs(al[0].sum(-1) - 1).max() < 1e-3       # rows are probability vectors
 
 
-@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24"])
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask"])
 def test_pipeline_f32_word_for_word_vs_reference(tiny, name):
     """The drop-in call of REF/transcribe.py:21-33 + REF/README pause split, f32 engine, against the
     transformers CPU output: identical text/words, timestamps within +-0.02 s (one encoder frame)."""

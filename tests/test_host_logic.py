@@ -47,7 +47,7 @@ def test_shard_bounds_and_records():
     assert idx == 7 and toks.tolist() == [1, 2, 300] and ts.tolist() == [0.5, 1.25] and stride == (30.0, 5.0, 0.0)
 
 
-@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24"])
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask"])
 def test_host_control_flow_word_for_word(name):
     """generation.generate + collate.decode_asr (product host code) over the oracle-backed engine
     reproduce the reference pipeline output word for word."""
@@ -62,9 +62,9 @@ def test_host_control_flow_word_for_word(name):
     for b0 in range(0, len(windows), meta["batch_size"]):
         batch = windows[b0:b0 + meta["batch_size"]]
         _, nf = eng.mel([x[s:s + n] for s, n, _, _ in batch])
-        out = generation.generate(eng, len(batch), nf, language="<|en|>", task="transcribe",
-                                  max_new_tokens=meta["extra"].get("max_new_tokens"),
-                                  min_new_tokens=meta["extra"].get("min_new_tokens"))
+        kw = {"language": "<|en|>", "task": "transcribe", **meta["extra"]}
+        out = generation.generate(eng, len(batch), nf, language=kw["language"], task=kw["task"],
+                                  max_new_tokens=kw.get("max_new_tokens"), min_new_tokens=kw.get("min_new_tokens"))
         assert np.array_equal(out["sequences"], z[f"{name}/call{call}/sequences"])
         for k, (_, _, st, _) in enumerate(batch):
             assert np.array_equal(out["token_timestamps"][k], z[f"{name}/call{call}/tts{k}"])

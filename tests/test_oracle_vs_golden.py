@@ -69,14 +69,15 @@ def test_teacher_forced_logits_and_cross_attention():
     assert np.abs(cross[0] - z["tf/cross"]).max() < 1e-5
 
 
-@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24"])
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask"])
 def test_pipeline_word_for_word(name):
     g, v, W, spec = Hh.tiny_setup()
     meta = Hh.gold_json("e2e_golden.json")[name]
     x = syn.synth_audio(meta["seed"], meta["secs"] * 16000, meta["kind"])
     orc = WhisperOracle(W, g)
+    kw = {"language": "<|en|>", "task": "transcribe", **meta["extra"]}
     out = OPIPE.transcribe(orc, Hh.oracle_spec(g, v, spec), Hh.oracle_vocab(v), x, n_mels=g.n_mels,
-                           batch_size=meta["batch_size"], **meta["extra"])
+                           batch_size=meta["batch_size"], **kw)
     assert out["text"] == meta["text"]
     ok, why = Hh.words_equal(out["chunks"], meta["chunks"], tol=0.0)
     assert ok, why
