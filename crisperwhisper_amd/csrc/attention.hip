@@ -270,9 +270,9 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
     for (int k0 = grp; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
         float kv[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * DEC_GROUPS;
-            if (k < n_keys) Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv[u]);
+        for (int u = 0; u < 4; ++u) {   // unconditional loads (clamped row): no exec-masked blocks, all in flight
+            const int k = min(k0 + u * DEC_GROUPS, n_keys - 1);
+            Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
         float vv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * DEC_GROUPS;
-            if (k < n_keys) Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv[u]);
+            const int k = min(k0 + u * DEC_GROUPS, n_keys - 1);
+            Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -358,9 +358,9 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSpli
     for (int k0 = grp; k0 < nk; k0 += 4 * DEC_GROUPS) {
         float kv[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * DEC_GROUPS;
-            if (k < nk) Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv[u]);
+        for (int u = 0; u < 4; ++u) {   // unconditional loads (clamped row): no exec-masked blocks, all in flight
+            const int k = min(k0 + u * DEC_GROUPS, nk - 1);
+            Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -398,8 +398,8 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSpli
         float vv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * DEC_GROUPS;
-            if (k < nk) Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv[u]);
+            const int k = min(k0 + u * DEC_GROUPS, nk - 1);
+            Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -16,11 +16,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;   // one MFMA 16x16 C
 __host__ __device__ inline float bf16_to_f32(bf16_t v) {
     union { uint32_t u; float f; } x; x.u = ((uint32_t)v) << 16; return x.f;
 }
-__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {   // round-nearest-even, branchless (NaN stays quiet NaN)
     union { uint32_t u; float f; } x; x.f = f;
-    if ((x.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x.u >> 16) | 0x40);  // quiet NaN
-    x.u += 0x7fffu + ((x.u >> 16) & 1u);                                          // round-nearest-even
-    return (bf16_t)(x.u >> 16);
+    const uint32_t rounded = (x.u + 0x7fffu + ((x.u >> 16) & 1u)) >> 16;
+    const uint32_t nan = (x.u >> 16) | 0x40u;
+    return (bf16_t)(((x.u & 0x7fffffffu) > 0x7f800000u) ? nan : rounded);
 }
 
 // Activation storage trait: the engine runs either fully in f32 (parity mode) or with bf16

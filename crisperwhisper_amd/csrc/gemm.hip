@@ -302,16 +302,20 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------------
 // Decode GEMV v2 (Mb <= 16, K slice per block <= 1280).  Latency-oriented rewrite of the kernel above:
-//   phase 0  every wave issues ALL of its weight loads (<= 3 steps x 64 B per lane, non-temporal) first;
-//   phase 1  while they fly, each wave pulls its 2-4 activation rows straight into registers (all loads in
-//            flight at once), does the LayerNorm statistics wave-locally (a row lives in one wave: no block
-//            barrier), normalises, rounds to bf16 and parks the rows in LDS;
-//   phase 2  one barrier, then MFMA 16x16x32 over the wave's K steps;
-//   phase 3  cross-wave reduction through LDS, epilogue spread over all 256 threads.
+//   * every global load is UNCONDITIONAL (indices are clamped to valid memory instead of predicated):
+//     hipcc otherwise wraps each load in its own exec-masked block and serialises them with vmcnt waits;
+//     garbage in unused MFMA rows/columns is harmless because it never reaches a stored output;
+//   * issue order: bias, activation rows, LayerNorm parameters, then the weight stream -- vmcnt retires
+//     in order, so the LayerNorm math overlaps the weight fetch;
+//   * a row of activations lives in one wave (rows wave, wave+4, ...): LayerNorm statistics are wave-local
+//     shuffles, no block barrier; rows are rounded to bf16 and parked in LDS;
+//   * one barrier, MFMA 16x16x32 over the wave's K steps, cross-wave reduction through LDS, epilogue
+//     spread over all 256 threads.
 // grid = (ceil(N/16), KSPLIT).  KSPLIT > 1 is only used with the in-place residual epilogue, where the
 // partial sums are accumulated with f32 atomics straight into the residual stream.
+// NSLOT = ceil(steps / 4) weight steps per wave, PER_LANE = ceil(Kb / 256) float4 per lane per row.
 // ---------------------------------------------------------------------------------------------------
-template <int EPI, int RPW, bool ATOMIC, bool COMBINE>
+template <int EPI, int RPW, bool ATOMIC, bool COMBINE, int NSLOT, int PER_LANE>
 __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict__ x, int Mb, int K, int Kb,
                                                          const bf16_t* __restrict__ W, int N,
                                                          const float* __restrict__ ln_g,
@@ -322,82 +326,82 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     bf16_t* xs = (bf16_t*)smem2;                              // [16][Kb+8]
     float* red = (float*)(smem2 + (size_t)16 * xs_stride * 2); // [4 waves][4][64]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int kbase = blockIdx.y * Kb;
     const int steps = Kb >> 7;
     const int n = n0 + l15;
-
-    // Issue order matters: vmcnt retires in order, so the small activation / LayerNorm-parameter loads go
-    // first and the (long) weight stream last -- the LayerNorm math then overlaps the weight fetch.
-    const float bias_v = (ep.bias && n < N) ? ep.bias[n] : 0.f;
-    // phase 1a: activation rows wave, wave+4, ... -> registers -> (LayerNorm) -> bf16 -> LDS
-    const int per_lane = 5;                                   // ceil(1280 / 4 / 64)
+    const int nc = n < N ? n : N - 1;                         // clamped column (results of n >= N are dropped)
     const int nvec = Kb >> 2;                                 // float4 per row slice
-    float4 xv[RPW][per_lane];
+    const bool has_ln = ln_g != nullptr;
+
+    const float bias_v = ep.bias ? ep.bias[nc] : 0.f;
+
+    // activation rows -> registers
+    float4 xv[RPW][PER_LANE];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-        const int row = wave + 4 * i;
+        int row = wave + 4 * i;
+        row = row < Mb ? row : Mb - 1;
 #pragma unroll
-        for (int c = 0; c < per_lane; ++c) {
-            const int v4 = lane + 64 * c;
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < Mb && v4 < nvec) {
-                const size_t off = (size_t)row * K + kbase + v4 * 4;
-                if (!COMBINE) {
-                    r = *(const float4*)(x + off);
-                } else {   // x = sum_s w_s o_s over the ATT_NS attention partials of head (k / 64)
-                    const int head = (kbase + v4 * 4) >> 6;
-                    const float* ml = cb.part_ml + ((size_t)row * cb.H + head) * ATT_NS * 2;
-                    float m[ATT_NS], l[ATT_NS];
-                    float4 o[ATT_NS];
+        for (int c = 0; c < PER_LANE; ++c) {
+            int v4 = lane + 64 * c;
+            v4 = v4 < nvec ? v4 : nvec - 1;
+            const size_t off = (size_t)row * K + kbase + v4 * 4;
+            if (!COMBINE) {
+                xv[i][c] = *(const float4*)(x + off);
+            } else {   // x = sum_s w_s o_s over the ATT_NS attention partials of head (k / 64)
+                const int head = (kbase + v4 * 4) >> 6;
+                const float* ml = cb.part_ml + ((size_t)row * cb.H + head) * ATT_NS * 2;
+                float m[ATT_NS], l[ATT_NS];
+                float4 o[ATT_NS];
 #pragma unroll
-                    for (int sI = 0; sI < ATT_NS; ++sI) {
-                        const float2 t = *(const float2*)(ml + 2 * sI);
-                        m[sI] = t.x; l[sI] = t.y;
-                        o[sI] = *(const float4*)(x + (size_t)sI * cb.plane + off);
-                    }
-                    float M = m[0];
-#pragma unroll
-                    for (int sI = 1; sI < ATT_NS; ++sI) M = fmaxf(M, m[sI]);
-                    float L = 0.f;
-#pragma unroll
-                    for (int sI = 0; sI < ATT_NS; ++sI) {
-                        const float w = __expf(m[sI] - M);
-                        L += l[sI] * w;
-                        r.x += w * o[sI].x; r.y += w * o[sI].y; r.z += w * o[sI].z; r.w += w * o[sI].w;
-                    }
-                    const float inv = 1.0f / L;
-                    r.x *= inv; r.y *= inv; r.z *= inv; r.w *= inv;
+                for (int sI = 0; sI < ATT_NS; ++sI) {
+                    const float2 t = *(const float2*)(ml + 2 * sI);
+                    m[sI] = t.x; l[sI] = t.y;
+                    o[sI] = *(const float4*)(x + (size_t)sI * cb.plane + off);
                 }
+                float M = m[0];
+#pragma unroll
+                for (int sI = 1; sI < ATT_NS; ++sI) M = fmaxf(M, m[sI]);
+                float L = 0.f;
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int sI = 0; sI < ATT_NS; ++sI) {
+                    const float w = __expf(m[sI] - M);
+                    L += l[sI] * w;
+                    r.x += w * o[sI].x; r.y += w * o[sI].y; r.z += w * o[sI].z; r.w += w * o[sI].w;
+                }
+                const float inv = 1.0f / L;
+                r.x *= inv; r.y *= inv; r.z *= inv; r.w *= inv;
+                xv[i][c] = r;
             }
-            xv[i][c] = r;
         }
     }
-    const bool has_ln = ln_g != nullptr;
-    float4 gv[per_lane], bv[per_lane];
+    // LayerNorm parameters (a valid dummy pointer is passed when there is no LayerNorm; loads are cheap)
+    float4 gv[PER_LANE], bv[PER_LANE];
+    if (has_ln) {   // kernel-uniform: the whole block of loads is either issued or not
 #pragma unroll
-    for (int c = 0; c < per_lane; ++c) {
-        const int v4 = lane + 64 * c;
-        gv[c] = (has_ln && v4 < nvec) ? *(const float4*)(ln_g + v4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        bv[c] = (has_ln && v4 < nvec) ? *(const float4*)(ln_b + v4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < PER_LANE; ++c) {
+            int v4 = lane + 64 * c;
+            v4 = v4 < nvec ? v4 : nvec - 1;
+            gv[c] = *(const float4*)(ln_g + v4 * 4);
+            bv[c] = *(const float4*)(ln_b + v4 * 4);
+        }
     }
-    // phase 0: weights for steps wave, wave+4, wave+8
-    u32x4_t wq[3][4];
+    // weight stream: steps wave, wave+4, wave+8 (clamped: a tail wave re-reads a step another wave owns)
+    u32x4_t wq[NSLOT][4];
     {
-        const bf16_t* wrow = W + (size_t)(n < N ? n : 0) * K + kbase + g * 8;   // MFMA j covers k = j*32 + g*8 .. +7
+        const bf16_t* wrow = W + (size_t)nc * K + kbase + g * 8;   // MFMA j covers k = j*32 + g*8 .. +7
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int step = wave + 4 * s;
-            if (step < steps && n < N) {
-                const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
+        for (int s = 0; s < NSLOT; ++s) {
+            int step = wave + 4 * s;
+            step = step < steps ? step : steps - 1;
+            const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * 4];   // +32 bf16
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wq[s][j] = (u32x4_t){0u, 0u, 0u, 0u};
-            }
+            for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * 4];      // +32 bf16
         }
     }
 
@@ -406,19 +410,21 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
         for (int i = 0; i < RPW; ++i) {
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < per_lane; ++c) s += (xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w);
+            for (int c = 0; c < PER_LANE; ++c) {
+                const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+                s += ok * ((xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w));
+            }
             const float mean = wave_sum(s) / (float)K;
             float q = 0.f;
 #pragma unroll
-            for (int c = 0; c < per_lane; ++c) {
-                if (lane + 64 * c < nvec) {
-                    float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
-                    q += (a * a + b * b) + (cc * cc + d * d);
-                }
+            for (int c = 0; c < PER_LANE; ++c) {
+                const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+                float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
+                q += ok * ((a * a + b * b) + (cc * cc + d * d));
             }
             const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
 #pragma unroll
-            for (int c = 0; c < per_lane; ++c) {
+            for (int c = 0; c < PER_LANE; ++c) {
                 xv[i][c].x = (xv[i][c].x - mean) * rstd * gv[c].x + bv[c].x;
                 xv[i][c].y = (xv[i][c].y - mean) * rstd * gv[c].y + bv[c].y;
                 xv[i][c].z = (xv[i][c].z - mean) * rstd * gv[c].z + bv[c].z;
@@ -426,30 +432,27 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
             }
         }
     }
+    // rows -> bf16 -> LDS.  Rows >= Mb are never written: they only feed MFMA output rows that are dropped.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                              // rows wave + 4*i cover 0..15
+    for (int i = 0; i < RPW; ++i) {
         const int row = wave + 4 * i;
 #pragma unroll
-        for (int c = 0; c < per_lane; ++c) {
-            const int v4 = lane + 64 * c;
-            if (v4 < nvec) {
-                ushort4 o = make_ushort4(0, 0, 0, 0);
-                if (i < RPW && row < Mb) {
-                    const float4 v = xv[i < RPW ? i : 0][c];
-                    o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
-                }
-                *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
-            }
+        for (int c = 0; c < PER_LANE; ++c) {
+            int v4 = lane + 64 * c;
+            v4 = v4 < nvec ? v4 : nvec - 1;                    // clamped lanes rewrite identical data
+            const float4 v = xv[i][c];
+            ushort4 o;
+            o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+            *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
         }
     }
     __syncthreads();
 
-    // phase 2
     f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < NSLOT; ++s) {
         const int step = wave + 4 * s;
-        if (step < steps) {
+        if (step < steps) {                                     // wave-uniform (scalar) branch, no loads inside
             const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
             }
         }
     }
-    // phase 3: D[row = batch g*4 + r][col = l15]
+    // D[row = batch g*4 + r][col = l15]
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
     __syncthreads();
@@ -544,6 +547,26 @@ int cw_gemv_kc(int Mb, int K) {
     return 128;
 }
 
+template <int EPI, int RPW, int NSLOT, int PER_LANE>
+static void launch_gemv2_shape(dim3 grid, size_t lds, int ksplit, const float* x, int Mb, int K, int Kb, const void* W,
+                               int N, const float* ln_g, const float* ln_b, const EpiParams& ep, hipStream_t st,
+                               const CombineParams& cb) {
+    if (EPI == EPI_RESID_F32 && cb.part_ml) {
+        if (ksplit > 1)
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, true, NSLOT, PER_LANE>), grid, dim3(256), lds, st,
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+        else
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, false, true, NSLOT, PER_LANE>), grid, dim3(256), lds, st,
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+    } else if (EPI == EPI_RESID_F32 && ksplit > 1) {
+        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x,
+                           Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+    } else {
+        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x, Mb, K,
+                           Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+    }
+}
+
 template <int EPI, int RPW>
 static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b,
                          const EpiParams& ep, hipStream_t st, const CombineParams* comb) {
@@ -560,19 +583,9 @@ static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, co
     const int Kb = K / ksplit;
     const size_t lds = (size_t)16 * (Kb + 8) * 2 + 4 * 4 * 64 * 4;
     dim3 grid((N + 15) / 16, ksplit);
-    if (EPI == EPI_RESID_F32 && cb.part_ml) {
-        if (ksplit > 1)
-            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, true>), grid, dim3(256), lds, st, x, Mb, K, Kb,
-                               (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
-        else
-            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, false, true>), grid, dim3(256), lds, st, x, Mb, K, Kb,
-                               (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
-    } else if (ksplit > 1)
-        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, true, false>), grid, dim3(256), lds, st, x, Mb, K, Kb,
-                           (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
-    else
-        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false>), grid, dim3(256), lds, st, x, Mb, K, Kb,
-                           (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+    if (Kb <= 256) launch_gemv2_shape<EPI, RPW, 1, 1>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb);
+    else if (Kb <= 768) launch_gemv2_shape<EPI, RPW, 2, 3>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb);
+    else launch_gemv2_shape<EPI, RPW, 3, 5>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb);
 }
 
 static bool gemv2_ok(int epi, int Mb, int K, const float* ln_g, const EpiParams& ep) {
