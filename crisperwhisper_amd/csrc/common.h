@@ -138,6 +138,59 @@ __device__ inline void epi_store1(const EpiParams& p, int m, int n, float acc) {
     }
 }
 
+// erf for the bf16 path: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution); the f32
+// parity path keeps erff().
+__device__ inline float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+// Vectorised epilogue of the tile GEMMs: 4 consecutive output columns n..n+3 (n % 4 == 0, all < N) of row m.
+template <typename T> struct Pack4;
+template <> struct Pack4<bf16_t> {
+    __device__ static inline void st(bf16_t* p, float a, float b, float c, float d) {
+        ushort4 o; o.x = f32_to_bf16(a); o.y = f32_to_bf16(b); o.z = f32_to_bf16(c); o.w = f32_to_bf16(d);
+        *(ushort4*)p = o;
+    }
+    __device__ static inline float gelu(float x) { return gelu_fast(x); }
+};
+template <> struct Pack4<float> {
+    __device__ static inline void st(float* p, float a, float b, float c, float d) { *(float4*)p = make_float4(a, b, c, d); }
+    __device__ static inline float gelu(float x) { return gelu_erf(x); }
+};
+
+template <typename T, int MODE>
+__device__ inline void epi_store4(const EpiParams& p, int m, int n, float a0, float a1, float a2, float a3) {
+    if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + n);
+        a0 += b.x; a1 += b.y; a2 += b.z; a3 += b.w;
+    }
+    if (MODE == EPI_STORE) {
+        Pack4<T>::st((T*)p.out + (size_t)m * p.ldo + n, a0, a1, a2, a3);
+    } else if (MODE == EPI_GELU) {
+        Pack4<T>::st((T*)p.out + (size_t)m * p.ldo + n, Pack4<T>::gelu(a0), Pack4<T>::gelu(a1), Pack4<T>::gelu(a2), Pack4<T>::gelu(a3));
+    } else if (MODE == EPI_RESID_F32) {
+        const size_t o = (size_t)m * p.ldo + n;
+        const float4 r = *(const float4*)(p.resid + o);
+        *(float4*)(p.outf + o) = make_float4(r.x + a0, r.y + a1, r.z + a2, r.w + a3);
+    } else if (MODE == EPI_GELU_POS_F32) {
+        const float4 ps = *(const float4*)(p.pos + (size_t)(m % p.T) * p.ldo + n);
+        *(float4*)(p.outf + (size_t)m * p.ldo + n) =
+            make_float4(Pack4<T>::gelu(a0) + ps.x, Pack4<T>::gelu(a1) + ps.y, Pack4<T>::gelu(a2) + ps.z, Pack4<T>::gelu(a3) + ps.w);
+    } else if (MODE == EPI_HEADS) {
+        const int which = n / p.d_model, r = n - which * p.d_model;
+        const int h = r >> 6, dd = r & 63;
+        const int b = m / p.T, s = m - b * p.T;
+        T* base = (T*)(which == 0 ? p.out : (which == 1 ? p.out1 : p.out2));
+        Pack4<T>::st(base + (((size_t)b * p.H + h) * p.S_pad + s) * 64 + dd, a0, a1, a2, a3);
+    } else if (MODE == EPI_STORE_F32) {
+        *(float4*)(p.outf + (size_t)m * p.ldo + n) = make_float4(a0, a1, a2, a3);
+    }
+}
+
 // Host-side error plumbing -----------------------------------------------------------------------
 #define CW_OK 0
 #define CW_ERR_INVALID (-22)

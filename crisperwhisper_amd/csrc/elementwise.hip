@@ -111,7 +111,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
     __shared__ int s_i[64];
     __shared__ int s_tok;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    const float* lg = p.logits + (size_t)b * p.V;
+    const float* lg = p.logits + (size_t)b * p.ldv;
     int* ids = p.ids + (size_t)b * p.ids_stride;
     const int n_prompt = p.cfg[0], min_new_tokens = p.cfg[1], max_length = p.cfg[2], use_forced = p.cfg[3];
     const int t = p.pos[b] + 1, tb = p.timestamp_begin;
@@ -138,11 +138,42 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
         return dead ? -INFINITY : lg[v];
     };
 
-    // pass 1: best text token, best timestamp token
+    // pass 1: best text token, best timestamp token -- 4 logits + 4 mask bytes per load, all loads of the
+    // thread issued before use (rows are 16-byte aligned: ldv % 4 == 0)
     ArgPair bt = {-INFINITY, 0x7fffffff}, bs = {-INFINITY, 0x7fffffff};
-    for (int v = tid; v < p.V; v += blockDim.x) {
-        ArgPair c = {score(v), v};
-        if (v < tb) bt = arg_better(bt, c); else bs = arg_better(bs, c);
+    {
+        const float4* lg4 = (const float4*)lg;
+        const uchar4* mk4 = (const uchar4*)p.mask;
+        const int n4 = p.ldv >> 2;
+        for (int v4 = tid; v4 < n4; v4 += 4 * (int)blockDim.x) {
+            float4 x[4]; uchar4 mk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i4 = min(v4 + u * (int)blockDim.x, n4 - 1);
+                x[u] = lg4[i4]; mk[u] = mk4[i4];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i4 = v4 + u * (int)blockDim.x;
+                if (i4 < n4) {
+                    const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                    const unsigned char ms[4] = {mk[u].x, mk[u].y, mk[u].z, mk[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int v = i4 * 4 + j;
+                        if (v < p.V) {
+                            bool dead = (ms[j] & 1) || (at_begin && (ms[j] & 2));
+                            dead |= (v == p.eos && n_gen < min_new_tokens);
+                            if (last_ts) dead |= penult_ts ? (v >= tb) : (v < p.eos);
+                            dead |= (v >= tb && v < ts_floor);
+                            if (at_begin) dead |= (v < tb) || (v > ts_cap);
+                            ArgPair c = {dead ? -INFINITY : xs[j], v};
+                            if (v < tb) bt = arg_better(bt, c); else bs = arg_better(bs, c);
+                        }
+                    }
+                }
+            }
+        }
     }
     bt = wave_argmax(bt);
     bs = wave_argmax(bs);

@@ -32,7 +32,7 @@ struct cw_ctx {
     cw_model_desc d;
     bool bf16 = false;
     int device = 0;
-    int Bm = 0, S_pad = 0;
+    int Bm = 0, S_pad = 0, Vpad = 0;
     size_t esz = 4;
     hipStream_t st = nullptr;
     std::vector<void*> allocs;
@@ -307,13 +307,14 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->dx, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dxn, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->dq, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dattn, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->dmid, (size_t)Bm * F * 4));
-    CWCHK(c, dmalloc(c, &c->dlogits, (size_t)Bm * V * 4));
+    c->Vpad = (V + 3) & ~3;
+    CWCHK(c, dmalloc(c, &c->dlogits, (size_t)Bm * c->Vpad * 4));
     CWCHK(c, dmalloc(c, &c->d_ids, (size_t)Bm * TGT * 4)); CWCHK(c, dmalloc(c, &c->d_forced, (size_t)Bm * TGT * 4));
     CWCHK(c, dmalloc(c, &c->d_argmax, (size_t)Bm * TGT * 4));
     CWCHK(c, dmalloc(c, &c->d_last_ts, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_finished, Bm * 4));
     CWCHK(c, dmalloc(c, &c->d_nunf, 4));
     CWCHK(c, dmalloc(c, &c->d_pos, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_cfg, 4 * 4));
-    CWCHK(c, dmalloc(c, &c->d_mask, (size_t)V));
+    CWCHK(c, dmalloc(c, &c->d_mask, (size_t)V + 16));
     CWCHK(c, dmalloc(c, &c->d_align_slot, (size_t)d.dec_layers * H * 4));
     {
         std::vector<int> slot((size_t)d.dec_layers * H, -1);
@@ -664,7 +665,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         }
     }
     if (want_logits) {   // final LN + tied proj_out (:790, :1080), logits in f32 (utils.py:2894)
-        EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = V;
+        EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = c->Vpad;
         CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep));
     }
     return CW_OK;
@@ -673,7 +674,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
 static int launch_sample(cw_ctx* c, int nb, bool forced) {
     SampleParams sp;
     memset(&sp, 0, sizeof(sp));
-    sp.logits = c->dlogits; sp.V = c->d.vocab_size; sp.B = nb; sp.mask = c->d_mask;
+    sp.logits = c->dlogits; sp.V = c->d.vocab_size; sp.ldv = c->Vpad; sp.B = nb; sp.mask = c->d_mask;
     sp.eos = c->gen.eos_token_id; sp.pad = c->gen.pad_token_id;
     sp.timestamp_begin = c->gen.no_timestamps_token_id + 1;
     sp.max_initial_timestamp_index = c->gen.max_initial_timestamp_index;
@@ -748,7 +749,7 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
         // forward at position t-1, logits, fused processors + argmax -> ids[t], x for position t, pos := t
         CWCHK(c, run_step(c, nb));
         if (c->logits_capture && step < c->logits_capture_steps)
-            HIPCHK(c, hipMemcpyAsync(c->logits_capture + (size_t)step * nb * V, c->dlogits, (size_t)nb * V * 4, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipMemcpy2DAsync(c->logits_capture + (size_t)step * nb * V, (size_t)V * 4, c->dlogits, (size_t)c->Vpad * 4, (size_t)V * 4, nb, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipMemcpyAsync(c->h_nunf, c->d_nunf, 4, hipMemcpyDeviceToHost, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
         ++step;
@@ -775,7 +776,7 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
 
 int32_t cw_get_logits(cw_ctx* c, float* out, int32_t nb) {
     HIPCHK(c, hipStreamSynchronize(c->st));
-    HIPCHK(c, hipMemcpy(out, c->dlogits, (size_t)nb * c->d.vocab_size * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy2D(out, (size_t)c->d.vocab_size * 4, c->dlogits, (size_t)c->Vpad * 4, (size_t)c->d.vocab_size * 4, nb, hipMemcpyDeviceToHost));
     return CW_OK;
 }
 
@@ -1041,7 +1042,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
                 return cw_launch_attn_decode(c->bf16, p, c->st);
             }
             case 7: {   // logits
-                EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = V;
+                EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = c->Vpad;
                 return gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep);
             }
             case 8:     // near-empty kernel: launch/boundary floor

@@ -14,6 +14,7 @@
 //   gemv_f32_kernel    f32 parity flavour of the same.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -124,9 +125,109 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(AParams ap, const bf16_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int n = n0 + wn * 64 + j * 16 + g * 4;
+            if (n + 3 < N && (EPI == EPI_HEADS || (ep.ldo & 3) == 0)) {
+                epi_store4<bf16_t, EPI>(ep, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < N) epi_store1<bf16_t, EPI>(ep, m, n + r, acc[i][j][r]);
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) epi_store1<bf16_t, EPI>(ep, m, n + r, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA flavour of the tile GEMM: same 128x128x64 tiling and MFMA mapping, but the operand tiles go
+// HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass), double
+// buffered (2 x 32 KB).  The DMA destination is lane-linear (wave base + lane*16), so the bank-conflict
+// fix is an XOR swizzle applied to the *source* address and mirrored on the fragment reads: 16-byte
+// chunk c of row r lives at chunk position c ^ (r & 7).  Zero rows (M/N edges, conv padding, seek-window
+// tail) are sourced from a zero page.
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(AParams ap, const bf16_t* __restrict__ W, int M, int N,
+                                                             int K, EpiParams ep, int tiles_n,
+                                                             const bf16_t* __restrict__ zero_page) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];   // [2][A 16 KB | W 16 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    // this lane stages rows r = ch*8 + (lane >> 3) of chunk ch = wave*4 + q, source chunk (lane & 7) ^ (r & 7)
+    const int lrow = lane >> 3;
+    const int csrc = ((lane & 7) ^ lrow) * 8;                       // r & 7 == lrow (ch*8 is a multiple of 8)
+    auto stage = [&](int k0, int buf) {
+        unsigned char* base = gsm + buf * 32768;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = wave * 4 + q;
+            const int r = ch * 8 + lrow;
+            const bf16_t* pa = a_row_ptr<bf16_t>(ap, m0 + r, M, k0);
+            glds16(pa ? (const void*)(pa + csrc) : (const void*)zero_page, base + ch * 1024);
+            const int n = n0 + r;
+            glds16(n < N ? (const void*)(W + (size_t)n * K + k0 + csrc) : (const void*)zero_page, base + 16384 + ch * 1024);
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage((kt + 1) * BK, cur ^ 1);
+        const unsigned char* sA = gsm + cur * 32768;
+        const unsigned char* sW = sA + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[4], fw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wm * 64 + i * 16 + l15;
+                fa[i] = *(const bf16x8_t*)(sA + r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wn * 64 + j * 16 + l15;
+                fw[j] = *(const bf16x8_t*)(sW + r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[j], fa[i], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (this wave's DMAs) ...
+        __syncthreads();                                   // ... and everybody's; everyone done reading `cur`
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + wm * 64 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + wn * 64 + j * 16 + g * 4;
+            if (n + 3 < N && (EPI == EPI_HEADS || (ep.ldo & 3) == 0)) {
+                epi_store4<bf16_t, EPI>(ep, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) epi_store1<bf16_t, EPI>(ep, m, n + r, acc[i][j][r]);
+            }
         }
     }
 }
@@ -510,11 +611,23 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // Host launchers
 // ---------------------------------------------------------------------------------------------------
+static const bf16_t* g_zero_page = nullptr;   // 256 B of zeros: DMA source for padded rows
+static bool g_use_glds = true;
+
 template <int EPI>
 static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
                             hipStream_t st) {
     if (bf16) {
         int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+        if (!g_zero_page) {
+            void* z = nullptr;
+            if (hipMalloc(&z, 256) == hipSuccess) { hipMemset(z, 0, 256); g_zero_page = (const bf16_t*)z; }
+            if (getenv("CW_NO_GLDS")) g_use_glds = false;
+        }
+        if (g_use_glds && g_zero_page)
+            hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI>), dim3(tm * tn), dim3(256), 65536, st, ap, (const bf16_t*)W, M,
+                               N, K, ep, tn, g_zero_page);
+        else
         hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(tm * tn), dim3(256), 0, st, ap, (const bf16_t*)W, M, N, K, ep,
                            tn);
     } else {

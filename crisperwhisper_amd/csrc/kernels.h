@@ -25,8 +25,8 @@ int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, floa
                             hipStream_t st);
 
 struct SampleParams {
-    const float* logits;       // [B][V]
-    int V, B;
+    const float* logits;       // [B][ldv], rows 16-byte aligned
+    int V, B, ldv;
     const unsigned char* mask; // [V] bit0 always suppressed, bit1 suppressed at begin
     int eos, pad, timestamp_begin, max_initial_timestamp_index;  // max_initial < 0: none
     const int* cfg;            // device [4]: n_prompt (begin index), min_new_tokens, max_length, use_forced
