@@ -124,3 +124,51 @@ def test_pipeline_bf16_runs_and_is_well_formed(tiny):
     for a, b in zip(adj["chunks"][:-1], adj["chunks"][1:]):
         assert np.isfinite(a["timestamp"]).all() and np.isfinite(b["timestamp"]).all()
     pipe.engine.close()
+
+
+def test_large_geometry_layers_bf16_vs_oracle():
+    """BASELINE-size shapes (d=1280, 20 heads, ffn 5120, vocab 51866, 15 alignment heads) on a 2+2-layer
+    stack: exercises every large-shape kernel path of the bf16 engine (LDS-DMA GEMM tiles with M/N edges,
+    K-split atomic GEMVs, 4-way split cross-attention + combine, 51866-wide logits + sampler) against the
+    f32 oracle, teacher-forced.  Tolerances: bf16 weights/activations vs f32 reference."""
+    g, v = syn.large_v3_geometry()
+    g.enc_layers = g.dec_layers = 2
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19)]
+    W = syn.random_weights(g, seed=3)
+    x = syn.synth_audio(11, 480000, "mixed")
+    feats = OM.log_mel(x[None], g.n_mels)
+    orc = WhisperOracle(W, g)
+    enc_ref = orc.encode(feats)
+    eng = Engine(spec, dtype="bf16", max_batch=2)
+    eng.load_state_dict(W)
+    try:
+        f2, _ = eng.mel([x, x[:200000]], return_features=True)
+        assert np.abs(f2[0] - feats[0]).max() < 1e-4
+        eng.encode([0, 1], [0, 0], [3000, 1250])
+        enc = eng.encoder_output(2)
+        scale = np.abs(enc_ref).max()
+        assert np.abs(enc[0] - enc_ref[0]).max() < 0.06 * scale, np.abs(enc[0] - enc_ref[0]).max() / scale
+        # teacher-forced decode of 10 tokens on item 0 (batch row 1 rides along)
+        T = 13
+        rng = np.random.default_rng(0)
+        ids = np.concatenate([[v.sot, v.lang_id("en"), v.transcribe], [v.timestamp_begin], rng.integers(300, 50000, T - 5), [v.timestamp_begin + 40]])[None]
+        cache = orc.new_cache(enc_ref)
+        ref_logits, ref_cross = orc.decode(ids, cache, want_heads=[list(h) for h in spec.alignment_heads], all_logits=True)
+        cap = eng.capture_logits(2, T)
+        forced = np.full((2, T), -1, np.int32); forced[:, 3:] = ids[0, 3:]
+        seqs, lens, amax = eng.decode(np.tile(ids[:, :3], (2, 1)), max_length=T, forced=forced, want_argmax=True)
+        eng.stop_capture()
+        got, want = cap[:T - 3, 0], ref_logits[0, 2:T - 1]
+        rel = np.abs(got - want).max() / np.abs(want).max()
+        assert rel < 0.08, rel
+        # the graph path (no capture) must give the same argmax trace as the eager path
+        seqs2, lens2, amax2 = eng.decode(np.tile(ids[:, :3], (2, 1)), max_length=T, forced=forced, want_argmax=True)
+        assert np.array_equal(amax[:, 3:T], amax2[:, 3:T])
+        al = eng.alignment(1, T - 1)
+        assert np.abs(al[0] - ref_cross[0][:, :T - 1]).max() < 3e-2
+        assert np.abs(al[0].sum(-1) - 1).max() < 2e-3
+        ts = eng.token_timestamps(2, T - 1, 3, [3000, 1250])
+        assert np.isfinite(ts).all() and (ts[:, 3:] >= 0).all() and (ts[0] <= 30.0).all() and (ts[1] <= 12.5 + 1e-6).all()
+    finally:
+        eng.close()
