@@ -164,6 +164,19 @@ def main():
         ms, by = eng.time_kernel(which, B, a.kernel_iters)
         roof[which] = {"kernel": kname, "avg_ms": ms, "algo_bytes": by, "achieved": by / (ms * 1e-3) / 1e9}
 
+    def pmc_traffic(kernel_substr):
+        """HBM bytes per launch of the kernel from the committed rocprofv3 PMC pass (profiles/, same batch)."""
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_B8.json")))
+            if t.get("batch") != B:
+                return None
+            for k, val in t["kernels"].items():
+                if kernel_substr in k:
+                    return val["hbm_read_bytes_per_launch"]
+        except Exception:
+            pass
+        return None
+
     if rank == 0:
         total_audio = audio_s * world * a.steps
         dec_ms = stages["decode"][0]
@@ -182,7 +195,8 @@ def main():
                        "weight_load_s": round(t_load, 1)},
             "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1), 3) for k, val in stages.items()},
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
-                         "frac": r["achieved"] / 8000.0, "traffic": None, "kernel": r["kernel"],
+                         "frac": r["achieved"] / 8000.0,
+                         "traffic": pmc_traffic("attn_cross_split" if dom == 1 else "gemv2_bf16_kernelILi7"), "kernel": r["kernel"],
                          "avg_launch_ms": r["avg_ms"], "algorithmic_bytes_per_launch": r["algo_bytes"]},
             "roofline_other": [{"kernel": roof[k]["kernel"], "achieved_GBps": roof[k]["achieved"],
                                 "avg_launch_ms": roof[k]["avg_ms"], "algorithmic_bytes_per_launch": roof[k]["algo_bytes"]}

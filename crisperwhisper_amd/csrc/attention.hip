@@ -37,12 +37,22 @@ __global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
+    // 1-D grid, XCD-aware: the q-blocks of one (batch, head) are consecutive logical ids and therefore share
+    // an XCD's L2 for their K/V re-reads (round-robin placement re-fetched K/V once per XCD: 5.7x over-fetch).
+    const int nqb = (S + 127) / 128;
+    int lid;
+    {
+        const int nwg = gridDim.x, nx = 8, xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+        const int q = nwg / nx, r = nwg % nx;
+        lid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bh = lid / nqb, qblk = lid - bh * nqb;
+    const int b = bh / H, h = bh - b * H;
     const size_t head_off = ((size_t)b * H + h) * S_pad * 64;
     const bf16_t* Qh = Q + head_off;
     const bf16_t* Kh = K + head_off;
     const bf16_t* Vh = V + head_off;
-    const int qbase = blockIdx.x * 128 + wave * 32;
+    const int qbase = qblk * 128 + wave * 32;
 
     // Q fragments (B operand of S^T = K Q^T): lane supplies Q[q = l15][d = kk*32 + g*8 .. +7]
     bf16x8_t fq[2][2];
@@ -219,7 +229,7 @@ int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* 
                            int S_pad, hipStream_t st) {
     if (bf16) {
         if (S_pad % KT != 0 || S_pad < S) return CW_ERR_INVALID;
-        hipLaunchKernelGGL(attn_encoder_bf16_kernel, dim3((S + 127) / 128, H, B), dim3(256), 0, st, (const bf16_t*)Q,
+        hipLaunchKernelGGL(attn_encoder_bf16_kernel, dim3(((S + 127) / 128) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
                            (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
     } else {
         hipLaunchKernelGGL(attn_encoder_f32_kernel, dim3((S + 3) / 4, H, B), dim3(256), (size_t)4 * S * sizeof(float),

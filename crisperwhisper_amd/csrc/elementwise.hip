@@ -13,6 +13,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * d;
+    T* o = out + (size_t)row * d;
+    if (d <= 2048) {   // row cached in registers: one HBM read (the 3-pass form measured 2.2x fetch)
+        float4 v[8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = (lane + 64 * c) * 4;
+            v[c] = (k < d) ? *(const float4*)(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if ((lane + 64 * c) * 4 < d) {
+                float a = v[c].x - mean, bb = v[c].y - mean, cc = v[c].z - mean, e = v[c].w - mean;
+                q += (a * a + bb * bb) + (cc * cc + e * e);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = (lane + 64 * c) * 4;
+            if (k < d) {
+                const float4 gg = *(const float4*)(g + k), bb = *(const float4*)(b + k);
+                Pack4<T>::st(o + k, (v[c].x - mean) * rstd * gg.x + bb.x, (v[c].y - mean) * rstd * gg.y + bb.y,
+                             (v[c].z - mean) * rstd * gg.z + bb.z, (v[c].w - mean) * rstd * gg.w + bb.w);
+            }
+        }
+        return;
+    }
     float s = 0.f;
     for (int k = lane * 4; k < d; k += 256) {
         float4 v = *(const float4*)(xr + k);
@@ -26,14 +57,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         q += (a * a + bb * bb) + (c * c + e * e);
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
-    T* o = out + (size_t)row * d;
     for (int k = lane * 4; k < d; k += 256) {
         float4 v = *(const float4*)(xr + k);
         float4 gg = *(const float4*)(g + k), bb = *(const float4*)(b + k);
-        Act<T>::st(o + k + 0, (v.x - mean) * rstd * gg.x + bb.x);
-        Act<T>::st(o + k + 1, (v.y - mean) * rstd * gg.y + bb.y);
-        Act<T>::st(o + k + 2, (v.z - mean) * rstd * gg.z + bb.z);
-        Act<T>::st(o + k + 3, (v.w - mean) * rstd * gg.w + bb.w);
+        Pack4<T>::st(o + k, (v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y,
+                     (v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
     }
 }
 
