@@ -638,7 +638,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
             CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, L.lnc_b, ep));
         }
-        if (c->bf16 && nb <= 16) {
+        if (c->bf16) {
             // keys split over ATT_NS blocks per (row, head); the out-projection GEMV combines the partials
             CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml,
                                c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_ml, c->d_align_slot + (size_t)l * H,
@@ -769,7 +769,7 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
     }
     if (argmax_out) HIPCHK(c, hipMemcpy(argmax_out, c->d_argmax, (size_t)nb * TGT * 4, hipMemcpyDeviceToHost));
     c->last_L = t - 1;   // attention rows retained: one per decoder input position
-    c->align_unnormalized = c->bf16 && nb <= 16 && c->d.n_align > 0;
+    c->align_unnormalized = c->bf16 && c->d.n_align > 0;
     c->last_nb = nb;
     return CW_OK;
 }
@@ -1012,7 +1012,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
                 return gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep);
             }
             case 1: {   // cross-attention
-                if (c->bf16 && nb <= 16) {
+                if (c->bf16) {
                     CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml, nullptr, c->d_align_ml, nullptr,
                                        c->d_pos, 0, 0, nb, H};
                     return cw_launch_attn_cross_split(true, p, c->st);

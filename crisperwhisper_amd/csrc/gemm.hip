@@ -439,8 +439,9 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
                                                          const bf16_t* __restrict__ W, int N,
                                                          const float* __restrict__ ln_g,
                                                          const float* __restrict__ ln_b, EpiParams ep,
-                                                         CombineParams cb) {
+                                                         CombineParams cb, int m_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    x += (size_t)m_base * K;                                  // this launch handles batch rows m_base .. m_base+Mb-1
     const int xs_stride = Kb + 8;
     bf16_t* xs = (bf16_t*)smem2;                              // [16][Kb+8]
     float* red = (float*)(smem2 + (size_t)16 * xs_stride * 2); // [4 waves][4][64]
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
                 xv[i][c] = *(const float4*)(x + off);
             } else {   // x = sum_s w_s o_s over the ATT_NS attention partials of head (k / 64)
                 const int head = (kbase + v4 * 4) >> 6;
-                const float* ml = cb.part_ml + ((size_t)row * cb.H + head) * ATT_NS * 2;
+                const float* ml = cb.part_ml + ((size_t)(m_base + row) * cb.H + head) * ATT_NS * 2;
                 float m[ATT_NS], l[ATT_NS];
                 float4 o[ATT_NS];
 #pragma unroll
@@ -591,11 +592,11 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
         const int m = g * 4 + r;
         if (m < Mb && n < N) {
             if (ATOMIC) {
-                atomicAdd(ep.outf + (size_t)m * ep.ldo + n, v + (blockIdx.y == 0 ? bias_v : 0.f));
+                atomicAdd(ep.outf + (size_t)(m_base + m) * ep.ldo + n, v + (blockIdx.y == 0 ? bias_v : 0.f));
             } else {
                 EpiParams e2 = ep;
                 e2.bias = nullptr;                       // bias was prefetched at kernel entry
-                epi_store1<bf16_t, EPI>(e2, m, n, v + bias_v);
+                epi_store1<bf16_t, EPI>(e2, m_base + m, n, v + bias_v);
             }
         }
     }
@@ -681,26 +682,26 @@ int cw_gemv_kc(int Mb, int K) {
 template <int EPI, int RPW, int NSLOT, int PER_LANE>
 static void launch_gemv2_shape(dim3 grid, size_t lds, int ksplit, const float* x, int Mb, int K, int Kb, const void* W,
                                int N, const float* ln_g, const float* ln_b, const EpiParams& ep, hipStream_t st,
-                               const CombineParams& cb) {
+                               const CombineParams& cb, int m_base) {
     if (EPI == EPI_RESID_F32 && cb.part_ml) {
         if (ksplit > 1)
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, true, NSLOT, PER_LANE>), grid, dim3(256), lds, st,
-                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
         else
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, false, true, NSLOT, PER_LANE>), grid, dim3(256), lds, st,
-                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
     } else if (EPI == EPI_RESID_F32 && ksplit > 1) {
         hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x,
-                           Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+                           Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
     } else {
         hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x, Mb, K,
-                           Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb);
+                           Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
     }
 }
 
 template <int EPI, int RPW>
 static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b,
-                         const EpiParams& ep, hipStream_t st, const CombineParams* comb) {
+                         const EpiParams& ep, hipStream_t st, const CombineParams* comb, int m_base) {
     CombineParams cb{nullptr, 0, 0};
     if (comb) cb = *comb;
     // K split: only for the in-place residual epilogue (f32 atomics into the residual stream), sized so that
@@ -714,13 +715,13 @@ static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, co
     const int Kb = K / ksplit;
     const size_t lds = (size_t)16 * (Kb + 8) * 2 + 4 * 4 * 64 * 4;
     dim3 grid((N + 15) / 16, ksplit);
-    if (Kb <= 256) launch_gemv2_shape<EPI, RPW, 1, 1>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb);
-    else if (Kb <= 768) launch_gemv2_shape<EPI, RPW, 2, 3>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb);
-    else launch_gemv2_shape<EPI, RPW, 3, 5>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb);
+    if (Kb <= 256) launch_gemv2_shape<EPI, RPW, 1, 1>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base);
+    else if (Kb <= 768) launch_gemv2_shape<EPI, RPW, 2, 3>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base);
+    else launch_gemv2_shape<EPI, RPW, 3, 5>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base);
 }
 
 static bool gemv2_ok(int epi, int Mb, int K, const float* ln_g, const EpiParams& ep) {
-    if (Mb > 16 || K % 128 != 0) return false;
+    if (Mb > GV_MAXM || K % 128 != 0) return false;
     if (K <= 1280) return true;
     // larger K needs the K split, i.e. the in-place residual epilogue without LayerNorm
     if (epi != EPI_RESID_F32 || ln_g || ep.outf != ep.resid) return false;
@@ -735,8 +736,13 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
     if (comb && !(bf16 && gemv2_ok(EPI, Mb, K, ln_g, ep) && EPI == EPI_RESID_F32)) return CW_ERR_INVALID;
     if (bf16) {
         if (gemv2_ok(EPI, Mb, K, ln_g, ep)) {
-            if (Mb <= 8) launch_gemv2<EPI, 2>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
-            else launch_gemv2<EPI, 4>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
+            // batches beyond one MFMA tile (16 rows) run as row groups: the weights of the 2nd.. group come from
+            // L2 / Infinity Cache (the layer's weights were just streamed by the first group)
+            for (int m_base = 0; m_base < Mb; m_base += 16) {
+                const int rows = Mb - m_base < 16 ? Mb - m_base : 16;
+                if (rows <= 8) launch_gemv2<EPI, 2>(x, rows, K, W, N, ln_g, ln_b, ep, st, comb, m_base);
+                else launch_gemv2<EPI, 4>(x, rows, K, W, N, ln_g, ln_b, ep, st, comb, m_base);
+            }
             return CW_OK;
         }
         int kc = cw_gemv_kc(Mb, K);
