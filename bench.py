@@ -118,19 +118,25 @@ def main():
         eng.mel_resident(B)
         out = generation.generate(eng, B, nf, language="<|en|>", task="transcribe", max_new_tokens=a.tokens,
                                   min_new_tokens=a.tokens)
+        # every chunk is an independent clip here, so each rank collates + pause-splits its own chunks and the
+        # ranks exchange the per-chunk *word lists* (one small all-gather); rank 0 ends up with all results
         recs = []
+        n_tokens = 0
         for k in range(B):
             n = len(out["token_timestamps"][k])
-            recs.append(dist.pack_record(rank * B + k, out["sequences"][k][:n], out["token_timestamps"][k], (30.0, 0.0, 0.0)))
+            n_tokens += n
+            text, words = collate.decode_asr(vocab, [{"tokens": out["sequences"][k][:n],
+                                                      "token_timestamps": out["token_timestamps"][k],
+                                                      "stride": (30.0, 0.0, 0.0)}])
+            res = utils.adjust_pauses_for_hf_pipeline_output({"text": text, "chunks": words})
+            recs.append(dist.pack_words(rank * B + k, res["chunks"]))
         allr = shard.all_gather_records(np.stack(recs), B)
-        n_words = n_tokens = 0
-        if rank == 0:                                 # rank-0 merge: every chunk is an independent clip here
+        n_words = 0
+        if rank == 0:
             for r in allr:
-                _, toks, ts, stride = dist.unpack_record(r)
-                text, words = collate.decode_asr(vocab, [{"tokens": toks, "token_timestamps": ts, "stride": stride}])
-                res = utils.adjust_pauses_for_hf_pipeline_output({"text": text, "chunks": words})
-                n_words += len(res["chunks"])
-                n_tokens += len(toks)
+                _, words = dist.unpack_words(r)
+                n_words += len(words)
+        n_tokens *= world                             # every rank decodes the same number of tokens per chunk
         return n_words, n_tokens
 
     def fence():

@@ -83,6 +83,9 @@ struct cw_ctx {
     int *d_first_col = nullptr, *d_path_text = nullptr, *d_path_time = nullptr, *d_path_len = nullptr,
         *d_ncols = nullptr;
 
+    double* d_pause = nullptr;   // persistent scratch for cw_adjust_pauses: [4][pause_cap]
+    int pause_cap = 0;
+
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float stage_ms[CW_N_STAGES] = {};
@@ -912,17 +915,21 @@ int32_t cw_dtw(cw_ctx* c, const float* mat, int32_t N, int32_t M, int32_t* text_
 
 int32_t cw_adjust_pauses(cw_ctx* c, double* start, double* end, int32_t W, double thr) {
     if (W <= 0) return CW_OK;
-    double *ds = nullptr, *de = nullptr;
-    HIPCHK(c, hipMalloc((void**)&ds, (size_t)W * 16)); HIPCHK(c, hipMalloc((void**)&de, (size_t)W * 16));
-    HIPCHK(c, hipMemcpy(ds, start, (size_t)W * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(de, end, (size_t)W * 8, hipMemcpyHostToDevice));
-    int r = cw_launch_pauses(ds, de, W, thr, c->st);
-    hipError_t e = hipStreamSynchronize(c->st);
-    if (e == hipSuccess) e = hipMemcpy(start, ds + W, (size_t)W * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(end, de + W, (size_t)W * 8, hipMemcpyDeviceToHost);
-    hipFree(ds); hipFree(de);
-    if (e != hipSuccess) return fail(c, CW_ERR_HIP, "adjust_pauses: %s", hipGetErrorString(e));
-    return r;
+    if (W > c->pause_cap) {   // grow the persistent scratch (start/end in, start/end out)
+        int cap = 1024;
+        while (cap < W) cap *= 2;
+        CWCHK(c, dmalloc(c, &c->d_pause, (size_t)4 * cap * 8, false));
+        c->pause_cap = cap;
+    }
+    double* ds = c->d_pause;              // [in W | out W]
+    double* de = c->d_pause + 2 * (size_t)c->pause_cap;
+    HIPCHK(c, hipMemcpyAsync(ds, start, (size_t)W * 8, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(de, end, (size_t)W * 8, hipMemcpyHostToDevice, c->st));
+    CWCHK(c, cw_launch_pauses(ds, de, W, thr, c->st));
+    HIPCHK(c, hipMemcpyAsync(start, ds + W, (size_t)W * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(end, de + W, (size_t)W * 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return CW_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

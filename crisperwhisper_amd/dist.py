@@ -43,6 +43,37 @@ def unpack_record(rec: np.ndarray):
     return idx, tokens, ts, stride
 
 
+WORD_MAX = 448
+WORD_TEXT_BYTES = 4096
+WORD_REC = 3 + 4 * WORD_MAX + WORD_TEXT_BYTES // 4   # chunk_idx, n_words, n_text_bytes, (start,end) f64 bits, utf-8 text
+
+
+def pack_words(idx: int, words) -> np.ndarray:
+    """Per-chunk *word list* record (what the ranks exchange when chunks are independent clips):
+    words = [{"text", "timestamp": (start, end)}].  Texts are joined with a 0x00 separator."""
+    rec = np.zeros(WORD_REC, dtype=np.int32)
+    if len(words) > WORD_MAX:
+        raise ValueError("too many words in one chunk")
+    blob = b"\x00".join(w["text"].encode("utf-8") for w in words)
+    if len(blob) > WORD_TEXT_BYTES:
+        raise ValueError("word text exceeds record capacity")
+    rec[0], rec[1], rec[2] = idx, len(words), len(blob)
+    ts = np.asarray([w["timestamp"] for w in words], dtype=np.float64).reshape(-1)
+    rec[3:3 + 2 * len(ts)] = ts.view(np.int32)
+    buf = np.zeros(WORD_TEXT_BYTES, dtype=np.uint8)
+    buf[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+    rec[3 + 4 * WORD_MAX:] = buf.view(np.int32)
+    return rec
+
+
+def unpack_words(rec: np.ndarray):
+    idx, n, nb = int(rec[0]), int(rec[1]), int(rec[2])
+    ts = rec[3:3 + 4 * n].view(np.float64).reshape(n, 2)
+    blob = rec[3 + 4 * WORD_MAX:].view(np.uint8)[:nb].tobytes()
+    texts = blob.decode("utf-8").split("\x00") if n else []
+    return idx, [{"text": t, "timestamp": (float(a), float(b))} for t, (a, b) in zip(texts, ts)]
+
+
 class Shard:
     """rank/world + the gather primitive."""
 
@@ -50,11 +81,12 @@ class Shard:
         self.rank, self.world, self.device = rank, world, device
 
     def all_gather_records(self, recs: np.ndarray, max_per_rank: int) -> np.ndarray:
-        """recs [n_local, REC_WORDS] int32 -> [n_total, REC_WORDS] ordered by chunk index."""
+        """recs [n_local, W] int32 (W = REC_WORDS or WORD_REC) -> [n_total, W] ordered by chunk index."""
         if self.world == 1:
             return recs
         import torch
         import torch.distributed as dist
+        REC_WORDS = recs.shape[1]
         buf = np.full((max_per_rank, REC_WORDS), -1, dtype=np.int32)
         buf[:len(recs)] = recs
         t = torch.from_numpy(buf)

@@ -45,6 +45,9 @@ def test_shard_bounds_and_records():
     rec = dist.pack_record(7, np.array([1, 2, 300]), np.array([0.5, 1.25], np.float32), (30.0, 5.0, 0.0))
     idx, toks, ts, stride = dist.unpack_record(rec)
     assert idx == 7 and toks.tolist() == [1, 2, 300] and ts.tolist() == [0.5, 1.25] and stride == (30.0, 5.0, 0.0)
+    words = [{"text": " h\u00e9llo", "timestamp": (0.5, 1.29)}, {"text": "\ufffdx", "timestamp": (1.29, 2.0)}, {"text": " ", "timestamp": (2.0, 2.0)}]
+    assert dist.unpack_words(dist.pack_words(5, words)) == (5, words)
+    assert dist.unpack_words(dist.pack_words(6, [])) == (6, [])
 
 
 @pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask"])
