@@ -58,6 +58,13 @@ _SIGS = {
     "cw_align_matrix": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "cw_dtw": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "cw_adjust_pauses": (_I, [_P, _P, _P, _I, C.c_double]),
+    "cw_vocab_create": (_P, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "cw_vocab_destroy": (None, [_P]),
+    "cw_collate_begin": (_P, [_P, C.c_double]),
+    "cw_collate_feed": (_I, [_P, _P, _I, _P, _I, _I, C.c_double, C.c_double, C.c_double]),
+    "cw_collate_finish": (_I, [_P, _P, _P, _P, _P]),
+    "cw_collate_get": (_I, [_P, _P, _P, _P, _P, _P]),
+    "cw_collate_free": (None, [_P]),
     "cw_test_gemm": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "cw_test_gemv": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "cw_test_attention": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),

@@ -115,6 +115,28 @@ int32_t cw_dtw(cw_ctx* ctx, const float* mat, int32_t N, int32_t M, int32_t* tex
 /* ---- seam 4: adjust_pauses_for_hf_pipeline_output (REF/utils.py:1-29) on word start/end arrays, in place */
 int32_t cw_adjust_pauses(cw_ctx* ctx, double* start, double* end, int32_t W, double split_threshold);
 
+/* ---- seam 3: tokenizer._decode_asr(..., return_timestamps="word") (TF/models/whisper/tokenization_whisper.py
+ * :901-1406), host-only (no GPU): chunk-seam merge, word grouping, punctuation merge, 0.01 s rounding.
+ * Vocabulary: byte-level BPE table.  blob/offsets[n_tokens+1]: raw bytes of each text token; kind[i]: 0 text,
+ * 1 special (<|...|>), 2 other (timestamp tokens); lang_class[i] for specials: -1 not a language tag, 0 language
+ * written with spaces, 1 language without spaces (zh/ja/th/lo/my/yue: split on unicode points, :1299-1304).      */
+typedef struct cw_vocab cw_vocab;
+typedef struct cw_collator cw_collator;
+cw_vocab* cw_vocab_create(int32_t n_tokens, const uint8_t* blob, const int64_t* offsets, const int8_t* kind,
+                          const int8_t* lang_class, int32_t eos, int32_t timestamp_begin, int32_t startofprev,
+                          int32_t sot, int32_t default_lang_class);
+void cw_vocab_destroy(cw_vocab* v);
+cw_collator* cw_collate_begin(const cw_vocab* v, double time_precision);
+/* one pipeline output (chunk) in audio order: tokens [n_tokens], token_ts [n_ts] seconds, stride in seconds     */
+int32_t cw_collate_feed(cw_collator* c, const int64_t* tokens, int32_t n_tokens, const float* token_ts, int32_t n_ts,
+                        int32_t has_stride, double chunk_len, double stride_left, double stride_right);
+/* flushes leftovers; returns sizes: words, utf-8 bytes of the full text / of all word texts, warned = 1 when
+ * Whisper did not predict an ending timestamp (:1112-1116)                                                       */
+int32_t cw_collate_finish(cw_collator* c, int32_t* n_words, int64_t* text_bytes, int64_t* words_bytes, int32_t* warned);
+int32_t cw_collate_get(cw_collator* c, uint8_t* text, double* starts, double* ends, int64_t* word_offsets /* [n+1] */,
+                       uint8_t* words_blob);
+void cw_collate_free(cw_collator* c);
+
 /* ---- kernel-level hooks used by the parity tests (host f32 in/out, run in the context's dtype) -------- */
 int32_t cw_test_gemm(cw_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, const float* W,
                      const float* bias, int32_t gelu, float* out);

@@ -88,14 +88,15 @@ def test_collation_matches_oracle_on_random_token_streams():
     pv, ov = collate.Vocabulary.from_synthetic(v), Hh.oracle_vocab(v)
     rng = np.random.default_rng(11)
     tb = v.timestamp_begin
-    for trial in range(60):
+    for trial in range(300):
         outs = []
         n_chunks = int(rng.integers(1, 4))
         for c in range(n_chunks):
             toks, t = [], 0
             for _ in range(int(rng.integers(1, 5))):
                 t0 = t + int(rng.integers(0, 200)); t1 = t0 + int(rng.integers(1, 300)); t = min(t1, 1500)
-                body = rng.choice([32, 32, 46, 44, 39, 40, 65, 66, 97, 98, 99, 0xc3, 0xa9, 0xe2, 0x82, 0xac], size=int(rng.integers(1, 12))).tolist()
+                body = rng.choice([32, 32, 46, 44, 39, 40, 65, 66, 97, 98, 99, 0xc3, 0xa9, 0xe2, 0x82, 0xac, 0xed, 0xa0, 0x80, 0xf0,
+                                   0x90, 0xf4, 0x8f, 0xc0, 0xff, 0xe0, 0x9f, 0x85, 0x0b, 0x1f], size=int(rng.integers(1, 14))).tolist()
                 toks += [tb + min(t0, 1500)] + body + [tb + t]
                 if rng.random() < 0.3:
                     toks = toks[:-1]                       # unterminated segment
