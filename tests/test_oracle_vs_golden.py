@@ -81,3 +81,45 @@ def test_pipeline_word_for_word(name):
     assert out["text"] == meta["text"]
     ok, why = Hh.words_equal(out["chunks"], meta["chunks"], tol=0.0)
     assert ok, why
+
+
+def test_collation_matches_transformers_live_on_random_streams():
+    """Oracle (and the native product collation) vs the installed transformers `_decode_asr` on random
+    token/timestamp/stride streams, including ill-formed UTF-8 and seam overlaps.  Skipped if transformers is
+    not importable (the golden e2e fixtures pin the same code path through the pipeline)."""
+    pytest.importorskip("transformers")
+    import torch
+    from crisperwhisper_amd import collate
+    from oracle import collate as OC
+    from tests.golden import hf_synth as H
+    g, v = syn.tiny_geometry()
+    tok = H.build_tokenizer(v)
+    ov, pv = Hh.oracle_vocab(v), collate.Vocabulary.from_synthetic(v)
+    rng = np.random.default_rng(23)
+    tb = v.timestamp_begin
+    alphabet = [32, 32, 46, 44, 39, 40, 45, 34, 65, 66, 97, 98, 0xc3, 0xa9, 0xe2, 0x82, 0xac, 0xed, 0xa0, 0xf0, 0x9f, 0xff]
+    for trial in range(40):
+        outs = []
+        n_chunks = int(rng.integers(1, 4))
+        common = rng.choice(alphabet, size=6).tolist()
+        for c in range(n_chunks):
+            toks, t = [], 0
+            for _ in range(int(rng.integers(1, 4))):
+                t0 = t + int(rng.integers(0, 300)); t1 = t0 + int(rng.integers(1, 400)); t = min(t1, 1500)
+                body = rng.choice(alphabet, size=int(rng.integers(1, 10))).tolist()
+                if rng.random() < 0.5:
+                    body = common + body          # overlapping text across chunk seams
+                toks += [tb + min(t0, 1500)] + body + [tb + t]
+            ts = np.round(np.sort(rng.random(len(toks)) * 30), 2).astype(np.float32)
+            sl = 0.0 if c == 0 else 5.0
+            sr = 0.0 if c == n_chunks - 1 else 5.0
+            outs.append({"tokens": np.array(toks), "token_timestamps": ts, "stride": (30.0, sl, sr)})
+        hf_in = [{"tokens": torch.tensor(o["tokens"])[None], "token_timestamps": torch.tensor(o["token_timestamps"])[None],
+                  "stride": o["stride"]} for o in outs]
+        text, opt = tok._decode_asr(hf_in, return_timestamps="word", return_language=None, time_precision=0.02)
+        a = OC.decode_asr(ov, [dict(o) for o in outs])
+        b = collate.decode_asr(pv, [dict(o) for o in outs])
+        for got in (a, b):
+            assert got[0] == text, trial
+            ok, why = Hh.words_equal(got[1], opt["chunks"])
+            assert ok, (trial, why)
