@@ -88,6 +88,7 @@ struct cw_ctx {
 
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_step[2] = {nullptr, nullptr};
     float stage_ms[CW_N_STAGES] = {};
     int stage_calls[CW_N_STAGES] = {};
 };
@@ -197,7 +198,9 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipStreamCreate(&c->st));
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
-    HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 64, hipHostMallocDefault));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_step[0], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_step[1], hipEventDisableTiming));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
     c->bf16 = d.dtype == CW_DTYPE_BF16;
     if (getenv("CW_NO_GRAPH")) c->use_graph = false;
     c->esz = c->bf16 ? 2 : 4;
@@ -375,6 +378,7 @@ void cw_destroy(cw_ctx* c) {
     if (c->h_nunf) hipHostFree(c->h_nunf);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    for (auto& e : c->ev_step) if (e) hipEventDestroy(e);
     if (c->st) hipStreamDestroy(c->st);
     delete c;
 }
@@ -748,17 +752,35 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
     CWCHK(c, cw_launch_set_pos(c->d_pos, n_prompt - 1, nb, c->st));
     CWCHK(c, cw_launch_embed(c->d_ids, TGT, n_prompt - 1, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
     int t = n_prompt, step = 0;
+    // Host/device overlap: the "rows still running" counter of step s lands in its own pinned slot and is only
+    // *read* after step s+1 has been queued (one step of lag, so the GPU never waits for the host; at most one
+    // harmless extra step runs: it only writes cache / alignment rows beyond the ones that are used), and it
+    // is not even copied while no row can finish yet (fewer than min_new_tokens generated: eos is masked).
+    int first_copied = -1;
     for (;;) {
         // forward at position t-1, logits, fused processors + argmax -> ids[t], x for position t, pos := t
         CWCHK(c, run_step(c, nb));
         if (c->logits_capture && step < c->logits_capture_steps)
             HIPCHK(c, hipMemcpy2DAsync(c->logits_capture + (size_t)step * nb * V, (size_t)V * 4, c->dlogits, (size_t)c->Vpad * 4, (size_t)V * 4, nb, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipMemcpyAsync(c->h_nunf, c->d_nunf, 4, hipMemcpyDeviceToHost, c->st));
-        HIPCHK(c, hipStreamSynchronize(c->st));
-        ++step;
         ++t;                               // sequence length is now t
-        if (*c->h_nunf == 0 || t >= max_length) break;
+        const bool can_finish = (t - n_prompt) >= min_new_tokens;
+        if (can_finish) {
+            if (first_copied < 0) first_copied = step;
+            c->h_nunf[step] = 1;
+            HIPCHK(c, hipMemcpyAsync(c->h_nunf + step, c->d_nunf, 4, hipMemcpyDeviceToHost, c->st));
+            HIPCHK(c, hipEventRecord(c->ev_step[step & 1], c->st));
+        }
+        ++step;
+        if (t >= max_length) break;
+        if (first_copied >= 0 && step - 2 >= first_copied) {   // counter of the step before the one just queued
+            HIPCHK(c, hipEventSynchronize(c->ev_step[(step - 2) & 1]));
+            if (c->h_nunf[step - 2] == 0) break;
+        }
     }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (first_copied >= 0)                 // true end = first step after which no row was running
+        for (int s2 = first_copied; s2 < step; ++s2)
+            if (c->h_nunf[s2] == 0) { t = n_prompt + s2 + 1; break; }
     KCHK(c);
     tm.stop();
     HIPCHK(c, hipMemcpy(ids.data(), c->d_ids, ids.size() * 4, hipMemcpyDeviceToHost));
