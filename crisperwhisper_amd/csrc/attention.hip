@@ -351,9 +351,9 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
 // Cross-attention decode, split over keys.  grid (H, B, ATT_NS), 512 threads.
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSplitParams p) {
+__global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSplitParams p) {
     __shared__ float sc[512];
-    __shared__ float red[DEC_GROUPS * 64];
+    __shared__ float red[(CROSS_THREADS / 8) * 64];
     __shared__ float scratch[64];
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
@@ -365,16 +365,16 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSpli
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
 
     float mx = -INFINITY;
-    for (int k0 = grp; k0 < nk; k0 += 4 * DEC_GROUPS) {
+    for (int k0 = grp; k0 < nk; k0 += 4 * (CROSS_THREADS / 8)) {
         float kv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {   // unconditional loads (clamped row): no exec-masked blocks, all in flight
-            const int k = min(k0 + u * DEC_GROUPS, nk - 1);
+            const int k = min(k0 + u * (CROSS_THREADS / 8), nk - 1);
             Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * DEC_GROUPS;
+            const int k = k0 + u * (CROSS_THREADS / 8);
             if (k < nk) {
                 float d = 0.f;
 #pragma unroll
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSpli
     }
     mx = block_max(mx, scratch);
     float sum = 0.f;
-    for (int k = tid; k < nk; k += DEC_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
+    for (int k = tid; k < nk; k += CROSS_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
     sum = block_sum(sum, scratch);
 
     const int slot = p.align_out ? p.align_slot[h] : -1;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSpli
         const int arow = p.pos[b];
         const size_t rowi = ((size_t)b * p.n_align + slot) * p.align_rows + arow;
         float* dst = p.align_out + rowi * p.n_keys + k_lo;
-        for (int k = tid; k < nk; k += DEC_THREADS) dst[k] = sc[k];
+        for (int k = tid; k < nk; k += CROSS_THREADS) dst[k] = sc[k];
         if (tid == 0) { p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = sum; }
     }
     if (tid == 0) {
@@ -404,16 +404,16 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSpli
     }
 
     float acc[8] = {};
-    for (int k0 = grp; k0 < nk; k0 += 4 * DEC_GROUPS) {
+    for (int k0 = grp; k0 < nk; k0 += 4 * (CROSS_THREADS / 8)) {
         float vv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = min(k0 + u * DEC_GROUPS, nk - 1);
+            const int k = min(k0 + u * (CROSS_THREADS / 8), nk - 1);
             Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * DEC_GROUPS;
+            const int k = k0 + u * (CROSS_THREADS / 8);
             if (k < nk) {
                 const float pk = sc[k];
 #pragma unroll
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSpli
     __syncthreads();
     if (tid < 64) {
         float r = 0.f;
-        for (int gI = 0; gI < DEC_GROUPS; ++gI) r += red[gI * 64 + tid];
+        for (int gI = 0; gI < (CROSS_THREADS / 8); ++gI) r += red[gI * 64 + tid];
         p.part_o[((size_t)sp * p.B + b) * p.H * 64 + h * 64 + tid] = r;
     }
 }
@@ -434,8 +434,8 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_cross_split_kernel(CrossSpli
 int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > 512) return CW_ERR_INVALID;
     dim3 grid(p.H, p.B, ATT_NS);
-    if (bf16) hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t>), grid, dim3(DEC_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((attn_cross_split_kernel<float>), grid, dim3(DEC_THREADS), 0, st, p);
+    if (bf16) hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t>), grid, dim3(CROSS_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((attn_cross_split_kernel<float>), grid, dim3(CROSS_THREADS), 0, st, p);
     return CW_OK;
 }
 

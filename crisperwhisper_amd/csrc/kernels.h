@@ -71,7 +71,12 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st);
 // Cross-attention decode split over the 1500 keys (flash-decoding): ATT_NS blocks per (batch, head) write
 // un-normalised partial outputs + (max, sum); the consumer GEMV combines them while loading its activations,
 // alignment rows are normalised once per generate call by cw_launch_align_normalize.
+#ifndef ATT_NS
 #define ATT_NS 4
+#endif
+#ifndef CROSS_THREADS
+#define CROSS_THREADS 512
+#endif
 struct CrossSplitParams {
     const float* q;        // [B][H*64]
     const void* K;         // [B][H][1500][64]

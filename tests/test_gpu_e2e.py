@@ -172,3 +172,42 @@ def test_large_geometry_layers_bf16_vs_oracle():
         assert np.isfinite(ts).all() and (ts[:, 3:] >= 0).all() and (ts[0] <= 30.0).all() and (ts[1] <= 12.5 + 1e-6).all()
     finally:
         eng.close()
+
+
+def test_reference_call_sequence_with_hf_objects_and_wav_path(tiny, tmp_path):
+    """Literally REF/transcribe.py:14-33 with `pipeline` swapped for ours: HF model + processor objects in,
+    a .wav path in, the reference's result dict out; then REF/README's adjust_pauses call."""
+    transformers = pytest.importorskip("transformers")
+    import torch
+    from scipy.io import wavfile
+    from tests.golden import hf_synth as H
+    g, v, W, spec = tiny
+    model = H.build_model(g, v, n_align=3)
+    sd = {k: torch.from_numpy(x) for k, x in W.items()}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    model.load_state_dict(sd, strict=True)
+    model.generation_config.alignment_heads = syn.alignment_heads(g, 3)
+    tok, fe = H.build_tokenizer(v), H.build_feature_extractor(g)
+    meta = Hh.gold_json("e2e_golden.json")["mixed70_b2_n40"]
+    x = syn.synth_audio(meta["seed"], meta["secs"] * 16000, meta["kind"])
+    path = str(tmp_path / "clip.wav")
+    wavfile.write(path, 16000, x)                                  # float32 WAV: lossless
+    pipe = cw.pipeline("automatic-speech-recognition", model=model, tokenizer=tok, feature_extractor=fe,
+                       chunk_length_s=30, batch_size=2, return_timestamps="word", torch_dtype=torch.float32,
+                       device="cuda:0")
+    out = pipe(path, generate_kwargs={**Hh.GEN_KW, **meta["extra"]})
+    assert out["text"] == meta["text"]
+    ok, why = Hh.words_equal(out["chunks"], meta["chunks"], tol=0.02)
+    assert ok, why
+    out2 = pipe({"array": x, "sampling_rate": 16000}, generate_kwargs={**Hh.GEN_KW, **meta["extra"]})
+    assert out2 == out
+    from oracle import pauses as OP
+    import copy
+    want = OP.adjust_pauses_for_hf_pipeline_output(copy.deepcopy(out))
+    got = cw.adjust_pauses_for_hf_pipeline_output(out)
+    assert got is out and got == want
+    with pytest.raises(ValueError):
+        pipe({"array": x})                                         # missing sampling_rate, like the reference
+    with pytest.raises(TypeError):
+        pipe(12345)
+    pipe.engine.close()

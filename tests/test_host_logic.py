@@ -119,3 +119,42 @@ def test_init_tokens_errors_mirror_reference():
         generation.init_tokens(spec, "<|xx|>", "transcribe")
     with pytest.raises(ValueError):
         generation.init_tokens(spec, "<|en|>", "summarize")
+
+
+def test_drop_in_objects_from_transformers():
+    """The boundary accepts the reference's own objects (REF/transcribe.py:14-31): a WhisperForConditionalGeneration
+    and a WhisperTokenizer are converted to the native ModelSpec / weights / Vocabulary without loss."""
+    pytest.importorskip("transformers")
+    from crisperwhisper_amd.pipeline import ModelBundle
+    from tests.golden import hf_synth as H
+    g, v, W, spec = Hh.tiny_setup()
+    model = H.build_model(g, v, n_align=3)
+    model.generation_config.alignment_heads = syn.alignment_heads(g, 3)
+    b = ModelBundle.from_hf(model)
+    for f in ("d_model", "n_heads", "ffn_dim", "enc_layers", "dec_layers", "n_mels", "vocab_size", "max_target_positions",
+              "median_filter_width", "eos_token_id", "pad_token_id", "decoder_start_token_id", "no_timestamps_token_id",
+              "max_initial_timestamp_index", "lang_to_id", "task_to_id", "max_length"):
+        assert getattr(b.spec, f) == getattr(spec, f), f
+    assert [list(h) for h in b.spec.alignment_heads] == [list(h) for h in spec.alignment_heads]
+    assert list(b.spec.suppress_tokens) == list(spec.suppress_tokens) and list(b.spec.begin_suppress_tokens) == list(spec.begin_suppress_tokens)
+    assert set(b.weights) == set(syn.weight_shapes(g)) and all(b.weights[k].shape == s for k, s in syn.weight_shapes(g).items())
+    tok = H.build_tokenizer(v)
+    hv, sv = collate.Vocabulary.from_hf_tokenizer(tok), collate.Vocabulary.from_synthetic(v)
+    assert hv.token_bytes == sv.token_bytes and hv.specials == sv.specials
+    assert (hv.eos, hv.timestamp_begin, hv.startofprev, hv.sot) == (sv.eos, sv.timestamp_begin, sv.startofprev, sv.sot)
+    # same collation through either table
+    outs = [{"tokens": np.array([v.timestamp_begin, 72, 105, 32, 0xc3, 0xa9, 46, v.timestamp_begin + 100]),
+             "token_timestamps": np.linspace(0, 2, 8).astype(np.float32), "stride": (30.0, 0.0, 0.0)}]
+    assert collate.decode_asr(hv, outs) == collate.decode_asr(sv, outs)
+
+
+def test_pipeline_argument_errors_mirror_reference():
+    import crisperwhisper_amd as cw
+    with pytest.raises(KeyError):
+        cw.pipeline("text-generation", model=object())
+    with pytest.raises(ValueError):
+        cw.pipeline("automatic-speech-recognition")
+    from crisperwhisper_amd.pipeline import _device_index, _dtype_name
+    with pytest.raises(ValueError):
+        _device_index("cpu")
+    assert _device_index("cuda:3") == 3 and _device_index(None) == 0 and _dtype_name("torch.float16") == "bf16" and _dtype_name("torch.float32") == "f32"
