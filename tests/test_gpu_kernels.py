@@ -145,3 +145,36 @@ def test_pauses_vs_reference_golden(engines):
         out = utils.adjust_pauses_for_hf_pipeline_output(inp, split_threshold=case["thr"], engine=engines["f32"])
         assert out is inp
         assert [list(c["timestamp"]) for c in out["chunks"]] == [c["timestamp"] for c in case["out"]]
+
+
+def test_dtw_property_gpu_vs_oracle(engines):
+    """Random shapes / heavy ties / degenerate sizes: the wavefront DTW path equals the oracle exactly."""
+    from hypothesis import given, settings, strategies as st
+    e = engines["f32"]
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 445), st.integers(1, 1500), st.integers(0, 2 ** 31 - 1), st.sampled_from([0, 1, 3]))
+    def check(N, M, seed, quant):
+        rng = np.random.default_rng(seed)
+        m = rng.standard_normal((N, M)).astype(np.float32)
+        if quant:
+            m = (np.round(m * quant) / quant).astype(np.float32)
+        ti, tj = e.dtw(m)
+        oi, oj = OT.dtw(-m.astype(np.float64))
+        assert np.array_equal(ti, oi) and np.array_equal(tj, oj), (N, M, seed, quant)
+
+    check()
+
+
+def test_align_matrix_property_gpu_vs_oracle(engines):
+    """z-score + median + head-mean on ragged column counts (incl. M <= 3: the median filter's early return)."""
+    rng = np.random.default_rng(17)
+    e = engines["f32"]
+    for (B, Ha, N, M, w) in [(2, 3, 5, 40, 7), (1, 15, 128, 1500, 7), (3, 2, 9, 3, 7), (2, 4, 7, 64, 5), (1, 1, 2, 1, 7)]:
+        a = rng.random((B, Ha, N, M)).astype(np.float32)
+        a /= a.sum(-1, keepdims=True)
+        ncols = [M] + [max(1, M - 1 - 2 * b) for b in range(1, B)]
+        got = e.align_matrix(a, ncols, w)
+        for b in range(B):
+            want = OT.normalise_filter_mean(a[b][:, :, :ncols[b]], w)
+            assert np.allclose(got[b][:, :ncols[b]], want, rtol=2e-5, atol=5e-5, equal_nan=True), (B, Ha, N, M, w, b)  # std == 0 -> NaN on both sides, like the reference

@@ -123,3 +123,32 @@ def test_collation_matches_transformers_live_on_random_streams():
             assert got[0] == text, trial
             ok, why = Hh.words_equal(got[1], opt["chunks"])
             assert ok, (trial, why)
+
+
+def test_dtw_property_random_shapes_and_ties():
+    """Property test: C oracle == line-by-line Python restatement (== transformers when
+    importable) on random shapes incl. N=1, M=1, M<=3, heavy ties; path invariants hold."""
+    from hypothesis import given, settings, strategies as st
+    try:
+        from transformers.models.whisper.generation_whisper import _dynamic_time_warping as hf_dtw
+    except Exception:  # pragma: no cover
+        hf_dtw = None
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 24), st.integers(1, 40), st.integers(0, 2 ** 31 - 1), st.sampled_from([0, 1, 2]))
+    def check(N, M, seed, quant):
+        rng = np.random.default_rng(seed)
+        m = rng.standard_normal((N, M)).astype(np.float32)
+        if quant:
+            m = np.round(m * quant) / quant            # exact ties
+        a = OT.dtw(-m.astype(np.float64))
+        b = OT.dtw_python(-m.astype(np.float64))
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        if hf_dtw is not None:
+            c = hf_dtw(-m.astype(np.float64))
+            assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+        ti, tj = a
+        assert ti[0] == 0 and tj[0] == 0 and ti[-1] == N - 1 and tj[-1] == M - 1
+        assert (np.diff(ti) >= 0).all() and (np.diff(tj) >= 0).all() and ((np.diff(ti) + np.diff(tj)) >= 1).all()
+
+    check()
