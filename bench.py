@@ -87,16 +87,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch  # imported before the native library so that one HIP runtime serves both
     import torch.distributed as td
+    backend = os.environ.get("CW_DIST_BACKEND", "nccl")       # "gloo": lets 2 ranks share one GPU in a smoke test
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = local % ndev
     if world > 1:
-        torch.cuda.set_device(local)
-        td.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device(f"cuda:{dev}"))
+        else:
+            td.init_process_group(backend)
     from crisperwhisper_amd import collate, dist, generation, synthetic as syn, utils
     from crisperwhisper_amd.engine import Engine
 
     g, v = syn.large_v3_geometry() if a.geometry == "large-v3" else syn.tiny_geometry()
     spec = syn.model_spec(g, v, n_align=15 if a.geometry == "large-v3" else 3)
     B = a.batch
-    eng = Engine(spec, dtype=a.dtype, max_batch=B, device=local)
+    eng = Engine(spec, dtype=a.dtype, max_batch=B, device=dev)
     keep = (not a.no_cpu_baseline) and world == 1 and rank == 0
     weights = {}
     t0 = time.perf_counter()
@@ -108,7 +114,7 @@ def main():
     t_load = time.perf_counter() - t0
     vocab = collate.Vocabulary.from_synthetic(v)
     utils.bind_engine(eng)
-    shard = dist.Shard(rank, world, device=f"cuda:{local}" if world > 1 else None)
+    shard = dist.Shard(rank, world, device=f"cuda:{dev}" if (world > 1 and backend == "nccl") else None)
 
     clips = [syn.synth_audio(rank * B + i, 480000, "noise") for i in range(B)]
     nf = eng.upload_pcm(clips)                       # inputs resident in HBM before the timed region
@@ -158,7 +164,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}" if backend == "nccl" else "cpu")
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
     stages = eng.stage_times()
@@ -208,6 +214,42 @@ def main():
                                 "avg_launch_ms": roof[k]["avg_ms"], "algorithmic_bytes_per_launch": roof[k]["algo_bytes"]}
                                for k in roof if k != dom],
         }
+        # per-stage achieved fraction of roofline (BASELINE.md section 3 work figures; times = HIP events per call)
+        if a.geometry == "large-v3":
+            def per_call(stage):
+                ms, calls = stages[stage]
+                return (ms / calls) if calls else None
+            sr = {}
+            t = per_call("mel")
+            if t:
+                by = 3456000.0 * B
+                sr["mel"] = {"bound": "hbm", "algorithmic_bytes": by, "ms_per_call": t, "achieved_GBps": by / t / 1e6,
+                             "frac_of_8TBps": by / t / 1e6 / 8000.0, "note": "f64 direct-DFT: VALU-bound by design, off the critical path"}
+            t = per_call("encoder")
+            if t:
+                fl = 2.274e12 * B
+                sr["encoder"] = {"bound": "mfma", "algorithmic_flops": fl, "ms_per_call": t, "achieved_TFps": fl / t / 1e9,
+                                 "frac_of_2500TFps": fl / t / 1e9 / 2500.0}
+            t = per_call("cross_kv")
+            if t:
+                fl = 3.146e11 * B
+                sr["cross_kv"] = {"bound": "mfma", "algorithmic_flops": fl, "ms_per_call": t, "achieved_TFps": fl / t / 1e9,
+                                  "frac_of_2500TFps": fl / t / 1e9 / 2500.0}
+            ms, calls = stages["decode"]
+            if calls:
+                steps_per_call = a.tokens + 2            # prompt positions 0,1 + one forward per generated token
+                by = 1.812e9 + B * 245.76e6               # weights (bf16) + cross-K/V per step; self-K/V omitted
+                per_step_ms = ms / calls / steps_per_call
+                sr["decode_step"] = {"bound": "hbm", "algorithmic_bytes": by, "ms_per_step": per_step_ms,
+                                     "achieved_GBps": by / per_step_ms / 1e6, "frac_of_8TBps": by / per_step_ms / 1e6 / 8000.0}
+            t = per_call("timestamps")
+            if t:
+                by = 4.0 * 15 * a.tokens * 1500 * B
+                sr["token_timestamps"] = {"bound": "hbm (pre-pass) / dependency chain (DTW)", "algorithmic_bytes": by,
+                                          "ms_per_call": t, "achieved_GBps": by / t / 1e6,
+                                          "dtw_us_per_antidiagonal": t * 1e3 / (a.tokens + 1500 - 1)}
+            line["stage_roofline"] = sr
+            line["passes_per_step"] = stages["encoder"][1] / max(a.steps, 1)
         if keep:
             try:
                 line["cpu_baseline"] = cpu_baseline(g, v, spec, weights, a.tokens, words / max(a.steps * B * world, 1), a.cpu_tokens)
