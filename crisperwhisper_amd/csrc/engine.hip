@@ -1030,6 +1030,31 @@ int32_t cw_stage_times(cw_ctx* c, float* ms, int32_t* calls, int32_t reset) {
 }
 
 int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, float* avg_ms, double* algo_bytes) {
+    if (which == 100 || which == 101) {
+        // launch-boundary floor: a captured graph of `iters` dependent near-empty kernels (100), or the same
+        // launched eagerly (101); avg_ms = time per kernel
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        if (which == 100) {
+            HIPCHK(c, hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < iters; ++i) cw_launch_set_pos(c->d_pos, 64, nb, c->st);
+            HIPCHK(c, hipStreamEndCapture(c->st, &g));
+            HIPCHK(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            HIPCHK(c, hipGraphLaunch(ge, c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st));
+        }
+        HIPCHK(c, hipEventRecord(c->ev0, c->st));
+        if (which == 100) { for (int r = 0; r < 5; ++r) HIPCHK(c, hipGraphLaunch(ge, c->st)); }
+        else for (int r = 0; r < 5; ++r) for (int i = 0; i < iters; ++i) cw_launch_set_pos(c->d_pos, 64, nb, c->st);
+        HIPCHK(c, hipEventRecord(c->ev1, c->st));
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        *avg_ms = ms / (5.0f * iters);
+        *algo_bytes = 0;
+        if (ge) hipGraphExecDestroy(ge);
+        if (g) hipGraphDestroy(g);
+        return CW_OK;
+    }
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim;
     if (nb < 1 || nb > c->Bm || iters < 1) return fail(c, CW_ERR_INVALID, "time_kernel: bad args");
     LayerW& L = c->dec[0];

@@ -149,6 +149,12 @@ def test_large_geometry_layers_bf16_vs_oracle():
         enc = eng.encoder_output(2)
         scale = np.abs(enc_ref).max()
         assert np.abs(enc[0] - enc_ref[0]).max() < 0.06 * scale, np.abs(enc[0] - enc_ref[0]).max() / scale
+        # item 1: 200000 samples -> 1250 valid frames, zero-padded window (conv gather + seek-window semantics)
+        xp, _ = OM.pad_or_trim(x[:200000])
+        seg = np.zeros((1, g.n_mels, 3000), np.float32)
+        seg[0, :, :1250] = OM.log_mel(xp[None], g.n_mels)[0, :, :1250]
+        enc_ref1 = orc.encode(seg)
+        assert np.abs(enc[1] - enc_ref1[0]).max() < 0.06 * np.abs(enc_ref1).max()
         # teacher-forced decode of 10 tokens on item 0 (batch row 1 rides along)
         T = 13
         rng = np.random.default_rng(0)

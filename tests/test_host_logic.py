@@ -158,3 +158,13 @@ def test_pipeline_argument_errors_mirror_reference():
     with pytest.raises(ValueError):
         _device_index("cpu")
     assert _device_index("cuda:3") == 3 and _device_index(None) == 0 and _dtype_name("torch.float16") == "bf16" and _dtype_name("torch.float32") == "f32"
+
+
+def test_timestamp_accuracy_harness():
+    from crisperwhisper_amd import metrics
+    ref = [{"text": " a", "timestamp": (0.0, 0.5)}, {"text": " b", "timestamp": (0.6, 1.0)}, {"text": " c", "timestamp": (2.0, 2.5)}]
+    assert metrics.boundary_f1(ref, ref, 0.2) == (1.0, 1.0, 1.0) and metrics.mean_iou(ref, ref) == 1.0
+    hyp = [{"text": " a", "timestamp": (0.1, 0.55)}, {"text": " b", "timestamp": (0.6, 1.5)}, {"text": " x", "timestamp": (5.0, 5.5)}]
+    p, r, f = metrics.boundary_f1(ref, hyp, 0.2)
+    assert p == r == 0.5 and abs(f - 0.5) < 1e-12
+    assert 0.0 < metrics.mean_iou(ref, hyp) < 1.0
