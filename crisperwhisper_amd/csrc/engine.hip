@@ -471,6 +471,7 @@ int32_t cw_set_generation(cw_ctx* c, const cw_gen_cfg* g) {
     if (g->no_timestamps_token_id < 0 || g->no_timestamps_token_id + 1 >= V) return fail(c, CW_ERR_INVALID, "no_timestamps_token_id out of range");
     mask[g->no_timestamps_token_id] |= 1;  // logits_process.py:2003
     HIPCHK(c, hipMemcpy(c->d_mask, mask.data(), V, hipMemcpyHostToDevice));
+    for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // token ids are baked into captured kernel args
     c->gen = *g;
     c->gen.suppress_tokens = nullptr;
     c->gen.begin_suppress_tokens = nullptr;

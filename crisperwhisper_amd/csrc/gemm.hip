@@ -1,16 +1,19 @@
 // GEMM family for the Whisper encoder/decoder on gfx950.
 //
-//   gemm_bf16_kernel   C[M,N] = A[M,K] * W[N,K]^T  -- 128x128x64 LDS-tiled MFMA (16x16x32 bf16) GEMM.
-//                      A rows are either plain (lda) or an im2col-free conv1d(k=3,pad=1) gather over a
-//                      time-major activation (implicit GEMM for conv1 / conv2,
-//                      TF/models/whisper/modeling_whisper.py:618-619).  Operands are swapped in the MFMA
-//                      (D = W_frag x A_frag) so every lane owns 4 *consecutive output columns* of one
-//                      row -> 8-byte bf16 / 16-byte f32 epilogue stores along N.
+//   gemm_bf16_glds_kernel  C[M,N] = A[M,K] * W[N,K]^T -- 128x128x64 tiles, MFMA 16x16x32 bf16, operand tiles moved
+//                      HBM -> LDS by global_load_lds_dwordx4 (double buffered, XOR swizzle on the DMA source).
+//                      A rows are either plain (lda) or an im2col-free conv1d(k=3,pad=1) gather over a time-major
+//                      activation (implicit GEMM for conv1 / conv2, TF/models/whisper/modeling_whisper.py:618-619).
+//                      Operands are swapped in the MFMA (D = W_frag x A_frag) so every lane owns 4 *consecutive
+//                      output columns* of one row -> vectorised epilogues (epi_store4).
+//   gemm_bf16_kernel   register-staged variant of the same tiling (fallback, CW_NO_GLDS=1).
 //   gemm_f32_kernel    same contract in plain f32 VALU (parity mode + on-device reference).
-//   gemv_bf16_kernel   decode-time skinny GEMM (M = batch <= 64): weights streamed once from HBM
-//                      straight into MFMA B fragments (16 B / lane, 256 B contiguous per weight row per
-//                      step), activations staged in LDS as bf16 with an optional fused LayerNorm
-//                      prologue (TF modeling_whisper.py:470,485,498).  HBM-bound by design.
+//   gemv2_bf16_kernel  decode-time skinny GEMM (batch rows <= 16 per launch, row groups beyond): weights streamed once
+//                      from HBM straight into MFMA B fragments, activations pulled to registers with a wave-local
+//                      LayerNorm (TF modeling_whisper.py:470,485,498) and parked in LDS as bf16; in-place residual
+//                      epilogue with K split + f32 atomics; optional combination of split-attention partials.
+//   gemv_bf16_kernel   first-generation decode GEMV (any batch <= 64, K chunks through LDS); kept for shapes
+//                      gemv2 does not take.
 //   gemv_f32_kernel    f32 parity flavour of the same.
 #include "common.h"
 #include "kernels.h"
