@@ -103,12 +103,17 @@ def gen_e2e():
         # language auto-detection, as the reference calls it (REF/transcribe.py:33 passes no language)
         "noise40_b2_autolang": ("noise", 40, 8, 2, {"max_new_tokens": 20, "language": None, "task": "transcribe"}),
         "mixed20_b1_autolang_notask": ("mixed", 20, 4, 1, {"max_new_tokens": 20, "language": None, "task": None}),
+        # maximum decode length: 445 generated tokens fill max_target_positions (448) -> DTW over 444 rows
+        "noise30_b1_maxlen": ("noise", 30, 6, 1, {"min_new_tokens": 445, "max_new_tokens": 445}),
+        # ragged / degenerate inputs: a one-sample clip and a 0.1 s clip
+        "noise_1sample": ("noise", 1.0 / 16000, 7, 1, {"max_new_tokens": 8}),
+        "noise_100ms": ("noise", 0.1, 7, 1, {"max_new_tokens": 8}),
     }
     meta = {}
     arrays = {}
     import transformers.models.whisper.generation_whisper as GW
     for name, (kind, secs, seed, bs, extra) in scenarios.items():
-        x = syn.synth_audio(seed, secs * 16000, kind)
+        x = syn.synth_audio(seed, int(round(secs * 16000)), kind)
         pipe = H.build_pipeline(model, tok, fe, batch_size=bs)
         calls = []
         orig = model.generate

@@ -94,13 +94,13 @@ def test_teacher_forced_decoder(tiny, eng_f32, eng_bf16, mode):
     assert np.abs(al[0].sum(-1) - 1).max() < 1e-3       # rows are probability vectors
 
 
-@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask"])
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask", "noise30_b1_maxlen", "noise_1sample", "noise_100ms"])
 def test_pipeline_f32_word_for_word_vs_reference(tiny, name):
     """The drop-in call of REF/transcribe.py:21-33 + REF/README pause split, f32 engine, against the
     transformers CPU output: identical text/words, timestamps within +-0.02 s (one encoder frame)."""
     g, v, W, spec = tiny
     meta = Hh.gold_json("e2e_golden.json")[name]
-    x = syn.synth_audio(meta["seed"], meta["secs"] * 16000, meta["kind"])
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
     pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
                        tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30,
                        batch_size=meta["batch_size"], return_timestamps="word", torch_dtype="float32", device="cuda:0")
@@ -195,7 +195,7 @@ def test_reference_call_sequence_with_hf_objects_and_wav_path(tiny, tmp_path):
     model.generation_config.alignment_heads = syn.alignment_heads(g, 3)
     tok, fe = H.build_tokenizer(v), H.build_feature_extractor(g)
     meta = Hh.gold_json("e2e_golden.json")["mixed70_b2_n40"]
-    x = syn.synth_audio(meta["seed"], meta["secs"] * 16000, meta["kind"])
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
     path = str(tmp_path / "clip.wav")
     wavfile.write(path, 16000, x)                                  # float32 WAV: lossless
     pipe = cw.pipeline("automatic-speech-recognition", model=model, tokenizer=tok, feature_extractor=fe,

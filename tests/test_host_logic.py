@@ -50,14 +50,14 @@ def test_shard_bounds_and_records():
     assert dist.unpack_words(dist.pack_words(6, [])) == (6, [])
 
 
-@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask"])
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask", "noise30_b1_maxlen", "noise_1sample", "noise_100ms"])
 def test_host_control_flow_word_for_word(name):
     """generation.generate + collate.decode_asr (product host code) over the oracle-backed engine
     reproduce the reference pipeline output word for word."""
     g, v, W, spec = Hh.tiny_setup()
     meta = Hh.gold_json("e2e_golden.json")[name]
     z = Hh.gold_npz("e2e_golden.npz")
-    x = syn.synth_audio(meta["seed"], meta["secs"] * 16000, meta["kind"])
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
     eng = Hh.OracleBackedEngine(g, v, W, spec)
     vocab = collate.Vocabulary.from_synthetic(v)
     windows = audio.chunk_windows(len(x), 480000, 80000, 80000)

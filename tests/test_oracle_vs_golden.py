@@ -69,11 +69,11 @@ def test_teacher_forced_logits_and_cross_attention():
     assert np.abs(cross[0] - z["tf/cross"]).max() < 1e-5
 
 
-@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask"])
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24", "noise40_b2_autolang", "mixed20_b1_autolang_notask", "noise30_b1_maxlen", "noise_1sample", "noise_100ms"])
 def test_pipeline_word_for_word(name):
     g, v, W, spec = Hh.tiny_setup()
     meta = Hh.gold_json("e2e_golden.json")[name]
-    x = syn.synth_audio(meta["seed"], meta["secs"] * 16000, meta["kind"])
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
     orc = WhisperOracle(W, g)
     kw = {"language": "<|en|>", "task": "transcribe", **meta["extra"]}
     out = OPIPE.transcribe(orc, Hh.oracle_spec(g, v, spec), Hh.oracle_vocab(v), x, n_mels=g.n_mels,
