@@ -217,3 +217,24 @@ def test_reference_call_sequence_with_hf_objects_and_wav_path(tiny, tmp_path):
     with pytest.raises(TypeError):
         pipe(12345)
     pipe.engine.close()
+
+
+def test_ten_minute_long_form_vs_oracle(tiny):
+    """BASELINE configs[2] on one GPU: 600 s stream -> 30 chunks (29 x 30 s + 20 s, 5 s strides), batch_size 16,
+    seam merge across all chunk boundaries; tiny f32 engine vs the oracle pipeline (pinned to transformers)."""
+    from oracle import pipeline as OPIPE
+    g, v, W, spec = tiny
+    x = np.concatenate([syn.synth_audio(100 + i, 16000 * 60, "mixed" if i % 2 else "noise") for i in range(10)])
+    assert len(x) == 9_600_000
+    pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30, batch_size=16,
+                       return_timestamps="word", torch_dtype="float32", device="cuda:0")
+    kw = {**Hh.GEN_KW, "max_new_tokens": 24}
+    out = pipe(x, generate_kwargs=kw)
+    want = OPIPE.transcribe(WhisperOracle(W, g), Hh.oracle_spec(g, v, spec), Hh.oracle_vocab(v), x, n_mels=g.n_mels,
+                            batch_size=16, max_new_tokens=24)
+    assert out["text"] == want["text"]
+    ok, why = Hh.words_equal(out["chunks"], want["chunks"], tol=0.02)
+    assert ok, why
+    assert len(out["chunks"]) > 30
+    pipe.engine.close()
