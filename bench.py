@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=12)
     ap.add_argument("--kernel-iters", type=int, default=200)
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="independent engine contexts per GPU, each with its own batch of --batch chunks, driven by "
+                         "host threads (the decode step is latency-bound, so a second batch fills idle CUs); "
+                         "default 1 = the BASELINE configuration")
     return ap.parse_args()
 
 
@@ -102,13 +106,16 @@ def main():
     g, v = syn.large_v3_geometry() if a.geometry == "large-v3" else syn.tiny_geometry()
     spec = syn.model_spec(g, v, n_align=15 if a.geometry == "large-v3" else 3)
     B = a.batch
-    eng = Engine(spec, dtype=a.dtype, max_batch=B, device=dev)
+    C = max(1, a.contexts)
+    engines = [Engine(spec, dtype=a.dtype, max_batch=B, device=dev) for _ in range(C)]
+    eng = engines[0]
     keep = (not a.no_cpu_baseline) and world == 1 and rank == 0
     weights = {}
     t0 = time.perf_counter()
     for name, shape in syn.weight_shapes(g).items():
         w = syn.random_tensor(g, name, shape, seed=0)
-        eng.load_tensor(name, w)
+        for e_ in engines:
+            e_.load_tensor(name, w)
         if keep:
             weights[name] = w
     t_load = time.perf_counter() - t0
@@ -116,11 +123,14 @@ def main():
     utils.bind_engine(eng)
     shard = dist.Shard(rank, world, device=f"cuda:{dev}" if (world > 1 and backend == "nccl") else None)
 
-    clips = [syn.synth_audio(rank * B + i, 480000, "noise") for i in range(B)]
-    nf = eng.upload_pcm(clips)                       # inputs resident in HBM before the timed region
-    audio_s = 30.0 * B
+    nfs = []
+    for ci, e_ in enumerate(engines):
+        clips = [syn.synth_audio((rank * C + ci) * B + i, 480000, "noise") for i in range(B)]
+        nfs.append(e_.upload_pcm(clips))             # inputs resident in HBM before the timed region
+    audio_s = 30.0 * B * C
 
-    def step():
+    def step_ctx(ci):
+        eng, nf = engines[ci], nfs[ci]
         eng.mel_resident(B)
         out = generation.generate(eng, B, nf, language="<|en|>", task="transcribe", max_new_tokens=a.tokens,
                                   min_new_tokens=a.tokens)
@@ -134,9 +144,20 @@ def main():
             text, words = collate.decode_asr(vocab, [{"tokens": out["sequences"][k][:n],
                                                       "token_timestamps": out["token_timestamps"][k],
                                                       "stride": (30.0, 0.0, 0.0)}])
-            res = utils.adjust_pauses_for_hf_pipeline_output({"text": text, "chunks": words})
-            recs.append(dist.pack_words(rank * B + k, res["chunks"]))
-        allr = shard.all_gather_records(np.stack(recs), B)
+            res = utils.adjust_pauses_for_hf_pipeline_output({"text": text, "chunks": words}, engine=eng)
+            recs.append(dist.pack_words((rank * C + ci) * B + k, res["chunks"]))
+        return recs, n_tokens
+
+    def step():
+        if C == 1:
+            parts = [step_ctx(0)]
+        else:
+            import concurrent.futures as cf
+            with cf.ThreadPoolExecutor(C) as ex:
+                parts = list(ex.map(step_ctx, range(C)))
+        recs = [r for p_ in parts for r in p_[0]]
+        n_tokens = sum(p_[1] for p_ in parts)
+        allr = shard.all_gather_records(np.stack(recs), B * C)
         n_words = 0
         if rank == 0:
             for r in allr:
@@ -146,14 +167,16 @@ def main():
         return n_words, n_tokens
 
     def fence():
-        eng.sync()
+        for e_ in engines:
+            e_.sync()
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
-    eng.stage_times(reset=True)
+    for e_ in engines:
+        e_.stage_times(reset=True)
     fence()
     t0 = time.perf_counter()
     words = tokens = 0
@@ -168,6 +191,9 @@ def main():
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
     stages = eng.stage_times()
+    for e_ in engines[1:]:
+        for k_, (ms_, n_) in e_.stage_times().items():
+            stages[k_] = (stages[k_][0] + ms_, stages[k_][1] + n_)
 
     # roofline of the decode-step kernels, HIP events on the engine's own stream
     roof = {}
@@ -203,9 +229,9 @@ def main():
             "rtf": dt / total_audio, "tokens_per_s": tokens / dt,
             "config": {"workload": f"BASELINE configs[1]: batch={B} x 30 s synthetic 16 kHz audio per GPU, {a.dtype}, "
                                    f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, greedy, word timestamps",
-                       "chunks_per_gpu": B, "tokens_per_chunk": a.tokens, "parallelism": f"chunk-dp{world}",
+                       "chunks_per_gpu": B * C, "contexts_per_gpu": C, "tokens_per_chunk": a.tokens, "parallelism": f"chunk-dp{world}",
                        "weight_load_s": round(t_load, 1)},
-            "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1), 3) for k, val in stages.items()},
+            "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1) / C, 3) for k, val in stages.items()},
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
                          "frac": r["achieved"] / 8000.0,
                          "traffic": pmc_traffic("attn_cross_split" if dom == 1 else "gemv2_bf16_kernelILi7"), "kernel": r["kernel"],
@@ -252,12 +278,13 @@ def main():
             line["passes_per_step"] = stages["encoder"][1] / max(a.steps, 1)
         if keep:
             try:
-                line["cpu_baseline"] = cpu_baseline(g, v, spec, weights, a.tokens, words / max(a.steps * B * world, 1), a.cpu_tokens)
+                line["cpu_baseline"] = cpu_baseline(g, v, spec, weights, a.tokens, words / max(a.steps * B * C * world, 1), a.cpu_tokens)
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "aligned words/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {e!r}"}
         print(json.dumps(line), flush=True)
-    eng.close()
+    for e_ in engines:
+        e_.close()
     if world > 1:
         td.destroy_process_group()
 
