@@ -18,6 +18,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <mutex>
 
 #define BM 128
 #define BN 128
@@ -641,11 +642,12 @@ static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, 
                             hipStream_t st) {
     if (bf16) {
         int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-        if (!g_zero_page) {
+        static std::once_flag once;              // contexts may launch from several host threads
+        std::call_once(once, [] {
             void* z = nullptr;
             if (hipMalloc(&z, 256) == hipSuccess) { hipMemset(z, 0, 256); g_zero_page = (const bf16_t*)z; }
             if (getenv("CW_NO_GLDS")) g_use_glds = false;
-        }
+        });
         if (g_use_glds && g_zero_page)
             hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI>), dim3(tm * tn), dim3(256), 65536, st, ap, (const bf16_t*)W, M,
                                N, K, ep, tn, g_zero_page);

@@ -82,7 +82,7 @@ def _device_index(device) -> int:
 class CrisperWhisperPipeline:
     def __init__(self, model, tokenizer=None, feature_extractor=None, chunk_length_s=0, stride_length_s=None,
                  batch_size=1, return_timestamps=None, torch_dtype=None, dtype=None, device=None,
-                 shard: Optional[dist.Shard] = None, **kwargs):
+                 shard: Optional[dist.Shard] = None, contexts: int = 1, **kwargs):
         self.bundle = model if isinstance(model, ModelBundle) else ModelBundle.from_hf(model)
         if tokenizer is None:
             raise ValueError("a tokenizer (WhisperTokenizer or crisperwhisper_amd.collate.Vocabulary) is required")
@@ -95,9 +95,13 @@ class CrisperWhisperPipeline:
         self.batch_size = int(batch_size or 1)
         self.return_timestamps = return_timestamps
         self.shard = shard or dist.Shard()
-        self.engine = Engine(self.bundle.spec, dtype=_dtype_name(dtype if dtype is not None else torch_dtype),
-                             max_batch=self.batch_size, device=_device_index(device))
-        self.engine.load_state_dict(self.bundle.weights)
+        # `contexts` > 1: independent engine contexts on the same GPU, each running its own batches from a host
+        # thread -- the decode chain is latency-bound, so a second in-flight batch fills idle CUs.
+        self.engines = [Engine(self.bundle.spec, dtype=_dtype_name(dtype if dtype is not None else torch_dtype),
+                               max_batch=self.batch_size, device=_device_index(device)) for _ in range(max(1, int(contexts)))]
+        for e in self.engines:
+            e.load_state_dict(self.bundle.weights)
+        self.engine = self.engines[0]
         utils.bind_engine(self.engine)
         self.stats: Dict[str, Any] = {}
 
@@ -170,19 +174,36 @@ class CrisperWhisperPipeline:
 
         lo, hi = dist.shard_bounds(len(windows), self.shard.world)[self.shard.rank]
         mine = list(range(lo, hi))
-        recs = []
-        for b0 in range(0, len(mine), self.batch_size):
-            idxs = mine[b0:b0 + self.batch_size]
+        def run_batch(args):
+            slot, idxs = args
+            eng = self.engines[slot % len(self.engines)]
             clips = [pcm[windows[i][0]: windows[i][0] + windows[i][1]] for i in idxs]
-            _, nf = self.engine.mel(clips)
+            _, nf = eng.mel(clips)
+            st = {}
             out = generation.generate(
-                self.engine, len(idxs), nf, language=gk.get("language"), task=gk.get("task"),
+                eng, len(idxs), nf, language=gk.get("language"), task=gk.get("task"),
                 max_new_tokens=gk.get("max_new_tokens"), min_new_tokens=gk.get("min_new_tokens"),
-                num_beams=gk.get("num_beams", 1), stats=self.stats)
+                num_beams=gk.get("num_beams", 1), stats=st)
+            rs = []
             for k, i in enumerate(idxs):
                 n_tok = len(out["token_timestamps"][k])
                 stride = tuple(x / sr for x in windows[i][2])
-                recs.append(dist.pack_record(i, out["sequences"][k][:n_tok], out["token_timestamps"][k], stride))
+                rs.append(dist.pack_record(i, out["sequences"][k][:n_tok], out["token_timestamps"][k], stride))
+            return rs, st.get("generate_calls", 0)
+
+        batches = [(n, mine[b0:b0 + self.batch_size]) for n, b0 in enumerate(range(0, len(mine), self.batch_size))]
+        if len(self.engines) > 1 and len(batches) > 1:
+            import concurrent.futures as cf
+            # one worker per context; batch n always runs on context n % C, so a context is never re-entered
+            lanes = [[b for b in batches if b[0] % len(self.engines) == c] for c in range(len(self.engines))]
+            with cf.ThreadPoolExecutor(len(self.engines)) as ex:
+                lane_out = list(ex.map(lambda lane: [run_batch(b) for b in lane], lanes))
+            done = {b[0]: r for lane, outs in zip(lanes, lane_out) for b, r in zip(lane, outs)}
+            results = [done[n] for n, _ in batches]
+        else:
+            results = [run_batch(b) for b in batches]
+        recs = [r for rs, _ in results for r in rs]
+        self.stats["generate_calls"] = self.stats.get("generate_calls", 0) + sum(c for _, c in results)
         recs = np.stack(recs) if recs else np.zeros((0, dist.REC_WORDS), np.int32)
         max_per_rank = max(h - l for l, h in dist.shard_bounds(len(windows), self.shard.world))
         allr = self.shard.all_gather_records(recs, max_per_rank)

@@ -238,3 +238,20 @@ def test_ten_minute_long_form_vs_oracle(tiny):
     assert ok, why
     assert len(out["chunks"]) > 30
     pipe.engine.close()
+
+
+def test_concurrent_contexts_give_identical_result(tiny):
+    """pipeline(contexts=2): alternate batches run on two engine contexts from two host threads; chunks are
+    independent, so the merged result must equal the single-context one (f32 engine: bit-identical tokens)."""
+    g, v, W, spec = tiny
+    x = syn.synth_audio(21, 130 * 16000, "mixed")
+    kw = {**Hh.GEN_KW, "max_new_tokens": 20}
+    outs = []
+    for contexts in (1, 2):
+        pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
+                           tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30, batch_size=2,
+                           return_timestamps="word", torch_dtype="float32", device="cuda:0", contexts=contexts)
+        outs.append(pipe(x, generate_kwargs=kw))
+        for e in pipe.engines:
+            e.close()
+    assert outs[0] == outs[1] and len(outs[0]["chunks"]) > 0
