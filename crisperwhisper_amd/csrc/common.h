@@ -16,11 +16,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;   // one MFMA 16x16 C
 __host__ __device__ inline float bf16_to_f32(bf16_t v) {
     union { uint32_t u; float f; } x; x.u = ((uint32_t)v) << 16; return x.f;
 }
-__host__ __device__ inline bf16_t f32_to_bf16(float f) {   // round-nearest-even, branchless (NaN stays quiet NaN)
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {   // round-nearest-even (NaN stays quiet NaN)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950 has a hardware converter: the cast lowers to v_cvt_pk_bf16_f32 (pairs are packed by the compiler)
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+#else
     union { uint32_t u; float f; } x; x.f = f;
     const uint32_t rounded = (x.u + 0x7fffu + ((x.u >> 16) & 1u)) >> 16;
     const uint32_t nan = (x.u >> 16) | 0x40u;
     return (bf16_t)(((x.u & 0x7fffffffu) > 0x7f800000u) ? nan : rounded);
+#endif
 }
 
 // Activation storage trait: the engine runs either fully in f32 (parity mode) or with bf16
