@@ -24,6 +24,7 @@ __device__ inline f32x4_t mfma16a(bf16x8_t a, bf16x8_t b, f32x4_t c) {
 }
 
 #define KT 64          // keys per LDS tile
+#define RESCALE_THR 8.0f
 #define KS_STRIDE 72   // bf16 per K row in LDS (64 + 8)
 #define VS_STRIDE 66   // bf16 per V^T row in LDS (64 keys + 2): 33 dwords -> spreads the transposing writes
 
@@ -121,9 +122,20 @@ __global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrow[qt], mx);
-            const float alpha = __expf(mrow[qt] - mnew);   // exp(-inf) = 0 on the first tile
-            mrow[qt] = mnew;
+            // deferred rescale: the running max (and with it the O / l accumulators) is only moved when some row
+            // of the wave grew by more than RESCALE_THR; otherwise P = exp(s - m_old) <= e^THR, still exact in the
+            // final O / l ratio (f32 accumulators).  The decision is taken before this tile's P exists.
+            float mnew = mrow[qt];
+            if (__any(mx > mrow[qt] + RESCALE_THR)) {
+                mnew = fmaxf(mrow[qt], mx);
+                const float alpha = __expf(mrow[qt] - mnew);   // exp(-inf) = 0 on the first tile
+                mrow[qt] = mnew;
+                lrow[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+            }
             float psum = 0.f;
             bf16_t pb[16];
 #pragma unroll
@@ -134,11 +146,7 @@ __global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __
                     psum += pv;
                     pb[kt * 4 + r] = f32_to_bf16(pv);
                 }
-            lrow[qt] = lrow[qt] * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+            lrow[qt] += psum;
             // B operand of O^T = V^T P^T for k-step kp: contraction index j<4 -> key (2kp)*16 + g*4 + j,
             // j>=4 -> key (2kp+1)*16 + g*4 + (j-4); the A operand below uses the same mapping.
 #pragma unroll
