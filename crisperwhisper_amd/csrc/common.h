@@ -196,6 +196,64 @@ __device__ inline void epi_store4(const EpiParams& p, int m, int n, float a0, fl
     }
 }
 
+// Tile epilogue with the row / column decompositions hoisted out of the 4x4 fragment loop: per lane 4 row
+// offsets (integer divisions for the head-split and position layouts happen here, 4 instead of 16 times) and
+// 4 column descriptors (bias vector, destination pointer), then 16 vector stores.  rows[i] / cols[j] are the
+// lane's 4 row indices and 4 first-column indices (cols multiple of 4), all inside [0,M) x [0,N).
+template <typename T, int MODE>
+__device__ inline void epi_tile_interior(const EpiParams& p, const int (&rows)[4], const int (&cols)[4],
+                                         const f32x4_t (&acc)[4][4]) {
+    size_t roff[4]; int rpos[4];
+    float4 bias[4]; size_t coff[4]; T* cbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = rows[i];
+        rpos[i] = 0;
+        if (MODE == EPI_HEADS) {
+            const int b = m / p.T, s_ = m - b * p.T;
+            roff[i] = ((size_t)b * p.H * p.S_pad + s_) * 64;
+        } else {
+            roff[i] = (size_t)m * p.ldo;
+            if (MODE == EPI_GELU_POS_F32) rpos[i] = m % p.T;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = cols[j];
+        bias[j] = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cbase[j] = (T*)p.out;
+        if (MODE == EPI_HEADS) {
+            const int which = n / p.d_model, r = n - which * p.d_model;
+            cbase[j] = (T*)(which == 0 ? p.out : (which == 1 ? p.out1 : p.out2));
+            coff[j] = (size_t)(r >> 6) * p.S_pad * 64 + (r & 63);
+        } else {
+            coff[j] = (size_t)n;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a0 = acc[i][j][0] + bias[j].x, a1 = acc[i][j][1] + bias[j].y;
+            const float a2 = acc[i][j][2] + bias[j].z, a3 = acc[i][j][3] + bias[j].w;
+            const size_t o = roff[i] + coff[j];
+            if (MODE == EPI_STORE || MODE == EPI_HEADS) {
+                Pack4<T>::st(cbase[j] + o, a0, a1, a2, a3);
+            } else if (MODE == EPI_GELU) {
+                Pack4<T>::st(cbase[j] + o, Pack4<T>::gelu(a0), Pack4<T>::gelu(a1), Pack4<T>::gelu(a2), Pack4<T>::gelu(a3));
+            } else if (MODE == EPI_RESID_F32) {
+                const float4 r = *(const float4*)(p.resid + o);
+                *(float4*)(p.outf + o) = make_float4(r.x + a0, r.y + a1, r.z + a2, r.w + a3);
+            } else if (MODE == EPI_GELU_POS_F32) {
+                const float4 ps = *(const float4*)(p.pos + (size_t)rpos[i] * p.ldo + cols[j]);
+                *(float4*)(p.outf + o) = make_float4(Pack4<T>::gelu(a0) + ps.x, Pack4<T>::gelu(a1) + ps.y,
+                                                     Pack4<T>::gelu(a2) + ps.z, Pack4<T>::gelu(a3) + ps.w);
+            } else if (MODE == EPI_STORE_F32) {
+                *(float4*)(p.outf + o) = make_float4(a0, a1, a2, a3);
+            }
+        }
+}
+
 // Host-side error plumbing -----------------------------------------------------------------------
 #define CW_OK 0
 #define CW_ERR_INVALID (-22)

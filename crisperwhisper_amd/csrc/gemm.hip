@@ -138,6 +138,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(AParams ap, const bf16_t
     }
 
     // epilogue: acc[i][j][r] = C[m][n], m = m0 + wm*64 + i*16 + l15, n = n0 + wn*64 + j*16 + g*4 + r
+    if (m0 + BM <= M && n0 + BN <= N && (EPI == EPI_HEADS || (ep.ldo & 3) == 0)) {   // interior tile (block-uniform)
+        int rows[4], cols[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows[i] = m0 + wm * 64 + i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cols[j] = n0 + wn * 64 + j * 16 + g * 4;
+        epi_tile_interior<bf16_t, EPI>(ep, rows, cols, acc);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int m = m0 + wm * 64 + i * 16 + l15;
@@ -236,6 +245,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(AParams ap, const b
         __syncthreads();                                   // ... and everybody's; everyone done reading `cur`
     }
 
+    if (m0 + BM <= M && n0 + BN <= N && (EPI == EPI_HEADS || (ep.ldo & 3) == 0)) {   // interior tile (block-uniform)
+        int rows[4], cols[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows[i] = m0 + wm * 64 + i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cols[j] = n0 + wn * 64 + j * 16 + g * 4;
+        epi_tile_interior<bf16_t, EPI>(ep, rows, cols, acc);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int m = m0 + wm * 64 + i * 16 + l15;
