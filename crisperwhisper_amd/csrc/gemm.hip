@@ -195,16 +195,41 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(AParams ap, const b
     // this lane stages rows r = ch*8 + (lane >> 3) of chunk ch = wave*4 + q, source chunk (lane & 7) ^ (r & 7)
     const int lrow = lane >> 3;
     const int csrc = ((lane & 7) ^ lrow) * 8;                       // r & 7 == lrow (ch*8 is a multiple of 8)
+    // per-row address pieces are fixed across the K loop: hoist the (batch, time) decomposition of the conv gather
+    size_t a_base[4]; int a_t[4], a_valid[4]; const bf16_t* w_row[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (wave * 4 + q) * 8 + lrow;
+        const int m = m0 + r, n = n0 + r;
+        w_row[q] = (n < N) ? W + (size_t)n * K + csrc : nullptr;
+        a_valid[q] = -1;                                            // -1: zero row
+        a_base[q] = 0; a_t[q] = 0;
+        if (m < M) {
+            if (ap.amode == 0) { a_base[q] = (size_t)m * ap.lda + csrc; a_valid[q] = 0x7fffffff; }
+            else {
+                const int b = m / ap.T_out, t = m - b * ap.T_out;
+                a_t[q] = t * ap.stride - 1;                         // input row of tap 0 inside the window
+                a_base[q] = (size_t)ap.row_off[b] * ap.C_in + csrc;
+                a_valid[q] = ap.row_valid[b];
+            }
+        }
+    }
     auto stage = [&](int k0, int buf) {
         unsigned char* base = gsm + buf * 32768;
+        int tap = 0, c0 = k0;
+        if (ap.amode != 0) { tap = k0 / ap.C_in; c0 = k0 - tap * ap.C_in; }   // k-tile uniform (scalar)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ch = wave * 4 + q;
-            const int r = ch * 8 + lrow;
-            const bf16_t* pa = a_row_ptr<bf16_t>(ap, m0 + r, M, k0);
-            glds16(pa ? (const void*)(pa + csrc) : (const void*)zero_page, base + ch * 1024);
-            const int n = n0 + r;
-            glds16(n < N ? (const void*)(W + (size_t)n * K + k0 + csrc) : (const void*)zero_page, base + 16384 + ch * 1024);
+            const bf16_t* pa = nullptr;
+            if (ap.amode == 0) {
+                if (a_valid[q] >= 0) pa = (const bf16_t*)ap.A + a_base[q] + k0;
+            } else {
+                const int t_in = a_t[q] + tap;
+                if (t_in >= 0 && t_in < a_valid[q]) pa = (const bf16_t*)ap.A + a_base[q] + (size_t)t_in * ap.C_in + c0;
+            }
+            glds16(pa ? (const void*)pa : (const void*)zero_page, base + ch * 1024);
+            glds16(w_row[q] ? (const void*)(w_row[q] + k0) : (const void*)zero_page, base + 16384 + ch * 1024);
         }
     };
 
