@@ -37,6 +37,7 @@ struct cw_ctx {
     hipStream_t st = nullptr;
     std::vector<void*> allocs;
     char err[512] = "";
+    bool err_set = false;      // a specific message is pending (set by fail(), cleared by cw_last_error)
     std::vector<int> align_layers, align_heads;
 
     // weights
@@ -98,7 +99,13 @@ static int fail(cw_ctx* c, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(c ? c->err : g_err, 512, fmt, ap);
     va_end(ap);
+    if (c) c->err_set = true;
     return code;
+}
+// outer frames keep the innermost message and only add one when the callee reported a bare code
+static int fail_ctx(cw_ctx* c, int code, const char* call, const char* file, int line) {
+    if (c && c->err_set) return code;
+    return fail(c, code, "%s -> %d (%s:%d)", call, code, file, line);
 }
 
 #define HIPCHK(c, call)                                                                             \
@@ -110,7 +117,7 @@ static int fail(cw_ctx* c, int code, const char* fmt, ...) {
 #define CWCHK(c, call)                                                          \
     do {                                                                        \
         int r_ = (call);                                                        \
-        if (r_ != CW_OK) return fail(c, r_, "%s -> %d (%s:%d)", #call, r_, __FILE__, __LINE__); \
+        if (r_ != CW_OK) return fail_ctx(c, r_, #call, __FILE__, __LINE__); \
     } while (0)
 #define KCHK(c) HIPCHK(c, hipGetLastError())
 
@@ -180,7 +187,11 @@ extern "C" {
 
 int32_t cw_abi_version(void) { return 1; }
 
-const char* cw_last_error(cw_ctx* ctx) { return ctx ? ctx->err : g_err; }
+const char* cw_last_error(cw_ctx* ctx) {
+    if (!ctx) return g_err;
+    ctx->err_set = false;
+    return ctx->err;
+}
 
 int32_t cw_sync(cw_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->st));

@@ -178,3 +178,30 @@ def test_align_matrix_property_gpu_vs_oracle(engines):
         for b in range(B):
             want = OT.normalise_filter_mean(a[b][:, :, :ncols[b]], w)
             assert np.allclose(got[b][:, :ncols[b]], want, rtol=2e-5, atol=5e-5, equal_nan=True), (B, Ha, N, M, w, b)  # std == 0 -> NaN on both sides, like the reference
+
+
+def test_c_abi_error_behaviour(engines):
+    """Negative errno-style codes + messages instead of crashes (include/crisperwhisper.h conventions)."""
+    from crisperwhisper_amd.engine import EngineError
+    e = engines["f32"]
+    with pytest.raises(EngineError, match="unknown tensor name"):
+        e.load_tensor("model.encoder.not_a_tensor", np.zeros(4, np.float32))
+    with pytest.raises(EngineError, match="expected"):
+        e.load_tensor("model.encoder.conv1.bias", np.zeros(7, np.float32))
+    with pytest.raises(EngineError, match="bad window"):
+        e.encode([0], [2900], [500])                       # seek + n_frames beyond the 3000-frame window
+    with pytest.raises(EngineError):
+        e.encode(list(range(9)), [0] * 9, [3000] * 9)      # more windows than max_batch
+    g, v, W, spec = Hh.tiny_setup()
+    fresh = Engine(spec, dtype="f32", max_batch=2)
+    try:
+        with pytest.raises(EngineError, match="windows encoded"):
+            fresh.decode(np.array([[v.sot, v.lang_id("en"), v.transcribe]]), max_length=8)   # nothing encoded yet
+        with pytest.raises(EngineError):
+            fresh.mel([np.zeros(480001, np.float32)])       # longer than one 30 s window
+    finally:
+        fresh.close()
+    bad = syn.model_spec(*syn.tiny_geometry(), 3)
+    bad.alignment_heads = [[99, 0]]
+    with pytest.raises(EngineError, match="alignment head"):
+        Engine(bad, dtype="f32", max_batch=1)
