@@ -76,8 +76,14 @@ def cpu_baseline(g, v, spec, weights, n_tok_gpu, words_per_chunk, cpu_tokens):
     OT.extract_token_timestamps(wfull, np.array([3000]), 3, g.median_filter_width)
     t_ts = time.perf_counter() - t0
     per_step = t_dec / (cpu_tokens + 2)               # prompt positions are fed too
+    try:                                              # threads the BLAS behind numpy actually runs with
+        from threadpoolctl import threadpool_info
+        blas_threads = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+    except Exception:
+        blas_threads = os.cpu_count()
     total = t_mel + t_enc + per_step * (n_tok_gpu + 2) + t_ts
-    return {"value": words_per_chunk / total, "unit": "aligned words/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": words_per_chunk / total, "unit": "aligned words/s", "cores": blas_threads, "host_cpus": os.cpu_count(),
+            "kind": "port",
             "sample": f"1 x 30 s clip on numpy/C oracle (fp32): mel {t_mel:.2f}s + encoder {t_enc:.2f}s + "
                       f"{cpu_tokens}+2 decoder steps {t_dec:.2f}s + alignment(N={n_tok_gpu}) {t_ts:.2f}s, decoder "
                       f"extrapolated to {n_tok_gpu} tokens -> {total:.1f}s per chunk (RTF {total / 30:.3f})",

@@ -255,3 +255,35 @@ def test_concurrent_contexts_give_identical_result(tiny):
         for e in pipe.engines:
             e.close()
     assert outs[0] == outs[1] and len(outs[0]["chunks"]) > 0
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_live_transformers_pipeline_parity_on_fresh_inputs(seed):
+    """Not a fixture: fresh random weights + audio per seed, the installed transformers pipeline on the host CPU
+    (the reference's exact call, REF/transcribe.py:21-33) vs the native pipeline (f32 engine) on the GPU."""
+    pytest.importorskip("transformers")
+    import torch
+    from tests.golden import hf_synth as H
+    g, v = syn.tiny_geometry()
+    W = syn.random_weights(g, seed=seed)
+    spec = syn.model_spec(g, v, 3)
+    model = H.build_model(g, v, n_align=3)
+    sd = {k: torch.from_numpy(x) for k, x in W.items()}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    model.load_state_dict(sd, strict=True)
+    model.generation_config.alignment_heads = syn.alignment_heads(g, 3)
+    tok, fe = H.build_tokenizer(v), H.build_feature_extractor(g)
+    rng = np.random.default_rng(seed)
+    secs = int(rng.integers(8, 75))
+    x = syn.synth_audio(seed, secs * 16000, ["noise", "mixed", "chirp"][seed % 3])
+    bs = int(rng.integers(1, 4))
+    kw = {**Hh.GEN_KW, "max_new_tokens": int(rng.integers(12, 48))}
+    ref = H.build_pipeline(model, tok, fe, batch_size=bs)(x.copy(), generate_kwargs=kw)
+    pipe = cw.pipeline("automatic-speech-recognition", model=model, tokenizer=tok, feature_extractor=fe,
+                       chunk_length_s=30, batch_size=bs, return_timestamps="word", torch_dtype=torch.float32,
+                       device="cuda:0")
+    out = pipe(x, generate_kwargs=kw)
+    pipe.engine.close()
+    assert out["text"] == ref["text"]
+    ok, why = Hh.words_equal(out["chunks"], [{"text": c["text"], "timestamp": list(c["timestamp"])} for c in ref["chunks"]], tol=0.02)
+    assert ok, why

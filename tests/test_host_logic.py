@@ -168,3 +168,18 @@ def test_timestamp_accuracy_harness():
     p, r, f = metrics.boundary_f1(ref, hyp, 0.2)
     assert p == r == 0.5 and abs(f - 0.5) < 1e-12
     assert 0.0 < metrics.mean_iou(ref, hyp) < 1.0
+
+
+def test_missing_native_library_fails_loudly(monkeypatch):
+    """No CPU fallback: without libcrisperwhisper.so every entry point raises NativeLibraryError."""
+    from crisperwhisper_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libcrisperwhisper.so")
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        _native.load()
+    g, v, W, spec = Hh.tiny_setup()
+    from crisperwhisper_amd.engine import Engine
+    with pytest.raises(_native.NativeLibraryError):
+        Engine(spec, dtype="f32", max_batch=1)
+    with pytest.raises(_native.NativeLibraryError):
+        collate.decode_asr(collate.Vocabulary.from_synthetic(v), [])
