@@ -34,6 +34,12 @@ class GenCfg(C.Structure):
                 ("begin_suppress_tokens", C.POINTER(C.c_int32)), ("n_begin_suppress", C.c_int32)]
 
 
+class TranscribeCfg(C.Structure):
+    _fields_ = [("sot_token", C.c_int32), ("language_token", C.c_int32), ("task_token", C.c_int32),
+                ("max_new_tokens", C.c_int32), ("min_new_tokens", C.c_int32), ("max_length", C.c_int32),
+                ("lang_ids", C.POINTER(C.c_int32)), ("n_lang_ids", C.c_int32)]
+
+
 _P = C.c_void_p
 _I = C.c_int32
 _SIGS = {
@@ -55,6 +61,7 @@ _SIGS = {
     "cw_set_logits_capture": (_I, [_P, _P, _I]),
     "cw_get_alignment": (_I, [_P, _P, _I, _I]),
     "cw_token_timestamps": (_I, [_P, _I, _I, _I, _P, _P]),
+    "cw_transcribe": (_I, [_P, _I, _P, C.POINTER(TranscribeCfg), _P, _P, _P, _I, _P]),
     "cw_align_matrix": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "cw_dtw": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "cw_adjust_pauses": (_I, [_P, _P, _P, _I, C.c_double]),

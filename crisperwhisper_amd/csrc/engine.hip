@@ -899,6 +899,112 @@ int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, 
     return CW_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// native seek loop
+// ------------------------------------------------------------------------------------------------
+int32_t cw_transcribe(cw_ctx* c, int32_t B, const int32_t* num_frames, const cw_transcribe_cfg* cfg, int32_t* tokens,
+                      float* token_ts, int32_t* lens, int32_t cap, int32_t* n_passes) {
+    const int TGT = c->d.max_target_positions, V = c->d.vocab_size;
+    if (B < 1 || B > c->Bm) return fail(c, CW_ERR_INVALID, "B=%d out of range (max_batch %d)", B, c->Bm);
+    if (!c->gen_set) return fail(c, CW_ERR_STATE, "cw_set_generation not called");
+    const int tb = c->gen.no_timestamps_token_id + 1;
+    const int eos = c->gen.eos_token_id, pad = c->gen.pad_token_id;
+    std::vector<std::vector<int>> prompts(B);
+    std::vector<int> all(B), zeros(B, 0), full(B, CW_N_FRAMES);
+    for (int i = 0; i < B; ++i) all[i] = i;
+    bool pre_encoded = false;
+    if (cfg->language_token >= 0) {
+        for (int i = 0; i < B; ++i) {
+            prompts[i] = {cfg->sot_token, cfg->language_token};
+            if (cfg->task_token >= 0) prompts[i].push_back(cfg->task_token);
+        }
+    } else {   // detect_language (:1610-1673): one decoder step on <|startoftranscript|>, argmax over the language ids
+        if (!cfg->lang_ids || cfg->n_lang_ids <= 0) return fail(c, CW_ERR_INVALID, "language detection needs lang_ids");
+        CWCHK(c, cw_encode(c, B, all.data(), zeros.data(), full.data()));
+        std::vector<int> sotp(B, cfg->sot_token), seq((size_t)B * TGT), ln(B);
+        CWCHK(c, cw_decode(c, B, sotp.data(), 1, 2, 0, nullptr, seq.data(), ln.data(), nullptr));
+        std::vector<float> lg((size_t)B * V);
+        CWCHK(c, cw_get_logits(c, lg.data(), B));
+        for (int i = 0; i < B; ++i) {
+            int best = cfg->lang_ids[0];
+            for (int k = 1; k < cfg->n_lang_ids; ++k) {
+                const int id = cfg->lang_ids[k];
+                const float a = lg[(size_t)i * V + id], bv = lg[(size_t)i * V + best];
+                if (a > bv || (a == bv && id < best)) best = id;
+            }
+            prompts[i] = {cfg->sot_token, best};
+            if (cfg->task_token >= 0) prompts[i].push_back(cfg->task_token);
+        }
+        pre_encoded = true;
+    }
+    const int n_prompt = (int)prompts[0].size();
+    int max_new = cfg->max_new_tokens;
+    if (max_new >= 0 && max_new + n_prompt > TGT) max_new = TGT - n_prompt;            // :1937-1942
+    const int max_length = max_new >= 0 ? n_prompt + max_new : (cfg->max_length < TGT ? cfg->max_length : TGT);
+    std::vector<long> seek(B, 0);
+    std::vector<std::vector<int>> out_tok(B);
+    std::vector<std::vector<float>> out_ts(B);
+    int passes = 0;
+    for (;;) {
+        std::vector<int> active, a_seek, a_n, a_nf;
+        for (int i = 0; i < B; ++i)
+            if (seek[i] < CW_N_FRAMES) {                                               // _maybe_reduce_batch
+                active.push_back(i); a_seek.push_back((int)seek[i]);
+                a_n.push_back((int)(CW_N_FRAMES - seek[i]));
+                a_nf.push_back((int)(num_frames[i] - seek[i]));
+            }
+        if (active.empty()) break;
+        const int nb = (int)active.size();
+        if (!(pre_encoded && passes == 0)) CWCHK(c, cw_encode(c, nb, active.data(), a_seek.data(), a_n.data()));
+        std::vector<int> prm((size_t)nb * n_prompt), seq((size_t)nb * TGT), ln(nb);
+        for (int r = 0; r < nb; ++r) for (int k = 0; k < n_prompt; ++k) prm[(size_t)r * n_prompt + k] = prompts[active[r]][k];
+        CWCHK(c, cw_decode(c, nb, prm.data(), n_prompt, max_length, cfg->min_new_tokens, nullptr, seq.data(), ln.data(), nullptr));
+        int total = 0;
+        for (int r = 0; r < nb; ++r) total = ln[r] > total ? ln[r] : total;
+        const int L = total - 1;
+        std::vector<float> ts((size_t)nb * (L + 1));
+        CWCHK(c, cw_token_timestamps(c, nb, L, n_prompt, a_nf.data(), ts.data()));
+        ++passes;
+        for (int r = 0; r < nb; ++r) {
+            const int i = active[r];
+            const int* s = seq.data() + (size_t)r * TGT + n_prompt;
+            int n = total - n_prompt;
+            if (n > 0 && s[n - 1] == pad) {                                            // strip right padding (:1060-1067)
+                int npad = 0;
+                for (int k = 0; k < n; ++k) npad += (s[k] == pad);
+                if (pad == eos) npad -= 1;
+                n -= npad;
+            }
+            if (n > 0 && s[n - 1] == eos) n -= 1;                                      // :1081-1082
+            // _retrieve_segment: keep everything up to the last *pair* of timestamp tokens, or the whole window
+            const double time_offset = (double)seek[i] * 0.02 / 2.0;
+            const float off32 = (float)time_offset;
+            const bool single_ending = n >= 2 && s[n - 2] < tb && s[n - 1] >= tb;
+            int last_pair_end = -1;                                                    // index after the pair's 1st token
+            for (int k = 0; k + 1 < n; ++k) if (s[k] >= tb && s[k + 1] >= tb) last_pair_end = k + 1;
+            int keep, advance;
+            if (last_pair_end >= 0) {
+                if (single_ending) { keep = n; advance = a_n[r]; }
+                else { keep = last_pair_end + 1; advance = (s[last_pair_end - 1] - tb) * 2; }
+            } else { keep = n; advance = a_n[r]; }
+            for (int k = 0; k < keep; ++k) {
+                out_tok[i].push_back(s[k]);
+                out_ts[i].push_back(ts[(size_t)r * (L + 1) + n_prompt + k] + off32);
+            }
+            seek[i] += advance;
+        }
+    }
+    for (int i = 0; i < B; ++i) {
+        const int n = (int)out_tok[i].size();
+        if (n > cap) return fail(c, CW_ERR_INVALID, "item %d produced %d tokens, capacity %d", i, n, cap);
+        lens[i] = n;
+        memcpy(tokens + (size_t)i * cap, out_tok[i].data(), (size_t)n * 4);
+        memcpy(token_ts + (size_t)i * cap, out_ts[i].data(), (size_t)n * 4);
+    }
+    if (n_passes) *n_passes = passes;
+    return CW_OK;
+}
+
 int32_t cw_align_matrix(cw_ctx* c, const float* attn, int32_t B, int32_t Ha, int32_t N, int32_t M, const int32_t* n_cols,
                         int32_t width, float* mat_out) {
     float *dw = nullptr, *dmean = nullptr, *dstd = nullptr, *dmat = nullptr; int* dn = nullptr;

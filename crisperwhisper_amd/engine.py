@@ -183,6 +183,33 @@ class Engine:
         self._chk(self.lib.cw_get_alignment(self.ctx, _ptr(out), nb, L))
         return out
 
+    def transcribe(self, nb: int, num_frames, *, sot: int, language_token: int = -1, task_token: int = -1,
+                   max_new_tokens: int = -1, min_new_tokens: int = 0, max_length: int = 448, lang_ids=None):
+        """Native seek loop (cw_transcribe) over the nb resident feature items: returns (tokens, timestamps, passes),
+        the per-item concatenated segment tokens (int64) and absolute token timestamps (float32)."""
+        nf = _i32(num_frames)
+        lids = _i32(lang_ids if lang_ids is not None else [])
+        cfg = N.TranscribeCfg(sot, language_token, task_token, max_new_tokens, min_new_tokens, max_length,
+                              lids.ctypes.data_as(C.POINTER(C.c_int32)), len(lids))
+        # a 30 s window can be re-decoded at most once per 0.02 s of progress; 4 full-length passes is far above
+        # what the seek loop can emit before running out of frames with real timestamps, and the call fails loudly
+        # (never truncates) if an item exceeds it
+        cap = 4 * self.spec.max_target_positions
+        while True:
+            toks = np.zeros((nb, cap), dtype=np.int32)
+            ts = np.zeros((nb, cap), dtype=np.float32)
+            lens = np.zeros(nb, dtype=np.int32)
+            passes = C.c_int32(0)
+            rc = self.lib.cw_transcribe(self.ctx, nb, _ptr(nf), C.byref(cfg), _ptr(toks), _ptr(ts), _ptr(lens), cap,
+                                        C.byref(passes))
+            if rc != 0 and b"capacity" in (self.lib.cw_last_error(self.ctx) or b"") and cap < (1 << 20):
+                cap *= 4
+                continue
+            self._chk(rc)
+            break
+        return ([toks[i, :lens[i]].astype(np.int64) for i in range(nb)], [ts[i, :lens[i]].copy() for i in range(nb)],
+                int(passes.value))
+
     def token_timestamps(self, nb: int, L: int, n_prompt: int, num_frames) -> np.ndarray:
         nf = _i32(num_frames)
         out = np.zeros((nb, L + 1), dtype=np.float32)

@@ -98,16 +98,42 @@ def split_segments(seq: np.ndarray, token_ts: np.ndarray, time_offset: float, ti
 
 def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str], task: Optional[str] = None,
              max_new_tokens: Optional[int] = None, min_new_tokens: Optional[int] = None,
-             num_beams: Optional[int] = 1, stats: Optional[dict] = None):
+             num_beams: Optional[int] = 1, stats: Optional[dict] = None, native: Optional[bool] = None):
     """Transcribe the ``n_items`` 30 s feature windows resident in the engine (items 0..n-1).
 
     Returns {"sequences": [B, Lmax] int64 (pad-right), "token_timestamps": list of float32 arrays,
-    "segments": list of list of Segment} -- the fields the pipeline consumes."""
+    "segments": list of list of Segment (host loop only)} -- the fields the pipeline consumes.
+
+    ``native`` (default: whenever the engine exports it) runs the seek loop inside the library
+    (``cw_transcribe``, one C call per batch); ``native=False`` runs the same control flow here, stage by stage
+    over ``cw_encode`` / ``cw_decode`` / ``cw_token_timestamps`` -- the two are tested to agree exactly."""
     spec = engine.spec
     if num_beams not in (None, 1):
         raise ValueError("the native path implements greedy decoding only: pass generate_kwargs={'num_beams': 1} "
                          "(transformers 5.x pipelines default to 5 beams; the 2024 reference was greedy)")
     num_frames = np.asarray(num_frames, dtype=np.int64)
+    if native is None:
+        native = hasattr(engine, "transcribe")
+    if native:
+        if language is None:
+            if not spec.lang_to_id:
+                raise ValueError("Cannot detect language for an English-only checkpoint: the generation config has no `lang_to_id`.")
+            if task is not None and task not in spec.task_to_id:
+                raise ValueError(f"The `{task}` task is not supported. The task should be one of `{sorted(spec.task_to_id)}`")
+            lang_tok, task_tok = -1, (spec.task_to_id[task] if task is not None else -1)
+        else:
+            _, lang_tok, task_tok = init_tokens(spec, language, task)
+        toks, tts, n_calls = engine.transcribe(
+            n_items, num_frames, sot=spec.decoder_start_token_id, language_token=lang_tok, task_token=task_tok,
+            max_new_tokens=-1 if max_new_tokens is None else int(max_new_tokens), min_new_tokens=min_new_tokens or 0,
+            max_length=spec.max_length, lang_ids=sorted(set(spec.lang_to_id.values())) if spec.lang_to_id else None)
+        if stats is not None:
+            stats["generate_calls"] = stats.get("generate_calls", 0) + n_calls
+        width = max((len(s) for s in toks), default=0)
+        sequences = np.full((n_items, width), spec.pad_token_id, dtype=np.int64)
+        for i, s in enumerate(toks):
+            sequences[i, :len(s)] = s
+        return {"sequences": sequences, "token_timestamps": tts, "segments": None}
     pre_encoded = False
     if language is None:
         # language auto-detection (the reference does not pass `language`, REF/transcribe.py:33)

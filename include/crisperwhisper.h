@@ -99,6 +99,24 @@ int32_t cw_get_logits(cw_ctx* ctx, float* out /* [nb][vocab] */, int32_t nb);   
 int32_t cw_set_logits_capture(cw_ctx* ctx, float* host_buf, int32_t max_steps);    /* [steps][nb][vocab] */
 int32_t cw_get_alignment(cw_ctx* ctx, float* out /* [nb][n_align][L][1500] */, int32_t nb, int32_t L);
 
+/* cw_transcribe: the whole of WhisperGenerationMixin.generate(return_timestamps=True, return_token_timestamps=True)
+ * for the B feature items resident after cw_mel -- init tokens incl. language detection (:1455-1608, :1610-1673,
+ * reusing the first encoder pass), the seek loop with batch shrinking (:785-903), eos/pad stripping (:1060-1082),
+ * _retrieve_segment (:1977-2074) -- on top of cw_encode / cw_decode / cw_token_timestamps.  Greedy, no fallback.
+ * Output per item: the concatenated segment tokens and their absolute token timestamps (what the pipeline hands to
+ * _decode_asr, TF/pipelines/automatic_speech_recognition.py:529-540): tokens/token_ts [B][cap], lens [B].          */
+typedef struct {
+    int32_t sot_token;               /* decoder_start_token_id (<|startoftranscript|>)                             */
+    int32_t language_token;          /* e.g. id of <|en|>; -1: detect per item                                   */
+    int32_t task_token;              /* id of <|transcribe|> / <|translate|>; -1: none (only valid with detection) */
+    int32_t max_new_tokens;          /* -1: bounded by max_length                                                  */
+    int32_t min_new_tokens;          /* 0: none                                                                    */
+    int32_t max_length;              /* generation_config.max_length (448)                                         */
+    const int32_t* lang_ids; int32_t n_lang_ids;   /* generation_config.lang_to_id values (for detection)         */
+} cw_transcribe_cfg;
+int32_t cw_transcribe(cw_ctx* ctx, int32_t B, const int32_t* num_frames, const cw_transcribe_cfg* cfg,
+                      int32_t* tokens, float* token_ts, int32_t* lens, int32_t cap, int32_t* n_passes);
+
 /* cw_token_timestamps: _extract_token_timestamps (generation_whisper.py:241-381) on the retained rows:
  * crop to num_frames[b]//2 encoder frames, drop the n_prompt prompt rows, z-score over tokens, median
  * filter, head mean, DTW, jump times.  L = rows retained = max(lengths) - 1.  ts_out [nb][L+1] seconds. */

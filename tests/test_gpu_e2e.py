@@ -287,3 +287,26 @@ def test_live_transformers_pipeline_parity_on_fresh_inputs(seed):
     assert out["text"] == ref["text"]
     ok, why = Hh.words_equal(out["chunks"], [{"text": c["text"], "timestamp": list(c["timestamp"])} for c in ref["chunks"]], tol=0.02)
     assert ok, why
+
+
+@pytest.mark.parametrize("language,task,kw", [
+    ("<|en|>", "transcribe", dict(max_new_tokens=40)),
+    ("<|en|>", "transcribe", dict()),
+    (None, None, dict(max_new_tokens=24)),
+    (None, "transcribe", dict(max_new_tokens=24, min_new_tokens=8)),
+])
+def test_native_seek_loop_equals_host_loop(tiny, eng_f32, language, task, kw):
+    """cw_transcribe (seek loop inside the library) against the stage-by-stage host loop in generation.generate:
+    identical token ids and bit-identical token timestamps, same number of passes."""
+    from crisperwhisper_amd import generation
+    g, v, W, spec = tiny
+    clips = [syn.synth_audio(60 + i, n, kind) for i, (n, kind) in
+             enumerate([(480000, "mixed"), (130000, "noise"), (300001, "chirp"), (1600, "noise")])]
+    _, nf = eng_f32.mel(clips)
+    sa, sb = {}, {}
+    a = generation.generate(eng_f32, len(clips), nf, language=language, task=task, stats=sa, native=True, **kw)
+    b = generation.generate(eng_f32, len(clips), nf, language=language, task=task, stats=sb, native=False, **kw)
+    assert sa == sb
+    assert np.array_equal(a["sequences"], b["sequences"])
+    for x, y in zip(a["token_timestamps"], b["token_timestamps"]):
+        assert x.dtype == np.float32 and np.array_equal(x, y)
