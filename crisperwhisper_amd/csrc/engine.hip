@@ -62,6 +62,7 @@ struct cw_ctx {
 
     // decoder state
     float *dx = nullptr, *dxn = nullptr, *dq = nullptr, *dattn = nullptr, *dmid = nullptr, *dlogits = nullptr;
+    void* d_xfrag = nullptr;             // bf16 [64][5120] fragment-major activations of the 17..64-row GEMV path
     int *d_ids = nullptr, *d_forced = nullptr, *d_argmax = nullptr, *d_last_ts = nullptr, *d_finished = nullptr,
         *d_nunf = nullptr, *d_align_slot = nullptr;
     unsigned char* d_mask = nullptr;
@@ -324,6 +325,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->dx, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dxn, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->dq, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dattn, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->dmid, (size_t)Bm * F * 4));
+    CWCHK(c, dmalloc(c, &c->d_xfrag, (size_t)64 * 5120 * 2));
     c->Vpad = (V + 3) & ~3;
     CWCHK(c, dmalloc(c, &c->dlogits, (size_t)Bm * c->Vpad * 4));
     CWCHK(c, dmalloc(c, &c->d_ids, (size_t)Bm * TGT * 4)); CWCHK(c, dmalloc(c, &c->d_forced, (size_t)Bm * TGT * 4));
@@ -628,7 +630,7 @@ int32_t cw_get_encoder_output(cw_ctx* c, float* out, int32_t nb) {
 // ------------------------------------------------------------------------------------------------
 static int gemv_ln(cw_ctx* c, int epi, const float* x, int Mb, int K, const void* W, int N, const float* g,
                    const float* b, const EpiParams& ep) {
-    if (c->bf16 || !g) return cw_launch_gemv(c->bf16, epi, x, Mb, K, W, N, g, b, ep, c->st);
+    if (c->bf16 || !g) return cw_launch_gemv(c->bf16, epi, x, Mb, K, W, N, g, b, ep, c->st, nullptr, c->d_xfrag);
     int r = cw_launch_layernorm_f32(x, g, b, c->dxn, Mb, K, c->st);   // f32 parity mode: unfused LN
     if (r != CW_OK) return r;
     return cw_launch_gemv(false, epi, c->dxn, Mb, K, W, N, nullptr, nullptr, ep, c->st);
@@ -665,7 +667,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             CWCHK(c, cw_launch_attn_cross_split(true, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CombineParams cb{c->d_part_ml, H, nb * D};
-            CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb));
+            CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
         } else {
             DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn,
                             c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_slot + (size_t)l * H,
@@ -1108,7 +1110,7 @@ int32_t cw_test_gemv(cw_ctx* c, int32_t Mb, int32_t N, int32_t K, const float* x
     const float* xin = dx;
     if (ln_g && !c->bf16) { r = cw_launch_layernorm_f32(dx, dg, db, dxn, Mb, K, c->st); xin = dxn; }
     if (r == CW_OK) r = cw_launch_gemv(c->bf16, gelu ? EPI_GELU_F32 : EPI_STORE_F32, xin, Mb, K, dW, N,
-                                        (ln_g && c->bf16) ? dg : nullptr, (ln_g && c->bf16) ? db : nullptr, ep, c->st);
+                                        (ln_g && c->bf16) ? dg : nullptr, (ln_g && c->bf16) ? db : nullptr, ep, c->st, nullptr, c->d_xfrag);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemv: %s", hipGetErrorString(er)); }
     else fail(c, r, "test_gemv: launch rejected (Mb=%d N=%d K=%d)", Mb, N, K);
     if (r == CW_OK) { hipError_t er = hipMemcpy(out, dO, (size_t)Mb * N * 4, hipMemcpyDeviceToHost); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemv copy"); }

@@ -649,6 +649,162 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Decode GEMV for 17..64 batch rows: weights streamed ONCE for all rows (the row-group loop above re-streams
+// them per 16 rows).  Two launches:
+//   gemv_prep_kernel   one block per batch row: attention-partial combine / LayerNorm (both optional), round to
+//                      bf16 and park the row in MFMA *fragment-major* order
+//                          xf[((mt * K/32 + ks) * 64 + lane) * 8 + e],  lane = g*16 + l15,
+//                          row = mt*16 + l15, k = ks*32 + g*8 + e
+//                      so that a wave's A operand is one fully coalesced 1 KB read;
+//   gemv_mt_kernel     grid (ceil(N/16), KSPLIT): per wave K steps wave, wave+4, ..; per step 4 weight
+//                      fragments, each used by MT MFMAs whose A fragments come straight from xf (L2 resident,
+//                      no LDS staging, no barrier before the MFMAs); cross-wave reduction through LDS.
+// ---------------------------------------------------------------------------------------------------
+template <bool COMBINE>
+__global__ __launch_bounds__(256) void gemv_prep_kernel(const float* __restrict__ x, int K,
+                                                        const float* __restrict__ ln_g,
+                                                        const float* __restrict__ ln_b, CombineParams cb,
+                                                        bf16_t* __restrict__ xf) {
+    __shared__ float s_red[8];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int nvec = K >> 2;
+    float4 v[5];                                               // K <= 5120
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int v4 = tid + 256 * c;
+        v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v4 < nvec) {
+            const size_t off = (size_t)m * K + v4 * 4;
+            if (!COMBINE) {
+                v[c] = *(const float4*)(x + off);
+            } else {
+                const int head = (v4 * 4) >> 6;
+                const float* ml = cb.part_ml + ((size_t)m * cb.H + head) * ATT_NS * 2;
+                float mm[ATT_NS], ll[ATT_NS], M = -INFINITY;
+#pragma unroll
+                for (int sI = 0; sI < ATT_NS; ++sI) { mm[sI] = ml[2 * sI]; ll[sI] = ml[2 * sI + 1]; M = fmaxf(M, mm[sI]); }
+                float L = 0.f;
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int sI = 0; sI < ATT_NS; ++sI) {
+                    const float w = __expf(mm[sI] - M);
+                    const float4 o = *(const float4*)(x + (size_t)sI * cb.plane + off);
+                    L += ll[sI] * w;
+                    r.x += w * o.x; r.y += w * o.y; r.z += w * o.z; r.w += w * o.w;
+                }
+                const float inv = 1.0f / L;
+                v[c] = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
+            }
+        }
+    }
+    if (ln_g) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);   // out-of-range slots hold zeros
+        const float mean = block_sum(s, s_red) / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            if (tid + 256 * c < nvec) {
+                const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        const float rstd = 1.0f / sqrtf(block_sum(q, s_red) / (float)K + 1e-5f);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int v4 = tid + 256 * c;
+            if (v4 < nvec) {
+                const float4 gq = *(const float4*)(ln_g + v4 * 4), bq = *(const float4*)(ln_b + v4 * 4);
+                v[c].x = (v[c].x - mean) * rstd * gq.x + bq.x;
+                v[c].y = (v[c].y - mean) * rstd * gq.y + bq.y;
+                v[c].z = (v[c].z - mean) * rstd * gq.z + bq.z;
+                v[c].w = (v[c].w - mean) * rstd * gq.w + bq.w;
+            }
+        }
+    }
+    const int mt = m >> 4, l15 = m & 15, KS = K >> 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int v4 = tid + 256 * c;
+        if (v4 < nvec) {
+            const int k = v4 * 4, ks = k >> 5, g = (k & 31) >> 3, e = k & 7;
+            ushort4 o;
+            o.x = f32_to_bf16(v[c].x); o.y = f32_to_bf16(v[c].y); o.z = f32_to_bf16(v[c].z); o.w = f32_to_bf16(v[c].w);
+            *(ushort4*)(xf + (((size_t)mt * KS + ks) * 64 + g * 16 + l15) * 8 + e) = o;
+        }
+    }
+}
+
+template <int EPI, int MT, bool ATOMIC, int NSLOT>
+__global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__ xf, int Mb, int K, int Kb,
+                                                      const bf16_t* __restrict__ W, int N, EpiParams ep) {
+    __shared__ float red[4 * MT * 4 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kbase = blockIdx.y * Kb;
+    const int steps = Kb >> 7, KS = K >> 5;
+    const int n = n0 + l15;
+    const int nc = n < N ? n : N - 1;
+    const float bias_v = ep.bias ? ep.bias[nc] : 0.f;
+
+    u32x4_t wq[NSLOT][4];
+    const bf16_t* wrow = W + (size_t)nc * K + kbase + g * 8;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        int step = wave + 4 * s;
+        step = step < steps ? step : steps - 1;               // clamped (unconditional) load, zeroed below
+        const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * 4];
+    }
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const u32x4_t* xq = (const u32x4_t*)xf;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int step_raw = wave + 4 * s;
+        const bool live = step_raw < steps;                    // wave-uniform
+        const int step = live ? step_raw : steps - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4_t w = wq[s][j];
+            if (!live) w = (u32x4_t){0u, 0u, 0u, 0u};          // a dead slot contributes exactly zero
+            const int ks = (kbase >> 5) + step * 4 + j;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const u32x4_t a = xq[((size_t)t * KS + ks) * 64 + lane];
+                acc[t] = mfma16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, w), acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * MT + t) * 4 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    const int r = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[((w * MT + t) * 4 + r) * 64 + lane];
+        const int m = t * 16 + g * 4 + r;
+        if (m < Mb && n < N) {
+            if (ATOMIC) {
+                atomicAdd(ep.outf + (size_t)m * ep.ldo + n, v + (blockIdx.y == 0 ? bias_v : 0.f));
+            } else {
+                EpiParams e2 = ep;
+                e2.bias = nullptr;
+                epi_store1<bf16_t, EPI>(e2, m, n, v + bias_v);
+            }
+        }
+    }
+}
+
 // f32 parity GEMV: one wave per output column, x read from global (L2 resident); LN is applied by a
 // separate kernel in f32 mode (ln_g must be null here).
 template <int EPI>
@@ -778,9 +934,61 @@ static bool gemv2_ok(int epi, int Mb, int K, const float* ln_g, const EpiParams&
     return (K % ks == 0) && ((K / ks) % 128 == 0);
 }
 
+template <int EPI, int MT>
+static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N, const EpiParams& ep, bool allow_split,
+                           hipStream_t st) {
+    int ksplit = 1;
+    if (EPI == EPI_RESID_F32 && allow_split) {
+        const int tiles = (N + 15) / 16, steps = K / 128;
+        while (tiles * ksplit < 256 && steps % (ksplit * 2) == 0 && steps / (ksplit * 2) >= 4) ksplit *= 2;
+    }
+    while (K / ksplit > 1280) ksplit *= 2;
+    const int Kb = K / ksplit;
+    dim3 grid((N + 15) / 16, ksplit);
+    const bool atomic = EPI == EPI_RESID_F32 && ksplit > 1;
+#define CW_MT_LAUNCH(NS)                                                                                              \
+    do {                                                                                                              \
+        if (atomic)                                                                                                   \
+            hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, MT, true, NS>), grid, dim3(256), 0, st, xf, Mb, K, Kb,   \
+                               (const bf16_t*)W, N, ep);                                                              \
+        else                                                                                                          \
+            hipLaunchKernelGGL((gemv_mt_kernel<EPI, MT, false, NS>), grid, dim3(256), 0, st, xf, Mb, K, Kb,            \
+                               (const bf16_t*)W, N, ep);                                                              \
+    } while (0)
+    const int steps = Kb / 128;
+    if (steps <= 4) CW_MT_LAUNCH(1);
+    else if (steps <= 8) CW_MT_LAUNCH(2);
+    else CW_MT_LAUNCH(3);
+#undef CW_MT_LAUNCH
+}
+
+// Mb in 17..64, bf16: prep (combine / LayerNorm -> bf16 fragments in `scratch`) + one weight pass for all rows
+template <int EPI>
+static int launch_gemv_large(const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b,
+                             const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch) {
+    if (K > 5120 || K % 128 != 0) return CW_ERR_INVALID;
+    bf16_t* xf = (bf16_t*)scratch;
+    CombineParams cb{nullptr, 0, 0};
+    if (comb) cb = *comb;
+    if (cb.part_ml) hipLaunchKernelGGL((gemv_prep_kernel<true>), dim3(Mb), dim3(256), 0, st, x, K, ln_g, ln_b, cb, xf);
+    else hipLaunchKernelGGL((gemv_prep_kernel<false>), dim3(Mb), dim3(256), 0, st, x, K, ln_g, ln_b, cb, xf);
+    // the K split needs the in-place residual epilogue (partials accumulate into the residual stream)
+    const bool allow_split = EPI == EPI_RESID_F32 && ep.outf == ep.resid;
+    int ks = 1;
+    while (K / ks > 1280) ks *= 2;
+    if (ks > 1 && (!allow_split || K % ks != 0 || (K / ks) % 128 != 0)) return CW_ERR_INVALID;
+    const int MT = (Mb + 15) / 16;
+    if (MT == 2) launch_gemv_mt<EPI, 2>(xf, Mb, K, W, N, ep, allow_split, st);
+    else if (MT == 3) launch_gemv_mt<EPI, 3>(xf, Mb, K, W, N, ep, allow_split, st);
+    else launch_gemv_mt<EPI, 4>(xf, Mb, K, W, N, ep, allow_split, st);
+    return CW_OK;
+}
+
 template <int EPI>
 static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
-                           const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb) {
+                           const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb,
+                           void* scratch) {
+    if (bf16 && Mb > 16 && scratch) return launch_gemv_large<EPI>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
     if (comb && !(bf16 && gemv2_ok(EPI, Mb, K, ln_g, ep) && EPI == EPI_RESID_F32)) return CW_ERR_INVALID;
     if (bf16) {
         if (gemv2_ok(EPI, Mb, K, ln_g, ep)) {
@@ -808,13 +1016,13 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
 }
 
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
-                   const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb) {
+                   const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch) {
     if (Mb <= 0 || Mb > GV_MAXM || K % 128 != 0) return CW_ERR_INVALID;
     switch (epi) {
-        case EPI_GELU_F32: return launch_gemv_epi<EPI_GELU_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
-        case EPI_RESID_F32: return launch_gemv_epi<EPI_RESID_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
-        case EPI_STORE_F32: return launch_gemv_epi<EPI_STORE_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
-        case EPI_QKV_CACHE: return launch_gemv_epi<EPI_QKV_CACHE>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb);
+        case EPI_GELU_F32: return launch_gemv_epi<EPI_GELU_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
+        case EPI_RESID_F32: return launch_gemv_epi<EPI_RESID_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
+        case EPI_STORE_F32: return launch_gemv_epi<EPI_STORE_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
+        case EPI_QKV_CACHE: return launch_gemv_epi<EPI_QKV_CACHE>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
         default: return CW_ERR_INVALID;
     }
 }

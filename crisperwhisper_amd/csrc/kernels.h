@@ -16,7 +16,8 @@ int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, 
                    hipStream_t st);
 struct CombineParams;
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
-                   const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr);
+                   const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr,
+                   void* scratch = nullptr /* bf16 [64][5120]: enables the one-pass path for 17..64 rows */);
 
 // elementwise.hip
 int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d,
