@@ -342,7 +342,8 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
     if (tid < 64) {
         float r = 0.f;
         for (int gI = 0; gI < DEC_GROUPS; ++gI) r += red[gI * 64 + tid];
-        p.out[(size_t)b * p.H * 64 + h * 64 + tid] = r;
+        if (p.out_frag) p.out_frag[frag_index(b, h * 64 + tid, p.H * 64)] = f32_to_bf16(r);
+        else p.out[(size_t)b * p.H * 64 + h * 64 + tid] = r;
     }
 }
 

@@ -91,6 +91,7 @@ enum EpiMode {
     EPI_STORE_F32 = 5,   // outf[m][n] = acc + bias                            (logits, q vectors)
     EPI_QKV_CACHE = 6,   // decode: which==0 -> outf[m][n] (q, f32); 1/2 -> self-KV cache row `pos`
     EPI_GELU_F32 = 7,    // outf[m][n] = gelu(acc + bias)                      (decode MLP mid)
+    EPI_GELU_FRAG = 8,   // bf16 gelu(acc + bias) in MFMA fragment-major order (gemm.hip, 17..64-row decode GEMV), K' = ldo
 };
 
 struct EpiParams {
@@ -108,6 +109,12 @@ struct EpiParams {
     int d_model;          // columns per `which`
     const int* row_pos;   // EPI_QKV_CACHE: [batch] device array, cache row to write for each batch row
 };
+
+// MFMA 16x16x32 A-operand fragment-major position of activation (row m, column k) of a [rows][K] matrix:
+// xf[((mt * K/32 + ks) * 64 + g*16 + l15) * 8 + e], row = mt*16 + l15, k = ks*32 + g*8 + e.
+__host__ __device__ inline size_t frag_index(int m, int k, int K) {
+    return (((size_t)(m >> 4) * (K >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (m & 15)) * 8 + (k & 7);
+}
 
 template <typename T, int MODE>
 __device__ inline void epi_store1(const EpiParams& p, int m, int n, float acc) {
@@ -131,6 +138,8 @@ __device__ inline void epi_store1(const EpiParams& p, int m, int n, float acc) {
         p.outf[(size_t)m * p.ldo + n] = v;
     } else if (MODE == EPI_GELU_F32) {
         p.outf[(size_t)m * p.ldo + n] = gelu_erf(v);
+    } else if (MODE == EPI_GELU_FRAG) {
+        ((unsigned short*)p.out)[frag_index(m, n, p.ldo)] = f32_to_bf16(gelu_erf(v));
     } else if (MODE == EPI_QKV_CACHE) {
         int which = n / p.d_model, r = n - which * p.d_model;
         if (which == 0) {

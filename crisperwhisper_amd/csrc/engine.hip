@@ -62,7 +62,7 @@ struct cw_ctx {
 
     // decoder state
     float *dx = nullptr, *dxn = nullptr, *dq = nullptr, *dattn = nullptr, *dmid = nullptr, *dlogits = nullptr;
-    void* d_xfrag = nullptr;             // bf16 [64][5120] fragment-major activations of the 17..64-row GEMV path
+    void *d_xfrag = nullptr, *d_xfrag2 = nullptr;             // bf16 [64][5120] fragment-major activations of the 17..64-row GEMV path
     int *d_ids = nullptr, *d_forced = nullptr, *d_argmax = nullptr, *d_last_ts = nullptr, *d_finished = nullptr,
         *d_nunf = nullptr, *d_align_slot = nullptr;
     unsigned char* d_mask = nullptr;
@@ -326,6 +326,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->dq, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dattn, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->dmid, (size_t)Bm * F * 4));
     CWCHK(c, dmalloc(c, &c->d_xfrag, (size_t)64 * 5120 * 2));
+    CWCHK(c, dmalloc(c, &c->d_xfrag2, (size_t)64 * 5120 * 2));
     c->Vpad = (V + 3) & ~3;
     CWCHK(c, dmalloc(c, &c->dlogits, (size_t)Bm * c->Vpad * 4));
     CWCHK(c, dmalloc(c, &c->d_ids, (size_t)Bm * TGT * 4)); CWCHK(c, dmalloc(c, &c->d_forced, (size_t)Bm * TGT * 4));
@@ -640,6 +641,8 @@ static int gemv_ln(cw_ctx* c, int epi, const float* x, int Mb, int K, const void
 static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, V = c->d.vocab_size;
     const int TGT = c->d.max_target_positions;
+    // 17..64 rows (bf16): producers hand activations to the next GEMV already in MFMA fragment order (no prep launch)
+    const bool frag = c->bf16 && nb > 16;
     for (int l = 0; l < c->d.dec_layers; ++l) {
         LayerW& L = c->dec[l];
         {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
@@ -648,12 +651,13 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, L.ln1_b, ep));
         }
         {
-            DecAttnParams p{c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nullptr, nullptr, 0, 0, nb, H};
+            DecAttnParams p{c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, frag ? (unsigned short*)c->d_xfrag2 : nullptr, nullptr, nullptr, 0, 0, nb, H};
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
-            CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));
+            if (frag) CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
+            else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));
         }
         {   // cross-attention: LN + q projection, attention over the cached encoder K/V
             EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
@@ -669,7 +673,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             CombineParams cb{c->d_part_ml, H, nb * D};
             CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
         } else {
-            DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn,
+            DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn, nullptr,
                             c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_slot + (size_t)l * H,
                             c->d.n_align, TGT, nb, H};
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
@@ -677,12 +681,13 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo_c, D, nullptr, nullptr, ep));
         }
         {
-            EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
-            CWCHK(c, gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep));
+            EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
+            CWCHK(c, gemv_ln(c, frag ? EPI_GELU_FRAG : EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep));
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.b2; ep.ldo = D;
-            CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
+            if (frag) CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
+            else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
         }
     }
     if (want_logits) {   // final LN + tied proj_out (:790, :1080), logits in f32 (utils.py:2894)

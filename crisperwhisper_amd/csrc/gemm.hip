@@ -699,6 +699,12 @@ __global__ __launch_bounds__(256) void gemv_prep_kernel(const float* __restrict_
         }
     }
     if (ln_g) {
+        float4 gq[5], bq[5];                                   // issued before the reductions
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int v4 = min(tid + 256 * c, nvec - 1);
+            gq[c] = *(const float4*)(ln_g + v4 * 4); bq[c] = *(const float4*)(ln_b + v4 * 4);
+        }
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 5; ++c) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);   // out-of-range slots hold zeros
@@ -715,23 +721,21 @@ __global__ __launch_bounds__(256) void gemv_prep_kernel(const float* __restrict_
         for (int c = 0; c < 5; ++c) {
             const int v4 = tid + 256 * c;
             if (v4 < nvec) {
-                const float4 gq = *(const float4*)(ln_g + v4 * 4), bq = *(const float4*)(ln_b + v4 * 4);
-                v[c].x = (v[c].x - mean) * rstd * gq.x + bq.x;
-                v[c].y = (v[c].y - mean) * rstd * gq.y + bq.y;
-                v[c].z = (v[c].z - mean) * rstd * gq.z + bq.z;
-                v[c].w = (v[c].w - mean) * rstd * gq.w + bq.w;
+                v[c].x = (v[c].x - mean) * rstd * gq[c].x + bq[c].x;
+                v[c].y = (v[c].y - mean) * rstd * gq[c].y + bq[c].y;
+                v[c].z = (v[c].z - mean) * rstd * gq[c].z + bq[c].z;
+                v[c].w = (v[c].w - mean) * rstd * gq[c].w + bq[c].w;
             }
         }
     }
-    const int mt = m >> 4, l15 = m & 15, KS = K >> 5;
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         const int v4 = tid + 256 * c;
         if (v4 < nvec) {
-            const int k = v4 * 4, ks = k >> 5, g = (k & 31) >> 3, e = k & 7;
+            const int k = v4 * 4;
             ushort4 o;
             o.x = f32_to_bf16(v[c].x); o.y = f32_to_bf16(v[c].y); o.z = f32_to_bf16(v[c].z); o.w = f32_to_bf16(v[c].w);
-            *(ushort4*)(xf + (((size_t)mt * KS + ks) * 64 + g * 16 + l15) * 8 + e) = o;
+            *(ushort4*)(xf + frag_index(m, k, K)) = o;
         }
     }
 }
@@ -970,7 +974,9 @@ static int launch_gemv_large(const float* x, int Mb, int K, const void* W, int N
     bf16_t* xf = (bf16_t*)scratch;
     CombineParams cb{nullptr, 0, 0};
     if (comb) cb = *comb;
-    if (cb.part_ml) hipLaunchKernelGGL((gemv_prep_kernel<true>), dim3(Mb), dim3(256), 0, st, x, K, ln_g, ln_b, cb, xf);
+    if (!x) {                                                  // producer already wrote the fragments into `scratch`
+        if (ln_g || cb.part_ml) return CW_ERR_INVALID;
+    } else if (cb.part_ml) hipLaunchKernelGGL((gemv_prep_kernel<true>), dim3(Mb), dim3(256), 0, st, x, K, ln_g, ln_b, cb, xf);
     else hipLaunchKernelGGL((gemv_prep_kernel<false>), dim3(Mb), dim3(256), 0, st, x, K, ln_g, ln_b, cb, xf);
     // the K split needs the in-place residual epilogue (partials accumulate into the residual stream)
     const bool allow_split = EPI == EPI_RESID_F32 && ep.outf == ep.resid;
@@ -1018,8 +1024,12 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
                    const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch) {
     if (Mb <= 0 || Mb > GV_MAXM || K % 128 != 0) return CW_ERR_INVALID;
+    if (!x && !(bf16 && Mb > 16 && scratch)) return CW_ERR_INVALID;
     switch (epi) {
         case EPI_GELU_F32: return launch_gemv_epi<EPI_GELU_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
+        case EPI_GELU_FRAG:
+            if (!(bf16 && Mb > 16 && scratch)) return CW_ERR_INVALID;
+            return launch_gemv_large<EPI_GELU_FRAG>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
         case EPI_RESID_F32: return launch_gemv_epi<EPI_RESID_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
         case EPI_STORE_F32: return launch_gemv_epi<EPI_STORE_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
         case EPI_QKV_CACHE: return launch_gemv_epi<EPI_QKV_CACHE>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);

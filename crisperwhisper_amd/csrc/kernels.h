@@ -62,6 +62,7 @@ struct DecAttnParams {
     int n_keys;            // keys to attend over when `pos` is null
     const int* pos;        // device [B]: decoder input position; self-attention uses n_keys = pos[b] + 1
     float* out;            // [B][H*64] f32
+    unsigned short* out_frag;  // non-null: write bf16 in MFMA fragment-major order instead (frag_index, K = H*64)
     float* align_out;      // [B][n_align][align_rows][S] or null
     const int* align_slot; // [H] slot index of each head in this layer (or -1), device
     int n_align, align_rows;            // alignment row written = pos[b]
