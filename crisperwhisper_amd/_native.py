@@ -60,6 +60,9 @@ _SIGS = {
     "cw_get_logits": (_I, [_P, _P, _I]),
     "cw_set_logits_capture": (_I, [_P, _P, _I]),
     "cw_get_alignment": (_I, [_P, _P, _I, _I]),
+    "cw_resampled_length": (C.c_int64, [C.c_int64, _I, _I]),
+    "cw_ingest": (_I, [_P, _P, _I, _I, C.c_int64, _I, _I, _I, _P]),
+    "cw_resample_taps": (_I, [_I, _I, _P, _I, _P, _P, _P]),
     "cw_token_timestamps": (_I, [_P, _I, _I, _I, _P, _P]),
     "cw_transcribe": (_I, [_P, _I, _P, C.POINTER(TranscribeCfg), _P, _P, _P, _I, _P]),
     "cw_align_matrix": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),

@@ -2,12 +2,15 @@
 
 ``chunk_windows`` follows TF/pipelines/automatic_speech_recognition.py:61-84 (chunk_iter) and
 :432-448 (chunk/stride lengths): 30 s windows, chunk_length_s/6 stride each side, hop = chunk - 2*stride.
-``read_audio`` replaces the ffmpeg subprocess of TF/pipelines/audio_utils.py:9-45 for WAV input
-(ffmpeg is not required; other containers raise like the reference does when ffmpeg is missing).
+``read_audio`` / ``decode_wav_bytes`` replace the ffmpeg subprocess of TF/pipelines/audio_utils.py:9-45 for WAV
+input: the RIFF container is parsed here (integer header fields only); sample decoding, mono mixdown and resampling
+run on the device (``cw_ingest``, csrc/ingest.hip).  ``resample`` is ``torchaudio.functional.resample`` with its
+defaults (TF/pipelines/automatic_speech_recognition.py:398-412), on the device as well.  Other containers raise like
+the reference does when ffmpeg is missing.
 """
 from __future__ import annotations
 
-import io
+import struct
 from typing import List, Tuple
 
 import numpy as np
@@ -34,33 +37,65 @@ def chunk_windows(n_samples: int, chunk_len: int, stride_left: int, stride_right
     return out
 
 
-def resample(x: np.ndarray, sr_in: int, sr_out: int = SAMPLING_RATE) -> np.ndarray:
-    if sr_in == sr_out:
+PCM_U8, PCM_S16, PCM_S24, PCM_S32, PCM_F32, PCM_F64 = range(6)
+_NP_FMT = {np.dtype(np.uint8): PCM_U8, np.dtype(np.int16): PCM_S16, np.dtype(np.int32): PCM_S32,
+           np.dtype(np.float32): PCM_F32, np.dtype(np.float64): PCM_F64}
+_MALFORMED = ("Soundfile is either not in the correct format or is malformed. Only RIFF/WAV input is decoded natively "
+              "(the reference needs ffmpeg for anything else).")
+
+
+def parse_wav(data: bytes):
+    """RIFF/WAVE container -> (fmt code, channels, sample rate, n_frames, payload bytes).  Handles WAVE_FORMAT_PCM (1),
+    IEEE_FLOAT (3) and EXTENSIBLE (0xFFFE, sub-format in the first two GUID bytes); chunks are word aligned."""
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(_MALFORMED)
+    pos, fmt, payload = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack_from("<I", data, pos + 4)[0]
+        body = pos + 8
+        if cid == b"fmt ":
+            if size < 16 or body + 16 > len(data):
+                raise ValueError(_MALFORMED)
+            tag, ch, sr, _, _, bits = struct.unpack_from("<HHIIHH", data, body)
+            if tag == 0xFFFE and size >= 26 and body + 26 <= len(data):
+                tag = struct.unpack_from("<H", data, body + 24)[0]
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            payload = data[body: min(body + size, len(data))]     # streamed files may overstate the size
+            break
+        pos = body + size + (size & 1)
+    if fmt is None or payload is None:
+        raise ValueError(_MALFORMED)
+    tag, ch, sr, bits = fmt
+    code = {(1, 8): PCM_U8, (1, 16): PCM_S16, (1, 24): PCM_S24, (1, 32): PCM_S32, (3, 32): PCM_F32, (3, 64): PCM_F64}.get((tag, bits))
+    if code is None or ch < 1 or sr < 1:
+        raise ValueError(_MALFORMED)
+    n_frames = len(payload) // (ch * (bits // 8))
+    if n_frames < 1:
+        raise ValueError(_MALFORMED)
+    return code, ch, sr, n_frames, payload[: n_frames * ch * (bits // 8)]
+
+
+def _need(engine):
+    if engine is None or not hasattr(engine, "ingest"):
+        raise RuntimeError("audio ingest runs on the device: pass the pipeline's Engine (there is no host fallback)")
+    return engine
+
+
+def resample(x: np.ndarray, sr_in: int, sr_out: int = SAMPLING_RATE, engine=None) -> np.ndarray:
+    if int(sr_in) == int(sr_out):
         return x
-    from math import gcd
-    from scipy.signal import resample_poly
-    g = gcd(int(sr_in), int(sr_out))
-    return resample_poly(x.astype(np.float64), sr_out // g, sr_in // g).astype(np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return _need(engine).ingest(x, PCM_F32, 1, len(x), int(sr_in), int(sr_out))
 
 
-def decode_wav_bytes(data: bytes, sampling_rate: int = SAMPLING_RATE) -> np.ndarray:
-    from scipy.io import wavfile
-    try:
-        sr, x = wavfile.read(io.BytesIO(data))
-    except Exception as e:
-        raise ValueError("Soundfile is either not in the correct format or is malformed. Only RIFF/WAV input is "
-                         "decoded natively (the reference needs ffmpeg for anything else).") from e
-    if x.dtype.kind == "i":
-        x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
-    elif x.dtype.kind == "u":
-        x = (x.astype(np.float32) - 128.0) / 128.0
-    else:
-        x = x.astype(np.float32)
-    if x.ndim == 2:
-        x = x.mean(axis=1)                      # mono mixdown
-    return resample(x, sr, sampling_rate)
+def decode_wav_bytes(data: bytes, sampling_rate: int = SAMPLING_RATE, engine=None, normalise: bool = False) -> np.ndarray:
+    """WAV bytes -> mono float32 at ``sampling_rate``.  ``normalise=True`` applies REF/app.py:85-93
+    ((y - mean) / std / 8 before resampling)."""
+    code, ch, sr, n_frames, payload = parse_wav(data)
+    return _need(engine).ingest(payload, code, ch, n_frames, sr, sampling_rate, normalise=normalise)
 
 
-def read_audio(path: str, sampling_rate: int = SAMPLING_RATE) -> np.ndarray:
+def read_audio(path: str, sampling_rate: int = SAMPLING_RATE, engine=None) -> np.ndarray:
     with open(path, "rb") as f:
-        return decode_wav_bytes(f.read(), sampling_rate)
+        return decode_wav_bytes(f.read(), sampling_rate, engine)

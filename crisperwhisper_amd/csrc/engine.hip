@@ -1080,6 +1080,101 @@ int32_t cw_adjust_pauses(cw_ctx* c, double* start, double* end, int32_t W, doubl
 }
 
 // ------------------------------------------------------------------------------------------------
+// audio ingest
+// ------------------------------------------------------------------------------------------------
+static int igcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+int64_t cw_resampled_length(int64_t n, int32_t sr_in, int32_t sr_out) {
+    if (n < 0 || sr_in <= 0 || sr_out <= 0) return -1;
+    const int g = igcd(sr_in, sr_out);
+    const int64_t o = sr_in / g, w = sr_out / g;
+    return (n * w + o - 1) / o;
+}
+
+// torchaudio's _get_sinc_resample_kernel with dtype=None (f64 arithmetic, rounded to f32 at the end): K[p][j],
+// p in 0..new-1, j in 0..2*width+orig-1
+static void resample_taps(int sr_in, int sr_out, std::vector<float>& K, int& orig, int& nw, int& width) {
+    const int g = igcd(sr_in, sr_out);
+    orig = sr_in / g; nw = sr_out / g;
+    const double lpw = 6.0, rolloff = 0.99;
+    const double base_freq = (double)(orig < nw ? orig : nw) * rolloff;
+    width = (int)ceil(lpw * orig / base_freq);
+    const int n_taps = 2 * width + orig;
+    K.assign((size_t)nw * n_taps, 0.f);
+    const double scale = base_freq / orig;
+    for (int p = 0; p < nw; ++p)
+        for (int j = 0; j < n_taps; ++j) {
+            double t = (double)(-p) / nw + (double)(j - width) / orig;
+            t *= base_freq;
+            t = t < -lpw ? -lpw : (t > lpw ? lpw : t);
+            const double c = cos(t * M_PI / lpw / 2.0);
+            const double window = c * c;
+            t *= M_PI;
+            const double sinc = t == 0.0 ? 1.0 : sin(t) / t;
+            K[(size_t)p * n_taps + j] = (float)(sinc * window * scale);
+        }
+}
+
+int32_t cw_resample_taps(int32_t sr_in, int32_t sr_out, float* taps, int32_t cap, int32_t* orig, int32_t* nw,
+                         int32_t* width) {
+    if (sr_in <= 0 || sr_out <= 0) return CW_ERR_INVALID;
+    std::vector<float> K;
+    int o, w, wd;
+    resample_taps(sr_in, sr_out, K, o, w, wd);
+    if (orig) *orig = o;
+    if (nw) *nw = w;
+    if (width) *width = wd;
+    if (taps) {
+        if ((size_t)cap < K.size()) return CW_ERR_INVALID;
+        memcpy(taps, K.data(), K.size() * 4);
+    }
+    return CW_OK;
+}
+
+int32_t cw_ingest(cw_ctx* c, const void* raw, int32_t fmt, int32_t channels, int64_t n_frames, int32_t sr_in,
+                  int32_t sr_out, int32_t normalise, float* out) {
+    static const int bytes_of[] = {1, 2, 3, 4, 4, 8};
+    if (fmt < 0 || fmt > CW_PCM_F64) return fail(c, CW_ERR_INVALID, "unknown sample format %d", fmt);
+    if (channels < 1 || n_frames < 1 || sr_in <= 0 || sr_out <= 0)
+        return fail(c, CW_ERR_INVALID, "bad audio geometry (channels=%d frames=%lld %d->%d Hz)", channels, (long long)n_frames, sr_in, sr_out);
+    const size_t raw_bytes = (size_t)n_frames * channels * bytes_of[fmt];
+    const int64_t n_out = cw_resampled_length(n_frames, sr_in, sr_out);
+    void* d_raw = nullptr; float *d_mono = nullptr, *d_out = nullptr, *d_taps = nullptr; double* d_acc = nullptr;
+    int rc = CW_OK;
+    auto cleanup = [&]() { hipFree(d_raw); hipFree(d_mono); hipFree(d_out); hipFree(d_taps); hipFree(d_acc); };
+#define ING(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(c, CW_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+    ING(hipMalloc(&d_raw, raw_bytes));
+    ING(hipMalloc((void**)&d_mono, (size_t)n_frames * 4));
+    ING(hipMemcpyAsync(d_raw, raw, raw_bytes, hipMemcpyHostToDevice, c->st));
+    rc = cw_launch_pcm_to_mono(d_raw, fmt, channels, n_frames, d_mono, c->st);
+    if (rc == CW_OK && normalise) {
+        ING(hipMalloc((void**)&d_acc, 16));
+        rc = cw_launch_normalise(d_mono, n_frames, d_acc, c->st);
+    }
+    const float* d_res = d_mono;
+    if (rc == CW_OK && sr_in != sr_out) {                       // F.resample returns its input when the rates agree
+        std::vector<float> K, Kt;
+        int orig, nw, width;
+        resample_taps(sr_in, sr_out, K, orig, nw, width);
+        const int n_taps = 2 * width + orig;
+        Kt.resize(K.size());
+        for (int p = 0; p < nw; ++p) for (int j = 0; j < n_taps; ++j) Kt[(size_t)j * nw + p] = K[(size_t)p * n_taps + j];
+        ING(hipMalloc((void**)&d_taps, Kt.size() * 4));
+        ING(hipMalloc((void**)&d_out, (size_t)n_out * 4));
+        ING(hipMemcpyAsync(d_taps, Kt.data(), Kt.size() * 4, hipMemcpyHostToDevice, c->st));
+        ING(hipStreamSynchronize(c->st));                       // Kt is a local
+        rc = cw_launch_resample(d_mono, n_frames, d_taps, orig, nw, width, n_out, d_out, c->st);
+        d_res = d_out;
+    }
+    if (rc != CW_OK) { cleanup(); return fail(c, rc, "cw_ingest: launch rejected"); }
+    ING(hipMemcpyAsync(out, d_res, (size_t)n_out * 4, hipMemcpyDeviceToHost, c->st));
+    ING(hipStreamSynchronize(c->st));
+#undef ING
+    cleanup();
+    return CW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernel-level test hooks
 // ------------------------------------------------------------------------------------------------
 int32_t cw_test_gemm(cw_ctx* c, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias,

@@ -113,6 +113,12 @@ int cw_launch_mel(const MelTables& t, const float* pcm, int B, int n_mels, float
 int cw_launch_mel_finish(const float* logspec_tm, const unsigned int* gmax, int B, int n_mels, void* feats_tm,
                          int feats_bf16, float* feats_hf, hipStream_t st);
 
+// ingest.hip
+int cw_launch_pcm_to_mono(const void* raw, int fmt, int channels, long long n_frames, float* out, hipStream_t st);
+int cw_launch_normalise(float* x, long long n, double* acc2, hipStream_t st);
+int cw_launch_resample(const float* x, long long n_in, const float* taps_t, int orig, int nw, int width,
+                       long long n_out, float* out, hipStream_t st);
+
 // align.hip
 int cw_launch_align_stats(const float* w, int B, int Ha, int rows_cap, int S, int row0, int N, const int* n_cols,
                           float* mean, float* stdv, hipStream_t st);

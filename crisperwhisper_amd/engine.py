@@ -183,6 +183,16 @@ class Engine:
         self._chk(self.lib.cw_get_alignment(self.ctx, _ptr(out), nb, L))
         return out
 
+    def ingest(self, raw, fmt: int, channels: int, n_frames: int, sr_in: int, sr_out: int = 16000,
+               normalise: bool = False) -> np.ndarray:
+        """cw_ingest: interleaved sample frames (bytes or a C-contiguous array) -> mono float32 at ``sr_out``."""
+        buf = np.frombuffer(raw, dtype=np.uint8) if isinstance(raw, (bytes, bytearray, memoryview)) else np.ascontiguousarray(raw)
+        n_out = int(self.lib.cw_resampled_length(int(n_frames), int(sr_in), int(sr_out)))
+        out = np.empty(n_out, dtype=np.float32)
+        self._chk(self.lib.cw_ingest(self.ctx, buf.ctypes.data_as(C.c_void_p), int(fmt), int(channels), int(n_frames),
+                                     int(sr_in), int(sr_out), 1 if normalise else 0, _ptr(out)))
+        return out
+
     def transcribe(self, nb: int, num_frames, *, sot: int, language_token: int = -1, task_token: int = -1,
                    max_new_tokens: int = -1, min_new_tokens: int = 0, max_length: int = 448, lang_ids=None):
         """Native seek loop (cw_transcribe) over the nb resident feature items: returns (tokens, timestamps, passes),

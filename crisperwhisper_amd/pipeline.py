@@ -110,9 +110,9 @@ class CrisperWhisperPipeline:
         if isinstance(inputs, str):
             if inputs.startswith("http://") or inputs.startswith("https://"):
                 raise ValueError("remote URLs are not fetched by the native pipeline; pass a local path or an array")
-            inputs = audio.read_audio(inputs, self.sampling_rate)
+            inputs = audio.read_audio(inputs, self.sampling_rate, self.engine)
         elif isinstance(inputs, bytes):
-            inputs = audio.decode_wav_bytes(inputs, self.sampling_rate)
+            inputs = audio.decode_wav_bytes(inputs, self.sampling_rate, self.engine)
         if hasattr(inputs, "detach") and hasattr(inputs, "cpu"):       # torch.Tensor
             inputs = inputs.detach().cpu().numpy()
         if isinstance(inputs, dict):
@@ -128,7 +128,7 @@ class CrisperWhisperPipeline:
                 arr = inputs.pop("array", None)
             if hasattr(arr, "detach"):
                 arr = arr.detach().cpu().numpy()
-            inputs = audio.resample(np.asarray(arr, dtype=np.float32), int(inputs["sampling_rate"]), self.sampling_rate)
+            inputs = audio.resample(np.asarray(arr, dtype=np.float32), int(inputs["sampling_rate"]), self.sampling_rate, self.engine)
         if not isinstance(inputs, np.ndarray):
             raise TypeError(f"We expect a numpy ndarray or torch tensor as input, got `{type(inputs)}`")
         if inputs.ndim != 1:

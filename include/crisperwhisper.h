@@ -65,6 +65,26 @@ int32_t cw_sync(cw_ctx* ctx);
 int32_t cw_load_tensor(cw_ctx* ctx, const char* hf_name, const float* data, const int64_t* shape, int32_t ndim);
 int32_t cw_set_generation(cw_ctx* ctx, const cw_gen_cfg* cfg);
 
+/* ---- audio ingest (the step in front of seam 1) -------------------------------------------------
+ * cw_ingest: interleaved little-endian sample frames as they sit in a RIFF/WAVE data chunk -> mono f32 at sr_out, on
+ * device: integer formats scaled to [-1, 1), channels averaged (what `ffmpeg -ac 1 -ar 16000 -f f32le` of
+ * TF/pipelines/audio_utils.py:9-45 delivers), optional (y - mean) / std / 8 of REF/app.py:85-93, then
+ * torchaudio.functional.resample with its defaults (sinc_interp_hann, lowpass_filter_width = 6, rolloff = 0.99:
+ * TF/pipelines/automatic_speech_recognition.py:398-412, REF/app.py:94-95).  out holds
+ * cw_resampled_length(n_frames, sr_in, sr_out) = ceil(n_frames * sr_out / sr_in) floats.
+ * cw_resample_taps exposes the tap table [new][2*width + orig] (f64 arithmetic rounded to f32) for differential tests. */
+#define CW_PCM_U8 0
+#define CW_PCM_S16 1
+#define CW_PCM_S24 2
+#define CW_PCM_S32 3
+#define CW_PCM_F32 4
+#define CW_PCM_F64 5
+int64_t cw_resampled_length(int64_t n_frames, int32_t sr_in, int32_t sr_out);
+int32_t cw_ingest(cw_ctx* ctx, const void* raw, int32_t fmt, int32_t channels, int64_t n_frames, int32_t sr_in,
+                  int32_t sr_out, int32_t normalise, float* out);
+int32_t cw_resample_taps(int32_t sr_in, int32_t sr_out, float* taps, int32_t cap, int32_t* orig, int32_t* nw,
+                         int32_t* width);
+
 /* ---- seam 1: feature extractor (WhisperFeatureExtractor.__call__, feature_extraction_whisper.py:193-346)
  * pcm: [B][n_samples[b]] packed back to back (each <= CW_N_SAMPLES; zero-padded to 30 s on device).
  * feats_out (nullable): [B][n_mels][3000] f32, HF layout.  n_frames_out (nullable): attention_mask.sum(-1).

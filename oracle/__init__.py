@@ -23,6 +23,9 @@ stage in numpy (plus one C file for the DTW inner loop) and cites the TF file:li
 * ``collate.py``    TF/models/whisper/tokenization_whisper.py:901-1406
 * ``pauses.py``     REF/utils.py:1-29
 * ``pipeline.py``   TF/pipelines/automatic_speech_recognition.py:61-84, 345-710
+* ``audio.py``      audio ingest in front of the path: torchaudio.functional.resample defaults (torchaudio is absent
+                    offline: published algorithm restated, **parity unpinned** for this module only),
+                    ffmpeg's f32le mono sample decoding, REF/app.py:85-93 normalisation
 
 Parity pinning
 --------------
