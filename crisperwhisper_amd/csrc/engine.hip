@@ -549,6 +549,13 @@ int32_t cw_set_features(cw_ctx* c, const float* feats, int32_t B) {
 // encoder
 // ------------------------------------------------------------------------------------------------
 static EpiParams epi0() { EpiParams p; memset(&p, 0, sizeof(p)); return p; }
+static DecAttnParams dec_attn(const float* q, const void* K, const void* V, int cap, int n_keys, const int* pos, float* out,
+                              int B, int H) {
+    DecAttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = q; p.K = K; p.V = V; p.cap = cap; p.n_keys = n_keys; p.pos = pos; p.out = out; p.B = B; p.H = H;
+    return p;
+}
 
 int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* seek, const int32_t* n_frames) {
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, NM = c->d.n_mels, S = CW_N_CTX;
@@ -651,7 +658,8 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, L.ln1_b, ep));
         }
         {
-            DecAttnParams p{c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, frag ? (unsigned short*)c->d_xfrag2 : nullptr, nullptr, nullptr, 0, 0, nb, H};
+            DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
+            if (frag) p.out_frag = (unsigned short*)c->d_xfrag2;
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
         }
         {
@@ -673,9 +681,9 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             CombineParams cb{c->d_part_ml, H, nb * D};
             CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
         } else {
-            DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn, nullptr,
-                            c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_slot + (size_t)l * H,
-                            c->d.n_align, TGT, nb, H};
+            DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn, nb, H);
+            p.align_out = c->d.n_align > 0 ? c->d_align : nullptr; p.align_slot = c->d_align_slot + (size_t)l * H;
+            p.n_align = c->d.n_align; p.align_rows = TGT;
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo_c, D, nullptr, nullptr, ep));
@@ -1277,9 +1285,13 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
     }
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim;
     if (nb < 1 || nb > c->Bm || iters < 1) return fail(c, CW_ERR_INVALID, "time_kernel: bad args");
-    LayerW& L = c->dec[0];
     const int TGT = c->d.max_target_positions, V = c->d.vocab_size;
+    // launches cycle through the decoder layers, as the real step does: every launch streams its weights / K,V cache
+    // from HBM (one layer's 61 MB cross cache alone would otherwise sit in the 256 MB Infinity Cache and flatter the
+    // kernel: 11.6 us "hot" vs 14.1 us inside the step)
+    int launch_no = 0;
     auto launch = [&]() -> int {
+        LayerW& L = c->dec[(launch_no++) % c->d.dec_layers];
         switch (which) {
             case 0: {   // fc1: LN + GEMV + GELU
                 EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
@@ -1291,7 +1303,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
                                        c->d_pos, 0, 0, nb, H};
                     return cw_launch_attn_cross_split(true, p, c->st);
                 }
-                DecAttnParams p{c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, nullptr, c->dattn, nullptr, nullptr, 0, 0, nb, H};
+                DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, nullptr, c->dattn, nb, H);
                 return cw_launch_attn_decode(c->bf16, p, c->st);
             }
             case 2: {   // self-attention out projection (in-place residual, K split)
@@ -1312,7 +1324,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
                 return gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep);
             }
             case 6: {   // self-attention at the positions in d_pos
-                DecAttnParams p{c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nullptr, nullptr, 0, 0, nb, H};
+                DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
                 return cw_launch_attn_decode(c->bf16, p, c->st);
             }
             case 7: {   // logits

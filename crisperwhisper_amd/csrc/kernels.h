@@ -74,7 +74,7 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st);
 // un-normalised partial outputs + (max, sum); the consumer GEMV combines them while loading its activations,
 // alignment rows are normalised once per generate call by cw_launch_align_normalize.
 #ifndef ATT_NS
-#define ATT_NS 4
+#define ATT_NS 6
 #endif
 #ifndef CROSS_THREADS
 #define CROSS_THREADS 512
