@@ -44,15 +44,32 @@ __device__ inline float gelu_erf(float x) {  // nn.functional.gelu default (exac
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// Wave-wide reductions on the DPP path (VALU cross-lane moves, a few cycles each).  __shfl_xor compiles to
+// ds_bpermute_b32 -- an LDS-crossbar round trip of ~100+ cycles per step, 6 dependent steps per reduction: measured
+// 1.2-1.5 us for the four reductions of a fused LayerNorm, which sat on the critical path of every decode GEMV.
+// Inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals
+// upwards: lane 63 ends up with the wave total, read back as a scalar.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_mov(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0x111, 0xf>(0.f, v);   // row_shr:1
+    v += dpp_mov<0x112, 0xf>(0.f, v);   // row_shr:2
+    v += dpp_mov<0x114, 0xf>(0.f, v);   // row_shr:4
+    v += dpp_mov<0x118, 0xf>(0.f, v);   // row_shr:8    lane 15 of each row = row total
+    v += dpp_mov<0x142, 0xa>(0.f, v);   // row_bcast:15 rows 1, 3 += total of the row below
+    v += dpp_mov<0x143, 0xc>(0.f, v);   // row_bcast:31 rows 2, 3 += total of rows 0-1
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0x111, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_mov<0x112, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_mov<0x114, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_mov<0x118, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_mov<0x142, 0xa>(-INFINITY, v));
+    v = fmaxf(v, dpp_mov<0x143, 0xc>(-INFINITY, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Block-wide reductions through a small LDS scratch (>= 32 floats).  All threads get the result.
