@@ -120,8 +120,7 @@ __global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __
                     st[qt][kt][r] = s;
                     mx = fmaxf(mx, s);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xor32_max(xor16_max(mx));
             // deferred rescale: the running max (and with it the O / l accumulators) is only moved when some row
             // of the wave grew by more than RESCALE_THR; otherwise P = exp(s - m_old) <= e^THR, still exact in the
             // final O / l ratio (f32 accumulators).  The decision is taken before this tile's P exists.
@@ -184,8 +183,7 @@ __global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         float l = lrow[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xor32_sum(xor16_sum(l));
         const float inv = 1.0f / l;
         const int q = qbase + qt * 16 + l15;
         if (q < S) {
@@ -299,7 +297,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
                 float d = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[u][e], d);
-                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);   // (a DPP quad_perm/half-mirror version measured slower here)
                 if (sub == 0) sc[k] = d;
                 mx = fmaxf(mx, d);
             }
@@ -388,7 +386,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
                 float d = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[u][e], d);
-                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);   // (a DPP quad_perm/half-mirror version measured slower here)
                 if (sub == 0) sc[k] = d;
                 mx = fmaxf(mx, d);
             }

@@ -72,6 +72,24 @@ __device__ inline float wave_max(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Cross-row exchanges (lane ^ 16, lane ^ 32) on gfx950's v_permlane16/32_swap: with both operands = v the two results
+// are the even-row and odd-row (lower-half and upper-half) copies, so op(r0, r1) is the butterfly step in one VALU op.
+__device__ inline float xor16_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float xor32_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float xor16_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float xor32_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // Block-wide reductions through a small LDS scratch (>= 32 floats).  All threads get the result.
 __device__ inline float block_sum(float v, float* scratch) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

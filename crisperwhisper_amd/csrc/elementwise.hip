@@ -124,13 +124,24 @@ __device__ inline ArgPair arg_better(ArgPair a, ArgPair b) {  // larger value wi
     if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
     return a;
 }
-__device__ inline ArgPair wave_argmax(ArgPair a) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ArgPair b; b.v = __shfl_xor(a.v, o, 64); b.i = __shfl_xor(a.i, o, 64);
-        a = arg_better(a, b);
-    }
-    return a;
+template <int CTRL, int ROW_MASK>
+__device__ inline ArgPair dpp_pair(ArgPair a) {   // identity (-inf, INT_MAX) where the DPP source lane does not exist
+    ArgPair b;
+    b.v = dpp_mov<CTRL, ROW_MASK>(-INFINITY, a.v);
+    b.i = __builtin_amdgcn_update_dpp(0x7fffffff, a.i, CTRL, ROW_MASK, 0xf, false);
+    return b;
+}
+__device__ inline ArgPair wave_argmax(ArgPair a) {   // same DPP scan as wave_sum; every lane gets lane 63's total
+    a = arg_better(a, dpp_pair<0x111, 0xf>(a));
+    a = arg_better(a, dpp_pair<0x112, 0xf>(a));
+    a = arg_better(a, dpp_pair<0x114, 0xf>(a));
+    a = arg_better(a, dpp_pair<0x118, 0xf>(a));
+    a = arg_better(a, dpp_pair<0x142, 0xa>(a));
+    a = arg_better(a, dpp_pair<0x143, 0xc>(a));
+    ArgPair r;
+    r.v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a.v), 63));
+    r.i = __builtin_amdgcn_readlane(a.i, 63);
+    return r;
 }
 
 template <typename T>
