@@ -481,6 +481,23 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const float* __restrict_
 // partial sums are accumulated with f32 atomics straight into the residual stream.
 // NSLOT = ceil(steps / 4) weight steps per wave, PER_LANE = ceil(Kb / 256) float4 per lane per row.
 // ---------------------------------------------------------------------------------------------------
+// Development aid (make CXXFLAGS+=-DCW_PHASE_TIMING, tools/phase_probe.py): thread 0 of the first 512 blocks stamps the
+// 100 MHz wall clock at the phase boundaries of the decode GEMV; cw_debug_phases copies the stamps out.  This is how the
+// ds_bpermute-based LayerNorm reductions were found on the critical path (1.5 us of a 7.9 us kernel).
+#ifdef CW_PHASE_TIMING
+__device__ unsigned long long g_phase[512 * 8];
+#define PH(i)                                                                                          \
+    do {                                                                                               \
+        const int bid_ = blockIdx.x + blockIdx.y * gridDim.x;                                          \
+        if (threadIdx.x == 0 && bid_ < 512) g_phase[bid_ * 8 + (i)] = wall_clock64();                  \
+    } while (0)
+extern "C" int cw_debug_phases(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 512 * 8);
+}
+#else
+#define PH(i) do { } while (0)
+#endif
+
 template <int EPI, int RPW, bool ATOMIC, bool COMBINE, int NSLOT, int PER_LANE>
 __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict__ x, int Mb, int K, int Kb,
                                                          const bf16_t* __restrict__ W, int N,
@@ -504,6 +521,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     const int nvec = Kb >> 2;                                 // float4 per row slice
     const bool has_ln = ln_g != nullptr;
 
+    PH(0);                                                    // kernel entry
     const float bias_v = ep.bias ? ep.bias[nc] : 0.f;
 
     // activation rows -> registers
@@ -572,6 +590,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
         }
     }
 
+    PH(1);                                                    // every load accepted by the memory pipeline
     if (has_ln) {   // only launched with Kb == K
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
@@ -613,7 +632,9 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
             *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
         }
     }
+    PH(2);                                                    // activations (LayerNorm) parked in LDS
     __syncthreads();
+    PH(3);
 
     f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -631,7 +652,9 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     // D[row = batch g*4 + r][col = l15]
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    PH(4);                                                    // weights arrived, MFMAs done
     __syncthreads();
+    PH(5);
     {
         const int r = tid >> 6;
         float v = red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane] + red[(2 * 4 + r) * 64 + lane] +

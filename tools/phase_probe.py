@@ -6,7 +6,7 @@ from crisperwhisper_amd.engine import Engine
 g, v = syn.large_v3_geometry()
 spec = syn.model_spec(g, v, 15)
 eng = Engine(spec, dtype="bf16", max_batch=8)
-for which, name, nblk in [(0, "fc1", 320), (3, "qkv", 240), (4, "q_c", 80)]:
+for which, name, nblk in [(0, "fc1", 320), (3, "qkv", 240), (4, "q_c", 80), (5, "fc2", 320), (2, "o-proj", 160)]:
     ms, by = eng.time_kernel(which, 8, 50)
     buf = np.zeros(512 * 8, np.uint64)
     eng.lib.cw_debug_phases.argtypes = [C.c_void_p]
