@@ -1,5 +1,5 @@
 """Phase timeline of the decode GEMV blocks (development aid).  Needs a library built with
-  make -C crisperwhisper_amd/csrc clean all CXXFLAGS+=-DCW_PHASE_TIMING   (see gemm.hip: PH / cw_debug_phases)."""
+  make -C crisperwhisper_amd/csrc clean all EXTRA=-DCW_PHASE_TIMING   (see gemm.hip: PH / cw_debug_phases)."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
