@@ -204,7 +204,7 @@ def main():
     # roofline of the decode-step kernels, HIP events on the engine's own stream
     roof = {}
     for which, kname in ((0, "gemv_bf16_kernel<EPI_GELU_F32> (decoder fc1 + fused LayerNorm)"),
-                         (1, "attn_cross_split_kernel<bf16> (cross-attention, 1500 frames, 4-way key split)")):
+                         (1, "attn_cross_split_kernel<bf16> (cross-attention, 1500 frames, 6-way key split)")):
         ms, by = eng.time_kernel(which, B, a.kernel_iters)
         roof[which] = {"kernel": kname, "avg_ms": ms, "algo_bytes": by, "achieved": by / (ms * 1e-3) / 1e9}
 
