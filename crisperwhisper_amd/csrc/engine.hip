@@ -1185,6 +1185,11 @@ int32_t cw_ingest(cw_ctx* c, const void* raw, int32_t fmt, int32_t channels, int
 // ------------------------------------------------------------------------------------------------
 // kernel-level test hooks
 // ------------------------------------------------------------------------------------------------
+int32_t cw_test_set_option(const char* name, int32_t value) {
+    if (!strcmp(name, "gemm256_min_tiles")) { cw_gemm_set_256_min_tiles(value); return CW_OK; }
+    return CW_ERR_INVALID;
+}
+
 int32_t cw_test_gemm(cw_ctx* c, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias,
                      int32_t gelu, float* out) {
     void *dA = nullptr, *dW = nullptr, *dO = nullptr; float* dB = nullptr;

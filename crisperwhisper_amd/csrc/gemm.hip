@@ -298,6 +298,140 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(AParams ap, const b
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 256x256x64 flavour of the LDS-DMA GEMM for the large encoder shapes (M = batch*1500 rows): 8 waves as 2 (M) x 4 (N),
+// each wave owns a 128x64 output patch (acc[8][4], 128 accumulator registers), two waves per SIMD.
+// Why: with 128x128 tiles and 64x64 wave patches the kernel sits at BOTH per-CU limits at once -- fragment reads need
+// 8 KB of LDS per 16 MFMAs (= 128 B/clk at full MFMA rate, the LDS limit) and the operand DMA needs 32 KB per K-tile
+// (= 62 B/clk of the 64 B/clk L1 path).  256x256 / 128x64 brings that to ~94 B/clk and ~32 B/clk, and halves the
+// L2/HBM re-fetch of the operand panels.  Same source-side XOR swizzle, staging map, raster and epilogues.
+// LDS: 2 stages x (A 32 KB | W 32 KB) = 128 KB dynamic.
+// ---------------------------------------------------------------------------------------------------
+#define BM2 256
+#define BN2 256
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_256_kernel(AParams ap, const bf16_t* __restrict__ W, int M, int N,
+                                                            int K, EpiParams ep, int tiles_n,
+                                                            const bf16_t* __restrict__ zero_page) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm2[];   // [2][A 32 KB | W 32 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int mt_, nt_;
+    grouped_tile(tile, gridDim.x / tiles_n, tiles_n, mt_, nt_);
+    const int m0 = mt_ * BM2, n0 = nt_ * BN2;
+
+    // staging map as in the 128 kernel: chunk ch = wave*4 + q (0..31) = rows ch*8 .. ch*8+7 of the 256-row tile
+    const int lrow = lane >> 3;
+    const int csrc = ((lane & 7) ^ lrow) * 8;
+    size_t a_base[4]; int a_t[4], a_valid[4]; const bf16_t* w_row[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (wave * 4 + q) * 8 + lrow;
+        const int m = m0 + r, n = n0 + r;
+        w_row[q] = (n < N) ? W + (size_t)n * K + csrc : nullptr;
+        a_valid[q] = -1;
+        a_base[q] = 0; a_t[q] = 0;
+        if (m < M) {
+            if (ap.amode == 0) { a_base[q] = (size_t)m * ap.lda + csrc; a_valid[q] = 0x7fffffff; }
+            else {
+                const int b = m / ap.T_out, t = m - b * ap.T_out;
+                a_t[q] = t * ap.stride - 1;
+                a_base[q] = (size_t)ap.row_off[b] * ap.C_in + csrc;
+                a_valid[q] = ap.row_valid[b];
+            }
+        }
+    }
+    auto stage = [&](int k0, int buf) {
+        unsigned char* base = gsm2 + buf * 65536;
+        int tap = 0, c0 = k0;
+        if (ap.amode != 0) { tap = k0 / ap.C_in; c0 = k0 - tap * ap.C_in; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = wave * 4 + q;
+            const bf16_t* pa = nullptr;
+            if (ap.amode == 0) {
+                if (a_valid[q] >= 0) pa = (const bf16_t*)ap.A + a_base[q] + k0;
+            } else {
+                const int t_in = a_t[q] + tap;
+                if (t_in >= 0 && t_in < a_valid[q]) pa = (const bf16_t*)ap.A + a_base[q] + (size_t)t_in * ap.C_in + c0;
+            }
+            glds16(pa ? (const void*)pa : (const void*)zero_page, base + ch * 1024);
+            glds16(w_row[q] ? (const void*)(w_row[q] + k0) : (const void*)zero_page, base + 32768 + ch * 1024);
+        }
+    };
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage((kt + 1) * BK, cur ^ 1);
+        const unsigned char* sA = gsm2 + cur * 65536;
+        const unsigned char* sW = sA + 32768;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[8], fw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = wn * 64 + j * 16 + l15;
+                fw[j] = *(const bf16x8_t*)(sW + r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = wm * 128 + i * 16 + l15;
+                fa[i] = *(const bf16x8_t*)(sA + r * 128 + (((kk * 4 + g) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[j], fa[i], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const bool vec_ok = (EPI == EPI_HEADS || (ep.ldo & 3) == 0);
+    if (m0 + BM2 <= M && n0 + BN2 <= N && vec_ok) {   // interior tile (block-uniform)
+        int cols[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cols[j] = n0 + wn * 64 + j * 16 + g * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int rows[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rows[i] = m0 + wm * 128 + (h * 4 + i) * 16 + l15;
+            epi_tile_interior<bf16_t, EPI>(ep, rows, cols, *(const f32x4_t(*)[4][4])&acc[h * 4]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int m = m0 + wm * 128 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + wn * 64 + j * 16 + g * 4;
+            if (n + 3 < N && vec_ok) {
+                epi_store4<bf16_t, EPI>(ep, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) epi_store1<bf16_t, EPI>(ep, m, n + r, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // f32 parity GEMM: 64x64 tile, 256 threads, 4x4 outputs per thread, BK = 16.
 // ---------------------------------------------------------------------------------------------------
 template <int EPI>
@@ -862,6 +996,9 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------
 static const bf16_t* g_zero_page = nullptr;   // 256 B of zeros: DMA source for padded rows
 static bool g_use_glds = true;
+static bool g_use_256 = true;   // CW_NO_GEMM256=1: keep the 128x128 tiles everywhere
+static int g_256_min_tiles = 200;
+void cw_gemm_set_256_min_tiles(int n) { g_256_min_tiles = n; }
 
 template <int EPI>
 static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
@@ -873,8 +1010,18 @@ static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, 
             void* z = nullptr;
             if (hipMalloc(&z, 256) == hipSuccess) { hipMemset(z, 0, 256); g_zero_page = (const bf16_t*)z; }
             if (getenv("CW_NO_GLDS")) g_use_glds = false;
+            if (getenv("CW_NO_GEMM256")) g_use_256 = false;
         });
-        if (g_use_glds && g_zero_page)
+        // large shapes: 256x256 tiles once they fill most of the chip (>= 200 tiles); small M keeps the 128 tiles
+        const int tm2 = (M + BM2 - 1) / BM2, tn2 = (N + BN2 - 1) / BN2;
+        if (g_use_glds && g_zero_page && g_use_256 && tm2 * tn2 >= g_256_min_tiles) {
+            static std::once_flag attr_once;     // one per EPI instantiation (function-local static in a template)
+            std::call_once(attr_once, [] {
+                hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            });
+            hipLaunchKernelGGL((gemm_bf16_256_kernel<EPI>), dim3(tm2 * tn2), dim3(512), 131072, st, ap, (const bf16_t*)W, M,
+                               N, K, ep, tn2, g_zero_page);
+        } else if (g_use_glds && g_zero_page)
             hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI>), dim3(tm * tn), dim3(256), 65536, st, ap, (const bf16_t*)W, M,
                                N, K, ep, tn, g_zero_page);
         else

@@ -14,6 +14,7 @@ struct AParams {
 
 int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
                    hipStream_t st);
+void cw_gemm_set_256_min_tiles(int n);   // test hook: tile count from which the 256x256 GEMM is used (default 200)
 struct CombineParams;
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
                    const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr,

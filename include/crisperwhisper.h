@@ -176,6 +176,8 @@ int32_t cw_collate_get(cw_collator* c, uint8_t* text, double* starts, double* en
 void cw_collate_free(cw_collator* c);
 
 /* ---- kernel-level hooks used by the parity tests (host f32 in/out, run in the context's dtype) -------- */
+/* process-wide tuning knobs for the tests: "gemm256_min_tiles" = tile count from which the 256x256 GEMM is used */
+int32_t cw_test_set_option(const char* name, int32_t value);
 int32_t cw_test_gemm(cw_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, const float* W,
                      const float* bias, int32_t gelu, float* out);
 int32_t cw_test_gemv(cw_ctx* ctx, int32_t Mb, int32_t N, int32_t K, const float* x, const float* W,

@@ -126,8 +126,10 @@ def test_pipeline_bf16_runs_and_is_well_formed(tiny):
     pipe.engine.close()
 
 
-def test_large_geometry_layers_bf16_vs_oracle():
-    """BASELINE-size shapes (d=1280, 20 heads, ffn 5120, vocab 51866, 15 alignment heads) on a 2+2-layer
+@pytest.mark.parametrize("min_tiles", [200, 1])
+def test_large_geometry_layers_bf16_vs_oracle(min_tiles):
+    """min_tiles = 1 forces the 256x256 GEMM for every encoder GEMM (conv gather, HEADS / RESID / GELU epilogues).
+    BASELINE-size shapes (d=1280, 20 heads, ffn 5120, vocab 51866, 15 alignment heads) on a 2+2-layer
     stack: exercises every large-shape kernel path of the bf16 engine (LDS-DMA GEMM tiles with M/N edges,
     K-split atomic GEMVs, 4-way split cross-attention + combine, 51866-wide logits + sampler) against the
     f32 oracle, teacher-forced.  Tolerances: bf16 weights/activations vs f32 reference."""
@@ -142,6 +144,7 @@ def test_large_geometry_layers_bf16_vs_oracle():
     enc_ref = orc.encode(feats)
     eng = Engine(spec, dtype="bf16", max_batch=2)
     eng.load_state_dict(W)
+    eng.lib.cw_test_set_option(b"gemm256_min_tiles", min_tiles)
     try:
         f2, _ = eng.mel([x, x[:200000]], return_features=True)
         assert np.abs(f2[0] - feats[0]).max() < 1e-4
@@ -177,6 +180,7 @@ def test_large_geometry_layers_bf16_vs_oracle():
         ts = eng.token_timestamps(2, T - 1, 3, [3000, 1250])
         assert np.isfinite(ts).all() and (ts[:, 3:] >= 0).all() and (ts[0] <= 30.0).all() and (ts[1] <= 12.5 + 1e-6).all()
     finally:
+        eng.lib.cw_test_set_option(b"gemm256_min_tiles", 200)
         eng.close()
 
 

@@ -48,6 +48,28 @@ def test_gemm(engines, dt, tol, M, N, K):
         assert rel_err(got, ref) < tol, (dt, M, N, K, gelu, rel_err(got, ref))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 384, 256), (77, 51, 64), (700, 515, 128), (3333, 1280, 1280)])
+def test_gemm_256_tile_kernel(engines, M, N, K):
+    """The 256x256x64 LDS-DMA GEMM (used from 200 tiles up) forced on for small shapes: interior tiles, M / N edge
+    tiles, a row length that is not a multiple of 4 (scalar epilogue), K = 64 (single K-tile) .. 1280."""
+    eng = engines["bf16"]
+    rng = np.random.default_rng(M * 3 + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    A = (A.view(np.uint32) & 0xFFFF0000).view(np.float32); W = (W.view(np.uint32) & 0xFFFF0000).view(np.float32)
+    assert eng.lib.cw_test_set_option(b"gemm256_min_tiles", 1) == 0
+    try:
+        for gelu in (False, True):
+            ref = A.astype(np.float64) @ W.astype(np.float64).T + b
+            if gelu:
+                ref = OMOD.gelu(ref.astype(np.float32)).astype(np.float64)
+            got = eng.test_gemm(A, W, b, gelu)
+            assert rel_err(got, ref) < 2e-2, (M, N, K, gelu, rel_err(got, ref))
+    finally:
+        eng.lib.cw_test_set_option(b"gemm256_min_tiles", 200)
+
+
 @pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("Mb,N,K", [(1, 128, 128), (3, 200, 256), (8, 1769, 128), (16, 64, 1280), (20, 128, 512), (40, 96, 1280), (64, 80, 256)])
 def test_gemv_with_layernorm(engines, dt, tol, Mb, N, K):
