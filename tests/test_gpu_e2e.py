@@ -357,3 +357,33 @@ def test_large_batch_decode_matches_small_batch_path():
             assert np.abs(al_big[lo:lo + 10] - al_small).max() < 2e-2
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["large_mixed30_n32", "large_noise12_n24"])
+def test_full_size_f32_pipeline_word_for_word_vs_transformers(name):
+    """BASELINE geometry end to end (large-v3 shapes, 32 + 32 layers, vocab 51866, 15 alignment heads, 1.54 B synthetic
+    parameters): the reference pipeline call through the f32 engine against the committed transformers 5.15.0 CPU
+    output (tests/golden/gen_golden_large.py): identical text and words, timestamps within one encoder frame."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "e2e_large_golden.json")
+    if not os.path.exists(path):
+        pytest.skip("full-size golden not generated")
+    meta = Hh.gold_json("e2e_large_golden.json")[name]
+    g, v = syn.large_v3_geometry()
+    spec = syn.model_spec(g, v, n_align=15)
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
+
+    class LazyWeights(dict):                      # stream the 6.2 GB of f32 weights tensor by tensor
+        def items(self):
+            for n, shape in syn.weight_shapes(g).items():
+                yield n, syn.random_tensor(g, n, shape, seed=meta["weight_seed"])
+    pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, LazyWeights()),
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30, batch_size=1,
+                       return_timestamps="word", torch_dtype="float32", device="cuda:0")
+    try:
+        out = pipe(x, generate_kwargs=dict(meta["generate_kwargs"]))
+        assert out["text"] == meta["text"]
+        ok, why = Hh.words_equal(out["chunks"], meta["chunks"], tol=0.02)
+        assert ok, why
+    finally:
+        pipe.engine.close()
