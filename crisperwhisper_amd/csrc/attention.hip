@@ -264,14 +264,32 @@ template <> struct Row8<bf16_t> {
     }
 };
 
+// 8 consecutive elements held raw (no conversion) so that loads can be issued long before their use
+template <typename T> struct Raw8;
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ inline void ld(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+    __device__ inline void cvt(float* o) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
+};
+template <> struct Raw8<bf16_t> {
+    uint4 a;
+    __device__ inline void ld(const bf16_t* p) { a = *(const uint4*)p; }
+    __device__ inline void cvt(float* o) const {
+        o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
+        o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
+        o[4] = __uint_as_float(a.z << 16); o[5] = __uint_as_float(a.z & 0xffff0000u);
+        o[6] = __uint_as_float(a.w << 16); o[7] = __uint_as_float(a.w & 0xffff0000u);
+    }
+};
+
 #define DEC_THREADS 512
 #define DEC_GROUPS (DEC_THREADS / 8)
+#define DEC_PRE 2          // keys per 8-lane group fetched up front (2 x 64 = 128 keys)
 
 template <typename T>
 __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams p) {
     extern __shared__ float dsm[];          // scores [cap rounded] | red [DEC_GROUPS][64] | scratch [64]
     const int h = blockIdx.x, b = blockIdx.y;
-    const int n_keys = p.pos ? (p.n_keys > 0 ? p.n_keys : p.pos[b] + 1) : p.n_keys;
     float* sc = dsm;
     float* red = dsm + ((p.cap + 63) & ~63);
     float* scratch = red + DEC_GROUPS * 64;
@@ -280,10 +298,35 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
     const T* Vh = (const T*)p.V + ((size_t)b * p.H + h) * p.cap * 64;
     float qv[8];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
+    // The first DEC_PRE keys of every 8-lane group (128 keys in all: the whole self-attention history of a typical
+    // decode) are fetched before anything else, K AND V, with the row clamped to the cache capacity instead of to
+    // n_keys: the loads then depend neither on the device-side position nor on the softmax, which takes two memory
+    // round trips (pos -> K rows, softmax -> V rows) out of this latency-bound kernel.  Rows >= n_keys hold stale but
+    // addressable data and are masked out below.
+    Raw8<T> kpre[DEC_PRE], vpre[DEC_PRE];
+#pragma unroll
+    for (int u = 0; u < DEC_PRE; ++u) kpre[u].ld(Kh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
+#pragma unroll
+    for (int u = 0; u < DEC_PRE; ++u) vpre[u].ld(Vh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
+    const int n_keys = p.pos ? (p.n_keys > 0 ? p.n_keys : p.pos[b] + 1) : p.n_keys;
 
-    // scores: 4 key rows per thread in flight (unrolled by 4 x DEC_GROUPS keys)
     float mx = -INFINITY;
-    for (int k0 = grp; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
+#pragma unroll
+    for (int u = 0; u < DEC_PRE; ++u) {
+        const int k = grp + u * DEC_GROUPS;
+        float kv[8];
+        kpre[u].cvt(kv);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[e], d);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if (k < n_keys) {
+            if (sub == 0) sc[k] = d;
+            mx = fmaxf(mx, d);
+        }
+    }
+    // remaining keys: 4 key rows per thread in flight (unrolled by 4 x DEC_GROUPS keys)
+    for (int k0 = grp + DEC_PRE * DEC_GROUPS; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
         float kv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {   // unconditional loads (clamped row): no exec-masked blocks, all in flight
@@ -317,7 +360,18 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
     }
 
     float acc[8] = {};
-    for (int k0 = grp; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
+#pragma unroll
+    for (int u = 0; u < DEC_PRE; ++u) {
+        const int k = grp + u * DEC_GROUPS;
+        float vv[8];
+        vpre[u].cvt(vv);
+        const float pk = (k < n_keys) ? sc[k] * inv : 0.f;
+        if (k < n_keys) {                                   // stale rows may hold non-finite bit patterns: skip, not scale
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+        }
+    }
+    for (int k0 = grp + DEC_PRE * DEC_GROUPS; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
         float vv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
