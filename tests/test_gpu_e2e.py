@@ -359,7 +359,7 @@ def test_large_batch_decode_matches_small_batch_path():
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["large_mixed30_n32", "large_noise12_n24"])
+@pytest.mark.parametrize("name", ["large_mixed30_n32", "large_noise12_n24", "large_mixed70_b2_n20"])
 def test_full_size_f32_pipeline_word_for_word_vs_transformers(name):
     """BASELINE geometry end to end (large-v3 shapes, 32 + 32 layers, vocab 51866, 15 alignment heads, 1.54 B synthetic
     parameters): the reference pipeline call through the f32 engine against the committed transformers 5.15.0 CPU
@@ -378,7 +378,7 @@ def test_full_size_f32_pipeline_word_for_word_vs_transformers(name):
             for n, shape in syn.weight_shapes(g).items():
                 yield n, syn.random_tensor(g, n, shape, seed=meta["weight_seed"])
     pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, LazyWeights()),
-                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30, batch_size=1,
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30, batch_size=meta.get("batch_size", 1),
                        return_timestamps="word", torch_dtype="float32", device="cuda:0")
     try:
         out = pipe(x, generate_kwargs=dict(meta["generate_kwargs"]))
