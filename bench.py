@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=12)
     ap.add_argument("--kernel-iters", type=int, default=200)
+    ap.add_argument("--cross-kv", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: opt-in e4m3 cross-attention cache (accuracy-gated mode, not the headline)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="independent engine contexts per GPU, each with its own batch of --batch chunks, driven by "
                          "host threads (the decode step is latency-bound, so a second batch fills idle CUs); "
@@ -113,7 +115,8 @@ def main():
     spec = syn.model_spec(g, v, n_align=15 if a.geometry == "large-v3" else 3)
     B = a.batch
     C = max(1, a.contexts)
-    engines = [Engine(spec, dtype=a.dtype, max_batch=B, device=dev) for _ in range(C)]
+    engines = [Engine(spec, dtype=a.dtype, max_batch=B, device=dev, cross_kv_dtype=None if a.cross_kv == "bf16" else a.cross_kv)
+               for _ in range(C)]
     eng = engines[0]
     keep = (not a.no_cpu_baseline) and world == 1 and rank == 0
     weights = {}
@@ -204,7 +207,8 @@ def main():
     # roofline of the decode-step kernels, HIP events on the engine's own stream
     roof = {}
     for which, kname in ((0, "gemv_bf16_kernel<EPI_GELU_F32> (decoder fc1 + fused LayerNorm)"),
-                         (1, "attn_cross_split_kernel<bf16> (cross-attention, 1500 frames, 6-way key split)")):
+                         (1, ("attn_cross_split_fp8_kernel (cross-attention over the e4m3 cache, 1500 frames, 6-way key split)" if a.cross_kv == "fp8" else
+                              "attn_cross_split_kernel<bf16> (cross-attention, 1500 frames, 6-way key split)"))):
         ms, by = eng.time_kernel(which, B, a.kernel_iters)
         roof[which] = {"kernel": kname, "avg_ms": ms, "algo_bytes": by, "achieved": by / (ms * 1e-3) / 1e9}
 
@@ -234,13 +238,14 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "rtf": dt / total_audio, "tokens_per_s": tokens / dt,
             "config": {"workload": f"BASELINE configs[1]: batch={B} x 30 s synthetic 16 kHz audio per GPU, {a.dtype}, "
-                                   f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, greedy, word timestamps",
+                                   f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, greedy, word timestamps"
+                                   + (", fp8 (e4m3) cross-attention cache [opt-in mode]" if a.cross_kv == "fp8" else ""),
                        "chunks_per_gpu": B * C, "contexts_per_gpu": C, "tokens_per_chunk": a.tokens, "parallelism": f"chunk-dp{world}",
-                       "weight_load_s": round(t_load, 1)},
+                       "cross_kv_cache": a.cross_kv, "weight_load_s": round(t_load, 1)},
             "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1) / C, 3) for k, val in stages.items()},
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
                          "frac": r["achieved"] / 8000.0,
-                         "traffic": pmc_traffic("attn_cross_split" if dom == 1 else "gemv2_bf16_kernelILi7"), "kernel": r["kernel"],
+                         "traffic": pmc_traffic(("attn_cross_split_fp8" if a.cross_kv == "fp8" else "attn_cross_split_kernel") if dom == 1 else "gemv2_bf16_kernelILi7"), "kernel": r["kernel"],
                          "avg_launch_ms": r["avg_ms"], "algorithmic_bytes_per_launch": r["algo_bytes"]},
             "roofline_other": [{"kernel": roof[k]["kernel"], "achieved_GBps": roof[k]["achieved"],
                                 "avg_launch_ms": roof[k]["avg_ms"], "algorithmic_bytes_per_launch": roof[k]["algo_bytes"]}

@@ -75,6 +75,7 @@ _SIGS = {
     "cw_collate_finish": (_I, [_P, _P, _P, _P, _P]),
     "cw_collate_get": (_I, [_P, _P, _P, _P, _P, _P]),
     "cw_collate_free": (None, [_P]),
+    "cw_set_option": (_I, [_P, C.c_char_p, _I]),
     "cw_test_set_option": (_I, [C.c_char_p, _I]),
     "cw_test_gemm": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "cw_test_gemv": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),

@@ -500,6 +500,151 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
     return CW_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Opt-in fp8 (OCP e4m3) cross-attention cache.  The cross K/V stream is the largest byte mover of the decode step
+// (245.76 MB per sequence per step in bf16); storing it in e4m3 with one f32 scale per (batch, head, K|V) halves it.
+// Quantisation runs once per encoded window (kv_quant_fp8_kernel, after the bf16 projection); the split kernel keeps
+// the structure of attn_cross_split_kernel with 4 lanes x 16 elements per key row.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(512) void kv_quant_fp8_kernel(const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                           unsigned char* __restrict__ K8, unsigned char* __restrict__ V8,
+                                                           float* __restrict__ kv_scale, int S) {
+    __shared__ float scratch[64];
+    const int h = blockIdx.x, b = blockIdx.y, which = blockIdx.z, H = gridDim.x;
+    const size_t base = ((size_t)b * H + h) * S * 64;
+    const bf16_t* src = (which ? V : K) + base;
+    unsigned char* dst = (which ? V8 : K8) + base;
+    const int nvec = S * 8;                                    // uint4 = 8 bf16
+    float amax = 0.f;
+    for (int i = threadIdx.x; i < nvec; i += 512) {
+        float v[8];
+        Row8<bf16_t>::ld(src + (size_t)i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    }
+    amax = block_max(amax, scratch);
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;     // e4m3 max finite = 448
+    const float inv = 1.0f / scale;
+    if (threadIdx.x == 0) kv_scale[((size_t)b * H + h) * 2 + which] = scale;
+    for (int i = threadIdx.x; i < nvec; i += 512) {
+        float v[8];
+        Row8<bf16_t>::ld(src + (size_t)i * 8, v);
+        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+        int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, 0, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+        *(uint2*)(dst + (size_t)i * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+}
+
+int cw_launch_kv_quant_fp8(const void* K, const void* V, void* K8, void* V8, float* kv_scale, int B, int H, int S,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(kv_quant_fp8_kernel, dim3(H, B, 2), dim3(512), 0, st, (const bf16_t*)K, (const bf16_t*)V,
+                       (unsigned char*)K8, (unsigned char*)V8, kv_scale, S);
+    return CW_OK;
+}
+
+__device__ inline void fp8x16_to_f32(const uint4& r, float* o) {
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], false);
+        const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], true);
+        o[4 * i] = a[0]; o[4 * i + 1] = a[1]; o[4 * i + 2] = c[0]; o[4 * i + 3] = c[1];
+    }
+}
+
+#define CROSS8_GROUPS (CROSS_THREADS / 4)
+#define C8U 2             // key rows per lane in flight: 2 x 128 groups = 256 slots for the 250 keys of a 6-way split
+__global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_fp8_kernel(CrossSplitParams p) {
+    __shared__ float sc[512];
+    __shared__ float red[CROSS8_GROUPS * 64];
+    __shared__ float scratch[64];
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
+    const int k_lo = sp * per, k_hi = min(p.n_keys, k_lo + per), nk = k_hi - k_lo;
+    const int tid = threadIdx.x, sub = tid & 3, grp = tid >> 2;
+    const unsigned char* Kh = (const unsigned char*)p.K + (((size_t)b * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
+    const unsigned char* Vh = (const unsigned char*)p.V + (((size_t)b * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
+    const float ks = p.kv_scale[((size_t)b * p.H + h) * 2], vs = p.kv_scale[((size_t)b * p.H + h) * 2 + 1];
+    float qv[16];
+    Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 16, qv);
+    Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 16 + 8, qv + 8);
+
+    float mx = -INFINITY;
+    for (int k0 = grp; k0 < nk; k0 += C8U * CROSS8_GROUPS) {
+        uint4 kr[C8U];
+#pragma unroll
+        for (int u = 0; u < C8U; ++u) kr[u] = *(const uint4*)(Kh + (size_t)min(k0 + u * CROSS8_GROUPS, nk - 1) * 64);
+#pragma unroll
+        for (int u = 0; u < C8U; ++u) {
+            const int k = k0 + u * CROSS8_GROUPS;
+            if (k < nk) {
+                float kv[16];
+                fp8x16_to_f32(kr[u], kv);
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) d = fmaf(qv[e], kv[e], d);
+                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
+                d *= ks;
+                if (sub == 0) sc[k] = d;
+                mx = fmaxf(mx, d);
+            }
+        }
+    }
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int k = tid; k < nk; k += CROSS_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
+    sum = block_sum(sum, scratch);
+
+    const int slot = p.align_out ? p.align_slot[h] : -1;
+    if (slot >= 0) {
+        const int arow = p.pos[b];
+        const size_t rowi = ((size_t)b * p.n_align + slot) * p.align_rows + arow;
+        float* dst = p.align_out + rowi * p.n_keys + k_lo;
+        for (int k = tid; k < nk; k += CROSS_THREADS) dst[k] = sc[k];
+        if (tid == 0) { p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = sum; }
+    }
+    if (tid == 0) {
+        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp) * 2;
+        ml[0] = mx; ml[1] = sum;
+    }
+
+    float acc[16] = {};
+    for (int k0 = grp; k0 < nk; k0 += C8U * CROSS8_GROUPS) {
+        uint4 vr[C8U];
+#pragma unroll
+        for (int u = 0; u < C8U; ++u) vr[u] = *(const uint4*)(Vh + (size_t)min(k0 + u * CROSS8_GROUPS, nk - 1) * 64);
+#pragma unroll
+        for (int u = 0; u < C8U; ++u) {
+            const int k = k0 + u * CROSS8_GROUPS;
+            if (k < nk) {
+                float vv[16];
+                fp8x16_to_f32(vr[u], vv);
+                const float pk = sc[k];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[grp * 64 + sub * 16 + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        float r = 0.f;
+        for (int gI = 0; gI < CROSS8_GROUPS; ++gI) r += red[gI * 64 + tid];
+        p.part_o[((size_t)sp * p.B + b) * p.H * 64 + h * 64 + tid] = r * vs;
+    }
+}
+
+int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st) {
+    if ((p.n_keys + ATT_NS - 1) / ATT_NS > 512 || !p.kv_scale) return CW_ERR_INVALID;
+    hipLaunchKernelGGL(attn_cross_split_fp8_kernel, dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+    return CW_OK;
+}
+
 // p[k] = e[k] * exp(m_s - M) / sum_s l_s exp(m_s - M) for the key range of split s.  grid (L, n_align, B).
 __global__ void align_normalize_kernel(float* __restrict__ align, const float* __restrict__ align_ml, int n_align,
                                        int align_rows, int n_keys) {

@@ -25,6 +25,8 @@ struct LayerW {
     void* w2 = nullptr; float* b2 = nullptr;
     float *ln2_g = nullptr, *ln2_b = nullptr;
     void *ck = nullptr, *cv = nullptr;   // cross K/V cache   [Bm][H][1500][64]
+    void *ck8 = nullptr, *cv8 = nullptr; // opt-in fp8 (e4m3) copy of it, one byte per element
+    float* kvs = nullptr;                // [Bm][H][2] dequantisation scales (K, V)
     void *sk = nullptr, *sv = nullptr;   // self  K/V cache   [Bm][H][448][64]
 };
 
@@ -75,6 +77,7 @@ struct cw_ctx {
     bool use_graph = true;
     cw_gen_cfg gen{};
     bool gen_set = false;
+    bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
     float* logits_capture = nullptr;
     int logits_capture_steps = 0;
     int last_L = 0, last_nb = 0;
@@ -620,6 +623,7 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
         EpiParams ep = epi0(); ep.out = L.ck; ep.out1 = L.cv; ep.bias = L.bkv_c;
         ep.T = S; ep.S_pad = S; ep.H = H; ep.d_model = D;
         CWCHK(c, cw_launch_gemm(bf, EPI_HEADS, ap, L.wkv_c, M, 2 * D, D, ep, c->st));
+        if (c->kv8) CWCHK(c, cw_launch_kv_quant_fp8(L.ck, L.cv, L.ck8, L.cv8, L.kvs, nb, H, S, c->st));
     }
     KCHK(c);
     tk.stop();
@@ -676,7 +680,10 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml,
                                c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_ml, c->d_align_slot + (size_t)l * H,
                                c->d_pos, c->d.n_align, TGT, nb, H};
-            CWCHK(c, cw_launch_attn_cross_split(true, p, c->st));
+            if (c->kv8) {
+                p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs;
+                CWCHK(c, cw_launch_attn_cross_split_fp8(p, c->st));
+            } else CWCHK(c, cw_launch_attn_cross_split(true, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CombineParams cb{c->d_part_ml, H, nb * D};
             CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
@@ -1185,6 +1192,25 @@ int32_t cw_ingest(cw_ctx* c, const void* raw, int32_t fmt, int32_t channels, int
 // ------------------------------------------------------------------------------------------------
 // kernel-level test hooks
 // ------------------------------------------------------------------------------------------------
+int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
+    if (!strcmp(name, "cross_kv_fp8")) {
+        if (!value) { c->kv8 = false; return CW_OK; }
+        if (!c->bf16) return fail(c, CW_ERR_INVALID, "cross_kv_fp8 needs the bf16 engine (the f32 engine is the parity mode)");
+        if (!c->dec[0].ck8) {
+            const size_t n = (size_t)c->Bm * c->d.n_heads * CW_N_CTX * 64;
+            for (auto& L : c->dec) {
+                CWCHK(c, dmalloc(c, &L.ck8, n, false)); CWCHK(c, dmalloc(c, &L.cv8, n, false));
+                CWCHK(c, dmalloc(c, &L.kvs, (size_t)c->Bm * c->d.n_heads * 2 * 4));
+            }
+        }
+        c->kv8 = true;
+        c->nb_encoded = 0;                                   // windows must be re-encoded to fill the fp8 cache
+        for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // graphs hold the kernel choice
+        return CW_OK;
+    }
+    return fail(c, CW_ERR_INVALID, "unknown option %s", name);
+}
+
 int32_t cw_test_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "gemm256_min_tiles")) { cw_gemm_set_256_min_tiles(value); return CW_OK; }
     return CW_ERR_INVALID;
@@ -1306,6 +1332,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
                 if (c->bf16) {
                     CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml, nullptr, c->d_align_ml, nullptr,
                                        c->d_pos, 0, 0, nb, H};
+                    if (c->kv8) { p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs; return cw_launch_attn_cross_split_fp8(p, c->st); }
                     return cw_launch_attn_cross_split(true, p, c->st);
                 }
                 DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, nullptr, c->dattn, nb, H);
@@ -1353,7 +1380,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
     const double e = (double)c->esz;
     switch (which) {
         case 0: *algo_bytes = (double)F * D * e + (double)nb * D * 4 + (double)nb * F * 4; break;
-        case 1: *algo_bytes = 2.0 * nb * H * CW_N_CTX * 64 * e + 2.0 * nb * D * 4; break;
+        case 1: *algo_bytes = 2.0 * nb * H * CW_N_CTX * 64 * (c->kv8 ? 1.0 : e) + 2.0 * nb * D * 4; break;
         case 2: case 4: *algo_bytes = (double)D * D * e + 2.0 * nb * D * 4; break;
         case 3: *algo_bytes = 3.0 * D * D * e + 4.0 * nb * D * 4; break;
         case 5: *algo_bytes = (double)F * D * e + (double)nb * (D + F) * 4; break;

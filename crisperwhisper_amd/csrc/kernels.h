@@ -92,8 +92,13 @@ struct CrossSplitParams {
     const int* align_slot; // [H]
     const int* pos;        // [B] alignment row to write
     int n_align, align_rows, B, H;
+    const float* kv_scale; // fp8 cache only: [B][H][2] dequantisation scales of K and V (null: K/V hold T)
 };
 int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st);
+// opt-in fp8 (OCP e4m3) cross-attention cache: quantise one layer's bf16 K/V [B][H][S][64] with a scale per (b, h, K|V)
+int cw_launch_kv_quant_fp8(const void* K, const void* V, void* K8, void* V8, float* kv_scale, int B, int H, int S,
+                           hipStream_t st);
+int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st);
 int cw_launch_align_normalize(float* align, const float* align_ml, int B, int n_align, int align_rows, int L,
                               int n_keys, hipStream_t st);
 struct CombineParams {     // activations of a GEMV = combination of ATT_NS attention partials

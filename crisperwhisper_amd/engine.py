@@ -57,7 +57,10 @@ class EngineError(RuntimeError):
 
 
 class Engine:
-    def __init__(self, spec: ModelSpec, dtype: str = "bf16", max_batch: int = 16, device: int = 0):
+    def __init__(self, spec: ModelSpec, dtype: str = "bf16", max_batch: int = 16, device: int = 0,
+                 cross_kv_dtype: Optional[str] = None):
+        """``cross_kv_dtype="fp8"`` (bf16 engine only): the decode step streams an OCP e4m3 copy of the cross-attention
+        cache, half the bytes of its dominant stream -- an accuracy-gated performance mode, not the parity path."""
         self.lib = N.load()
         self.spec = spec
         self.dtype = dtype
@@ -85,6 +88,10 @@ class Engine:
             begin_suppress_tokens=bsup.ctypes.data_as(C.POINTER(C.c_int32)), n_begin_suppress=len(bsup))
         self._chk(self.lib.cw_set_generation(self.ctx, C.byref(cfg)))
         self._capture = None
+        if cross_kv_dtype not in (None, "bf16", "f32", "fp8"):
+            raise ValueError(f"cross_kv_dtype must be None or 'fp8', got {cross_kv_dtype!r}")
+        if cross_kv_dtype == "fp8":
+            self._chk(self.lib.cw_set_option(self.ctx, b"cross_kv_fp8", 1))
 
     # ------------------------------------------------------------------
     def _chk(self, rc: int):

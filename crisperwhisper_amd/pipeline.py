@@ -82,7 +82,7 @@ def _device_index(device) -> int:
 class CrisperWhisperPipeline:
     def __init__(self, model, tokenizer=None, feature_extractor=None, chunk_length_s=0, stride_length_s=None,
                  batch_size=1, return_timestamps=None, torch_dtype=None, dtype=None, device=None,
-                 shard: Optional[dist.Shard] = None, contexts: int = 1, **kwargs):
+                 shard: Optional[dist.Shard] = None, contexts: int = 1, cross_kv_dtype: Optional[str] = None, **kwargs):
         self.bundle = model if isinstance(model, ModelBundle) else ModelBundle.from_hf(model)
         if tokenizer is None:
             raise ValueError("a tokenizer (WhisperTokenizer or crisperwhisper_amd.collate.Vocabulary) is required")
@@ -98,7 +98,8 @@ class CrisperWhisperPipeline:
         # `contexts` > 1: independent engine contexts on the same GPU, each running its own batches from a host
         # thread -- the decode chain is latency-bound, so a second in-flight batch fills idle CUs.
         self.engines = [Engine(self.bundle.spec, dtype=_dtype_name(dtype if dtype is not None else torch_dtype),
-                               max_batch=self.batch_size, device=_device_index(device)) for _ in range(max(1, int(contexts)))]
+                               max_batch=self.batch_size, device=_device_index(device), cross_kv_dtype=cross_kv_dtype)
+                        for _ in range(max(1, int(contexts)))]
         for e in self.engines:
             e.load_state_dict(self.bundle.weights)
         self.engine = self.engines[0]

@@ -64,6 +64,10 @@ int32_t cw_sync(cw_ctx* ctx);
  * the conv kernels for implicit GEMM.  proj_out.weight is tied to embed_tokens (:965) and ignored.     */
 int32_t cw_load_tensor(cw_ctx* ctx, const char* hf_name, const float* data, const int64_t* shape, int32_t ndim);
 int32_t cw_set_generation(cw_ctx* ctx, const cw_gen_cfg* cfg);
+/* Context options (before cw_encode).  "cross_kv_fp8" = 1: the cross-attention K/V cache is additionally stored in OCP
+ * e4m3 with one scale per (chunk, head, K|V) and the decode step streams that copy (half the bytes of the dominant
+ * stream; bf16 engine only; an accuracy-gated performance mode, BASELINE configs[3], not the parity path).        */
+int32_t cw_set_option(cw_ctx* ctx, const char* name, int32_t value);
 
 /* ---- audio ingest (the step in front of seam 1) -------------------------------------------------
  * cw_ingest: interleaved little-endian sample frames as they sit in a RIFF/WAVE data chunk -> mono f32 at sr_out, on

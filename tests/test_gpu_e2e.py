@@ -435,3 +435,47 @@ def test_full_size_bf16_engine_tracks_f32_engine():
     finally:
         for e in engs.values():
             e.close()
+
+
+def test_fp8_cross_kv_cache_tracks_bf16_cache():
+    """Opt-in e4m3 cross-attention cache (cw_set_option "cross_kv_fp8") against the bf16 cache of the same engine
+    build, large-v3 shapes on a 2 + 2 layer stack, teacher-forced: the accuracy gate of that mode.  Logits within
+    4 % of the logit range, >= 90 % top-1 agreement, alignment rows within 0.1 abs and correlated > 0.99 (3-bit mantissa
+    keys move individual probabilities by a few percent); the f32 engine refuses the option."""
+    g, v = syn.large_v3_geometry()
+    g.enc_layers = g.dec_layers = 2
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19)]
+    W = syn.random_weights(g, seed=7)
+    clips = [syn.synth_audio(300 + i, 480000 - 60000 * i, ("mixed", "noise", "chirp")[i]) for i in range(3)]
+    T = 3 + 24
+    prompt = np.tile(np.array([[v.sot, v.lang_id("en"), v.transcribe]], np.int32), (3, 1))
+    res = {}
+    forced = None
+    for kv in (None, "fp8"):
+        e = Engine(spec, dtype="bf16", max_batch=3, cross_kv_dtype=kv)
+        try:
+            e.load_state_dict(W)
+            e.mel(clips)
+            e.encode([0, 1, 2], [0, 0, 0], [3000, 3000, 3000])
+            cap = e.capture_logits(3, T)
+            seqs, lens, amax = e.decode(prompt, max_length=T, min_new_tokens=24, forced=forced, want_argmax=True)
+            e.stop_capture()
+            if forced is None:
+                forced = np.full((3, T), -1, np.int32); forced[:, 3:] = seqs[:, 3:T]
+            res[kv] = dict(logits=cap[:T - 3].copy(), amax=amax[:, 3:T].copy(), al=e.alignment(3, T - 1))
+            # the graph path must agree with the eager (capture) path in this mode too
+            seqs2, _, amax2 = e.decode(prompt, max_length=T, min_new_tokens=24, forced=forced, want_argmax=True)
+            assert (amax2[:, 3:T] == res[kv]["amax"]).mean() >= 0.95
+        finally:
+            e.close()
+    a, b = res[None], res["fp8"]
+    rng_ = a["logits"].max() - a["logits"].min()
+    assert np.abs(a["logits"] - b["logits"]).max() < 0.04 * rng_, np.abs(a["logits"] - b["logits"]).max() / rng_
+    assert (a["amax"] == b["amax"]).mean() >= 0.9, (a["amax"] == b["amax"]).mean()
+    assert np.abs(a["al"] - b["al"]).max() < 0.1, np.abs(a["al"] - b["al"]).max()
+    cc = np.corrcoef(a["al"].ravel(), b["al"].ravel())[0, 1]
+    assert cc > 0.99, cc
+    assert np.abs(b["al"].sum(-1) - 1).max() < 2e-3
+    with pytest.raises(Exception):
+        Engine(spec, dtype="f32", max_batch=1, cross_kv_dtype="fp8")
