@@ -116,9 +116,15 @@ def _native_vocab(vocab: "Vocabulary"):
     return h
 
 
-def decode_asr(vocab: Vocabulary, model_outputs: List[dict], time_precision: float = 0.02, warn=None):
+def decode_asr(vocab: Vocabulary, model_outputs: List[dict], time_precision: float = 0.02, warn=None,
+               return_timestamps="word"):
     """model_outputs: [{"tokens", "token_timestamps", optional "stride": (len_s, left_s, right_s)}] in audio
-    order -> (text, [{"text", "timestamp": (start, end)}]).  Runs in libcrisperwhisper.so (csrc/collate.cpp)."""
+    order -> (text, [{"text", "timestamp": (start, end)}]).  Runs in libcrisperwhisper.so (csrc/collate.cpp).
+    ``return_timestamps="word"``: word chunks; ``True``: one chunk per timestamp-delimited segment (token_timestamps
+    not needed; a missing boundary is None, as in the reference)."""
+    if return_timestamps not in ("word", True):
+        raise ValueError("return_timestamps must be 'word' or True")
+    seg = return_timestamps is True
     import ctypes as C
     from . import _native
     lib = _native.load()
@@ -126,9 +132,11 @@ def decode_asr(vocab: Vocabulary, model_outputs: List[dict], time_precision: flo
     if not col:
         raise RuntimeError("cw_collate_begin failed")
     try:
+        if seg:
+            lib.cw_collate_set_mode(col, 1)
         for out in model_outputs:
             toks = np.ascontiguousarray(np.asarray(out["tokens"]).reshape(-1), dtype=np.int64)
-            ts = np.ascontiguousarray(np.asarray(out["token_timestamps"]).reshape(-1), dtype=np.float32)
+            ts = np.ascontiguousarray(np.asarray(out.get("token_timestamps", np.zeros(0))).reshape(-1), dtype=np.float32)
             stride = out.get("stride")
             cl, sl, sr = (stride if stride is not None else (0.0, 0.0, 0.0))
             rc = lib.cw_collate_feed(col, toks.ctypes.data_as(C.c_void_p), len(toks), ts.ctypes.data_as(C.c_void_p),
@@ -149,7 +157,9 @@ def decode_asr(vocab: Vocabulary, model_outputs: List[dict], time_precision: flo
         lib.cw_collate_get(col, text.ctypes.data_as(C.c_void_p), starts.ctypes.data_as(C.c_void_p),
                            ends.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), blob.ctypes.data_as(C.c_void_p))
         raw = blob.tobytes()
-        words = [{"text": raw[offs[k]:offs[k + 1]].decode("utf-8"), "timestamp": (float(starts[k]), float(ends[k]))}
+        def _t(x):
+            return None if x != x else float(x)                  # NaN = no timestamp predicted (segment mode)
+        words = [{"text": raw[offs[k]:offs[k + 1]].decode("utf-8"), "timestamp": (_t(starts[k]), _t(ends[k]))}
                  for k in range(n)]
         return text.tobytes()[:tb.value].decode("utf-8"), words
     finally:

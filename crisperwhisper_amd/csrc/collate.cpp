@@ -121,6 +121,7 @@ struct cw_collator {
     bool has_open; double open_start;
     bool skip;
     bool warned;
+    int mode;                            // 0: word chunks (return_timestamps="word"), 1: one chunk per timestamp-delimited segment (True)
     std::string err;
 
     void merge_overlapping(std::vector<int>& toks, std::vector<Span>& ts) {
@@ -138,7 +139,7 @@ struct cw_collator {
                 const int r0 = span - nl > 0 ? span - nl : 0, r1 = nr < span ? nr : span;
                 int hits = 0;
                 for (int k = 0; k < l1 - l0; ++k)
-                    if (left[l0 + k] == right[r0 + k] && left_ts[l0 + k] <= right_ts[r0 + k]) ++hits;
+                    if (left[l0 + k] == right[r0 + k] && (mode != 0 || left_ts[l0 + k] <= right_ts[r0 + k])) ++hits;
                 const double score = (double)hits / (double)span + (double)span / 10000.0;
                 if (hits > 1 && score > best) { best = score; wl0 = l0; wl1 = l1; wr0 = r0; wr1 = r1; }
             }
@@ -152,12 +153,20 @@ struct cw_collator {
         ts.insert(ts.end(), left_ts.begin(), left_ts.end());
     }
 
-    void flush() {
+    // end_time: the closing timestamp of the segment (NaN: Whisper predicted none), used by the segment mode only
+    void flush(double end_time) {
         std::vector<int> toks; std::vector<Span> ts;
         merge_overlapping(toks, ts);
         U32 whole;
         v->text(toks, whole);
         full_text += whole;
+        if (mode == 1) {                                         // :1060-1075 without the word collation
+            Word w; w.text = whole; w.start = has_open ? open_start : NAN; w.end = end_time;
+            words.push_back(w);
+            pending.clear(); pending_ts.clear();
+            has_open = false;
+            return;
+        }
         // unicode pieces (:1315-1344)
         std::vector<U32> pieces; std::vector<std::vector<int>> pidx;
         {
@@ -236,8 +245,13 @@ cw_collator* cw_collate_begin(const cw_vocab* v, double time_precision) {
     if (!v) return nullptr;
     cw_collator* c = new cw_collator();
     c->v = v; c->tp = time_precision; c->segment_size = 1500; c->lang_class = -1; c->time_offset = 0.0;
-    c->has_open = false; c->open_start = 0.0; c->skip = false; c->warned = false;
+    c->has_open = false; c->open_start = 0.0; c->skip = false; c->warned = false; c->mode = 0;
     return c;
+}
+int32_t cw_collate_set_mode(cw_collator* c, int32_t mode) {
+    if (!c || mode < 0 || mode > 1) return -22;
+    c->mode = mode;
+    return 0;
 }
 void cw_collate_free(cw_collator* c) { delete c; }
 
@@ -289,12 +303,13 @@ int32_t cw_collate_feed(cw_collator* c, const int64_t* tokens, int32_t n_tokens,
             else if (!c->has_open) { c->has_open = true; c->open_start = when; }
             else if (when != c->open_start) {
                 c->pending.push_back(cur); c->pending_ts.push_back(cur_ts);
-                c->flush();
+                c->flush(when);
                 cur.clear(); cur_ts.clear();
             }
         } else {
-            if (i >= n_ts) { c->err = "token_timestamps shorter than tokens"; return -22; }
             cur.push_back(t);
+            if (c->mode == 1) { cur_ts.push_back(Span(0.0, 0.0)); continue; }
+            if (i >= n_ts) { c->err = "token_timestamps shorter than tokens"; return -22; }
             const double begin = (i == 0) ? py_round2(0.0 + c->time_offset) : py_round2((double)token_ts[i - 1] + c->time_offset);
             cur_ts.push_back(Span(begin, py_round2((double)token_ts[i] + c->time_offset)));
         }
@@ -310,7 +325,7 @@ int32_t cw_collate_feed(cw_collator* c, const int64_t* tokens, int32_t n_tokens,
 }
 
 int32_t cw_collate_finish(cw_collator* c, int32_t* n_words, int64_t* text_bytes, int64_t* words_bytes, int32_t* warned) {
-    if (!c->pending.empty()) { c->warned = true; c->flush(); }
+    if (!c->pending.empty()) { c->warned = true; c->flush(NAN); }
     std::string s;
     utf8_encode(c->full_text, s);
     int64_t wb = 0;

@@ -146,9 +146,10 @@ class CrisperWhisperPipeline:
     def _run_one(self, inputs, return_timestamps=None, generate_kwargs=None, chunk_length_s=None,
                  stride_length_s=None, return_language=None, **unused):
         rt = return_timestamps if return_timestamps is not None else self.return_timestamps
-        if rt not in ("word",):
-            raise ValueError("crisperwhisper_amd implements the word-timestamp path: pass return_timestamps='word' "
-                             "(CrisperWhisper's purpose, REF/transcribe.py:28)")
+        if not (rt == "word" or rt is True):
+            raise ValueError("crisperwhisper_amd implements the timestamped paths: pass return_timestamps='word' "
+                             "(CrisperWhisper's purpose, REF/transcribe.py:28) or True (segment-level chunks, the "
+                             "setting REF/app.py:51-61 constructs its pipeline with)")
         if return_language:
             raise ValueError("return_language is not supported on the native path")
         gk = dict(generate_kwargs or {})
@@ -215,7 +216,8 @@ class CrisperWhisperPipeline:
             if with_stride:
                 o["stride"] = stride
             outputs.append(o)
-        text, words = collate.decode_asr(self.vocab, outputs, time_precision=0.02, warn=logger.warning)
+        text, words = collate.decode_asr(self.vocab, outputs, time_precision=0.02, warn=logger.warning,
+                                         return_timestamps="word" if rt == "word" else True)
         return {"text": text, "chunks": words}
 
 

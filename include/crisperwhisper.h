@@ -169,6 +169,9 @@ cw_vocab* cw_vocab_create(int32_t n_tokens, const uint8_t* blob, const int64_t* 
                           int32_t sot, int32_t default_lang_class);
 void cw_vocab_destroy(cw_vocab* v);
 cw_collator* cw_collate_begin(const cw_vocab* v, double time_precision);
+/* mode 0 (default): word chunks (return_timestamps="word"); mode 1: one chunk per timestamp-delimited segment
+ * (return_timestamps=True, :1060-1075): token_ts is ignored, a missing start/end comes back as NaN                   */
+int32_t cw_collate_set_mode(cw_collator* c, int32_t mode);
 /* one pipeline output (chunk) in audio order: tokens [n_tokens], token_ts [n_ts] seconds, stride in seconds     */
 int32_t cw_collate_feed(cw_collator* c, const int64_t* tokens, int32_t n_tokens, const float* token_ts, int32_t n_ts,
                         int32_t has_stride, double chunk_len, double stride_left, double stride_right);

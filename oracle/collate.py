@@ -150,11 +150,14 @@ def strip_prompt(ids, prompt_id, sot):
     return ids
 
 
-def decode_asr(tok: ByteVocab, model_outputs, time_precision=0.02, segment_size=1500):
-    """:901-1150 with return_timestamps="word", return_language=None.
+def decode_asr(tok: ByteVocab, model_outputs, time_precision=0.02, segment_size=1500, return_timestamps="word"):
+    """:901-1150 with return_timestamps="word" (default) or True (segment chunks), return_language=None.
 
-    model_outputs: list of {"tokens": [L] ints, "token_timestamps": [L'] floats,
-    optional "stride": (chunk_len_s, left_s, right_s)}.  Returns (text, word chunks)."""
+    model_outputs: list of {"tokens": [L] ints, "token_timestamps": [L'] floats (word mode only),
+    optional "stride": (chunk_len_s, left_s, right_s)}.  Returns (text, chunks): word chunks, or for
+    return_timestamps=True one {"text", "timestamp": (start, end)} per timestamp-delimited segment
+    (end is None when Whisper did not predict an ending timestamp)."""
+    word = return_timestamps == "word"
     last_language = None
 
     def new_chunk():
@@ -169,7 +172,7 @@ def decode_asr(tok: ByteVocab, model_outputs, time_precision=0.02, segment_size=
     right_stride_start = None
     for output in model_outputs:
         token_ids = strip_prompt([int(t) for t in output["tokens"]], tok.startofprev, tok.sot)
-        token_timestamps = [float(t) for t in output["token_timestamps"]]
+        token_timestamps = [float(t) for t in output["token_timestamps"]] if word else []
         last_timestamp = None
         first_timestamp = tb
         cur_max_timestamp = 0.0
@@ -220,35 +223,42 @@ def decode_asr(tok: ByteVocab, model_outputs, time_precision=0.02, segment_size=
                     else:
                         chunk["timestamp"][1] = time
                         previous_tokens.append(current_tokens)
-                        previous_ts.append(current_ts)
+                        if word:
+                            previous_ts.append(current_ts)
                         rt, rts = find_longest_common_sequence(previous_tokens, previous_ts)
                         chunk["text"] = tok.decode(rt)
-                        chunk["words"] = collate_word_timestamps(tok, rt, rts, last_language or "english")
+                        if word:
+                            chunk["words"] = collate_word_timestamps(tok, rt, rts, last_language or "english")
                         chunks.append(chunk)
                         previous_tokens, current_tokens, previous_ts, current_ts = [], [], [], []
                         chunk = new_chunk()
             else:
                 current_tokens.append(token)
-                if i == 0:
-                    start_time = round(0.0 + time_offset, 2)
-                else:
-                    start_time = round(token_timestamps[i - 1] + time_offset, 2)
-                end_time = round(token_timestamps[i] + time_offset, 2)
-                current_ts.append((start_time, end_time))
+                if word:
+                    if i == 0:
+                        start_time = round(0.0 + time_offset, 2)
+                    else:
+                        start_time = round(token_timestamps[i - 1] + time_offset, 2)
+                    end_time = round(token_timestamps[i] + time_offset, 2)
+                    current_ts.append((start_time, end_time))
         if "stride" in output:
             time_offset += chunk_len - stride_right
         if current_tokens:
             previous_tokens.append(current_tokens)
-            previous_ts.append(current_ts)
+            if word:
+                previous_ts.append(current_ts)
         elif not any(p for p in previous_tokens):
             chunk = new_chunk()
             previous_tokens, current_tokens, previous_ts, current_ts = [], [], [], []
     if previous_tokens:
         rt, rts = find_longest_common_sequence(previous_tokens, previous_ts)
         chunk["text"] = tok.decode(rt)
-        chunk["words"] = collate_word_timestamps(tok, rt, rts, last_language or "english")
+        if word:
+            chunk["words"] = collate_word_timestamps(tok, rt, rts, last_language or "english")
         chunks.append(chunk)
     full_text = "".join(c["text"] for c in chunks)
+    if not word:
+        return full_text, [{"text": c["text"], "timestamp": tuple(c["timestamp"])} for c in chunks]
     words = []
     for c in chunks:
         words.extend(c["words"])

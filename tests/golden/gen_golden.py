@@ -157,12 +157,36 @@ def gen_e2e():
     np.savez_compressed(os.path.join(OUT, "e2e_golden.npz"), **arrays)
 
 
+def gen_segments():
+    """return_timestamps=True (segment-level chunks): the setting REF/app.py:51-61 builds its pipeline with."""
+    g, v, W, model = build_tiny()
+    tok = H.build_tokenizer(v)
+    fe = H.build_feature_extractor(g)
+    scenarios = {
+        "mixed70_b2_n40": ("mixed", 70, 0, 2, {"max_new_tokens": 40}),
+        "noise35_b4_free": ("noise", 35, 5, 4, {}),
+        "chirp12_b1_n24": ("chirp", 12, 2, 1, {"max_new_tokens": 24, "min_new_tokens": 24}),
+    }
+    meta = {}
+    for name, (kind, secs, seed, bs, extra) in scenarios.items():
+        x = syn.synth_audio(seed, int(round(secs * 16000)), kind)
+        pipe = H.build_pipeline(model, tok, fe, batch_size=bs)
+        res = pipe(x.copy(), return_timestamps=True, generate_kwargs={**GEN_KW, **extra})
+        meta[name] = {"kind": kind, "secs": secs, "seed": seed, "batch_size": bs, "extra": extra, "text": res["text"],
+                      "chunks": [{"text": c["text"], "timestamp": list(c["timestamp"])} for c in res["chunks"]]}
+    json.dump(meta, open(os.path.join(OUT, "e2e_segments_golden.json"), "w"), ensure_ascii=True, indent=0)
+
+
 def main():
+    if "--segments-only" in sys.argv:
+        gen_segments(); print("segments ok")
+        return
     torch.manual_seed(0)
     gen_mel(); print("mel ok")
     gen_align(); print("align ok")
     gen_pauses(); print("pauses ok")
     gen_e2e(); print("e2e ok")
+    gen_segments(); print("segments ok")
     for f in sorted(os.listdir(OUT)):
         if f.endswith((".npz", ".json")):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -479,3 +479,25 @@ def test_fp8_cross_kv_cache_tracks_bf16_cache():
     assert np.abs(b["al"].sum(-1) - 1).max() < 2e-3
     with pytest.raises(Exception):
         Engine(spec, dtype="f32", max_batch=1, cross_kv_dtype="fp8")
+
+
+@pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24"])
+def test_pipeline_segment_timestamps_vs_reference(tiny, name):
+    """return_timestamps=True (segment-level chunks, what REF/app.py:51-61 constructs its pipeline with), f32 engine,
+    against the transformers CPU output: identical text, chunk texts and chunk timestamps."""
+    g, v, W, spec = tiny
+    meta = Hh.gold_json("e2e_segments_golden.json")[name]
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
+    pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30,
+                       batch_size=meta["batch_size"], return_timestamps=True, torch_dtype="float32", device="cuda:0")
+    try:
+        out = pipe(x, generate_kwargs={**Hh.GEN_KW, **meta["extra"]})
+        assert out["text"] == meta["text"]
+        assert [(c["text"], list(c["timestamp"])) for c in out["chunks"]] == [(c["text"], c["timestamp"]) for c in meta["chunks"]]
+        out_w = pipe(x, return_timestamps="word", generate_kwargs={**Hh.GEN_KW, **meta["extra"]})     # per-call override (REF/app.py:102)
+        assert out_w["text"] == Hh.gold_json("e2e_golden.json")[name]["text"]    # (seam merging differs between the two modes)
+        with pytest.raises(ValueError):
+            pipe(x, return_timestamps=False)
+    finally:
+        pipe.engine.close()

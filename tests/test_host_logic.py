@@ -79,6 +79,11 @@ def test_host_control_flow_word_for_word(name):
     assert text == meta["text"]
     ok, why = Hh.words_equal(words, meta["chunks"])
     assert ok, why
+    seg = Hh.gold_json("e2e_segments_golden.json").get(name)
+    if seg is not None:      # same tokens, segment-level chunks (return_timestamps=True) vs the transformers pipeline output
+        text_s, chunks_s = collate.decode_asr(vocab, [{k: o[k] for k in ("tokens", "stride")} for o in outputs], return_timestamps=True)
+        assert text_s == seg["text"]
+        assert [(c["text"], list(c["timestamp"])) for c in chunks_s] == [(c["text"], c["timestamp"]) for c in seg["chunks"]]
 
 
 def test_collation_matches_oracle_on_random_token_streams():

@@ -123,6 +123,17 @@ def test_collation_matches_transformers_live_on_random_streams():
             assert got[0] == text, trial
             ok, why = Hh.words_equal(got[1], opt["chunks"])
             assert ok, (trial, why)
+        # segment-level chunks (return_timestamps=True; REF/app.py:51-61 builds its pipeline that way): same streams
+        # without token timestamps, sometimes with the last closing timestamp cut off (-> end None + warning path)
+        cut = trial % 3 == 0
+        outs_s = [{"tokens": (o["tokens"][:-1] if cut and k == len(outs) - 1 else o["tokens"]), "stride": o["stride"]} for k, o in enumerate(outs)]
+        hf_s = [{"tokens": torch.tensor(o["tokens"])[None], "stride": o["stride"]} for o in outs_s]
+        text_s, opt_s = tok._decode_asr(hf_s, return_timestamps=True, return_language=None, time_precision=0.02)
+        a = OC.decode_asr(ov, [dict(o) for o in outs_s], return_timestamps=True)
+        b = collate.decode_asr(pv, [dict(o) for o in outs_s], return_timestamps=True)
+        for got in (a, b):
+            assert got[0] == text_s, trial
+            assert [(c["text"], tuple(c["timestamp"])) for c in got[1]] == [(c["text"], tuple(c["timestamp"])) for c in opt_s["chunks"]], trial
 
 
 def test_dtw_property_random_shapes_and_ties():
