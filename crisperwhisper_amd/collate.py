@@ -58,13 +58,67 @@ class Vocabulary:
                     table.append(bytes(u2b[ch] for ch in s))
                 except KeyError:
                     table.append(s.encode("utf-8"))
-        try:
-            from transformers.models.whisper.tokenization_whisper import LANGUAGES
-            langs = dict(LANGUAGES)
-        except Exception:  # pragma: no cover
-            langs = {}
+        from .languages import LANGUAGES
         return cls(table, specials, tok.eos_token_id, tb, tok.convert_tokens_to_ids("<|startofprev|>"),
-                   tok.convert_tokens_to_ids("<|startoftranscript|>"), langs, getattr(tok, "language", None))
+                   tok.convert_tokens_to_ids("<|startoftranscript|>"), dict(LANGUAGES), getattr(tok, "language", None))
+
+    @classmethod
+    def from_pretrained(cls, path: str) -> "Vocabulary":
+        """Build the table from a checkpoint directory (or a ``tokenizer.json`` path) without ``transformers``:
+        the byte-level BPE vocabulary of ``tokenizer.json`` (``model.vocab`` + ``added_tokens``; falls back to
+        ``vocab.json`` + ``added_tokens.json``).  Decoding needs no merges: a token string maps to bytes through the
+        GPT-2 unicode<->byte alphabet.  Replaces ``AutoProcessor.from_pretrained(...).tokenizer`` (REF/transcribe.py:19)."""
+        import json
+        import os
+        from .languages import LANGUAGES
+        from .synthetic import bytes_to_unicode
+        base = path if os.path.isdir(path) else os.path.dirname(path)
+        tj = path if os.path.isfile(path) else os.path.join(base, "tokenizer.json")
+        ids: Dict[int, str] = {}
+        special_ids = set()
+        if os.path.exists(tj):
+            j = json.load(open(tj, encoding="utf-8"))
+            for s, i in j["model"]["vocab"].items():
+                ids[int(i)] = s
+            for a in j.get("added_tokens", []):
+                ids[int(a["id"])] = a["content"]
+                if a.get("special"):
+                    special_ids.add(int(a["id"]))
+        else:
+            vj = os.path.join(base, "vocab.json")
+            if not os.path.exists(vj):
+                raise FileNotFoundError(f"neither tokenizer.json nor vocab.json under {base}")
+            for s, i in json.load(open(vj, encoding="utf-8")).items():
+                ids[int(i)] = s
+            aj = os.path.join(base, "added_tokens.json")
+            if os.path.exists(aj):
+                for s, i in json.load(open(aj, encoding="utf-8")).items():
+                    ids[int(i)] = s
+        n = max(ids) + 1
+        by_name = {s: i for i, s in ids.items()}
+        if "<|notimestamps|>" not in by_name or "<|endoftext|>" not in by_name:
+            raise ValueError("not a Whisper vocabulary: <|notimestamps|> / <|endoftext|> missing")
+        tb = by_name["<|notimestamps|>"] + 1
+        eos = by_name["<|endoftext|>"]
+        u2b = {c: b for b, c in bytes_to_unicode().items()}
+        table: List[Optional[bytes]] = []
+        specials: Dict[int, str] = {}
+        for i in range(n):
+            s = ids.get(i)
+            # specials: flagged in tokenizer.json, else every <|...|> tag below the timestamp range
+            is_special = (i in special_ids) if special_ids else (s is not None and i < tb and s.startswith("<|") and s.endswith("|>"))
+            if s is None or i >= tb:
+                table.append(None)
+            elif is_special:
+                specials[i] = s
+                table.append(None)
+            else:
+                try:
+                    table.append(bytes(u2b[ch] for ch in s))
+                except KeyError:
+                    table.append(s.encode("utf-8"))
+        return cls(table, specials, eos, tb, by_name.get("<|startofprev|>"), by_name.get("<|startoftranscript|>"),
+                   dict(LANGUAGES), None)
 
     def text(self, ids: Sequence[int]) -> str:
         buf = bytearray()

@@ -501,3 +501,30 @@ def test_pipeline_segment_timestamps_vs_reference(tiny, name):
             pipe(x, return_timestamps=False)
     finally:
         pipe.engine.close()
+
+
+def test_pipeline_from_checkpoint_directory_without_transformers_objects(tiny, tmp_path):
+    """`pipeline(model="<local snapshot dir>")`: config / generation config / safetensors / tokenizer.json read natively
+    (the snapshot is written by transformers' save_pretrained), f32 engine, word for word against the golden."""
+    pytest.importorskip("transformers")
+    import torch
+    from tests.golden import hf_synth as H
+    g, v, W, spec = tiny
+    model = H.build_model(g, v, n_align=3)
+    sd = {k: torch.from_numpy(x) for k, x in W.items()}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    model.load_state_dict(sd, strict=True)
+    model.generation_config.alignment_heads = syn.alignment_heads(g, 3)
+    d = str(tmp_path / "ckpt")
+    model.save_pretrained(d); H.build_tokenizer(v).save_pretrained(d); H.build_feature_extractor(g).save_pretrained(d)
+    meta = Hh.gold_json("e2e_golden.json")["mixed70_b2_n40"]
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
+    pipe = cw.pipeline("automatic-speech-recognition", model=d, chunk_length_s=30, batch_size=meta["batch_size"],
+                       return_timestamps="word", torch_dtype="float32", device="cuda:0")
+    try:
+        out = pipe(x, generate_kwargs={**Hh.GEN_KW, **meta["extra"]})
+        assert out["text"] == meta["text"]
+        ok, why = Hh.words_equal(out["chunks"], meta["chunks"], tol=0.02)
+        assert ok, why
+    finally:
+        pipe.engine.close()

@@ -188,3 +188,42 @@ def test_missing_native_library_fails_loudly(monkeypatch):
         Engine(spec, dtype="f32", max_batch=1)
     with pytest.raises(_native.NativeLibraryError):
         collate.decode_asr(collate.Vocabulary.from_synthetic(v), [])
+
+
+def test_checkpoint_directory_loads_without_transformers(tmp_path):
+    """ModelBundle.from_pretrained / Vocabulary.from_pretrained read config.json, generation_config.json, model.safetensors
+    and tokenizer.json (or vocab.json + added_tokens.json) themselves; the result equals what the transformers objects give
+    (REF/transcribe.py:14-19 replaced for a local snapshot).  The checkpoint is written by transformers' save_pretrained."""
+    pytest.importorskip("transformers")
+    import dataclasses
+    import json
+    import crisperwhisper_amd as cw
+    from crisperwhisper_amd.languages import LANGUAGES
+    from transformers.models.whisper.tokenization_whisper import LANGUAGES as HF_LANGUAGES
+    from tests.golden import hf_synth as H
+    assert LANGUAGES == dict(HF_LANGUAGES)
+    g, v = syn.tiny_geometry()
+    model = H.build_model(g, v, n_align=3)
+    tok, fe = H.build_tokenizer(v), H.build_feature_extractor(g)
+    d = str(tmp_path / "ckpt")
+    model.save_pretrained(d); tok.save_pretrained(d); fe.save_pretrained(d)
+    a, b = cw.ModelBundle.from_hf(model), cw.ModelBundle.from_pretrained(d)
+    assert dataclasses.asdict(a.spec) == dataclasses.asdict(b.spec)
+    wb = dict(b.weights.items())
+    assert set(wb) == set(a.weights) and all(np.array_equal(a.weights[k], wb[k]) for k in a.weights)
+    va, vb = collate.Vocabulary.from_hf_tokenizer(tok), collate.Vocabulary.from_pretrained(d)
+    key = lambda x: (x.token_bytes, x.specials, x.eos, x.timestamp_begin, x.startofprev, x.sot)
+    assert key(va) == key(vb)
+    # older snapshots: vocab.json + added_tokens.json instead of tokenizer.json
+    tj = json.load(open(f"{d}/tokenizer.json"))
+    d2 = tmp_path / "old"; d2.mkdir()
+    json.dump(tj["model"]["vocab"], open(d2 / "vocab.json", "w"))
+    json.dump({t["content"]: t["id"] for t in tj["added_tokens"]}, open(d2 / "added_tokens.json", "w"))
+    assert key(collate.Vocabulary.from_pretrained(str(d2))) == key(va)
+    # reference-style errors
+    gcfg = json.load(open(f"{d}/generation_config.json")); gcfg.pop("alignment_heads")
+    json.dump(gcfg, open(f"{d}/generation_config.json", "w"))
+    with pytest.raises(ValueError, match="alignment_heads"):
+        cw.ModelBundle.from_pretrained(d)
+    with pytest.raises(FileNotFoundError):
+        collate.Vocabulary.from_pretrained(str(tmp_path))
