@@ -241,10 +241,7 @@ def main():
                                    f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, greedy, word timestamps"
                                    + (", fp8 (e4m3) cross-attention cache [opt-in mode]" if a.cross_kv == "fp8" else ""),
                        "chunks_per_gpu": B * C, "contexts_per_gpu": C, "tokens_per_chunk": a.tokens, "parallelism": f"chunk-dp{world}",
-                       "cross_kv_cache": a.cross_kv, "weight_load_s": round(t_load, 1),
-                       "note": "ms_per_step / rtf are the stable quantities: with random weights the transcript (and so the word "
-                               "count behind `value`) varies run to run by ~+-15 % in bf16, whose K-split GEMVs accumulate with f32 "
-                               "atomics (not bit-reproducible); the f32 engine is deterministic"},
+                       "cross_kv_cache": a.cross_kv, "weight_load_s": round(t_load, 1)},
             "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1) / C, 3) for k, val in stages.items()},
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
                          "frac": r["achieved"] / 8000.0,

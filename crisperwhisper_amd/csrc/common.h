@@ -44,6 +44,14 @@ __device__ inline float gelu_erf(float x) {  // nn.functional.gelu default (exac
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// Decode residual stream of the bf16 engine on a 2^-12 grid.  The K-split GEMVs accumulate their partial sums into the
+// f32 residual with atomics, whose order varies from run to run; f32 addition is exact -- and therefore order-independent
+// -- when every operand is a multiple of one quantum q and the sums stay below 2^24 q.  So the embedding and every
+// residual update are rounded to multiples of q = 2^-12 (|x| < 4096 stays exact; 1.2e-4 absolute, far below the bf16
+// rounding the next GEMV applies to the normalised row): the engine becomes bit-reproducible run to run at the cost of
+// two VALU ops per output element and no extra traffic or synchronisation.
+__device__ inline float resid_grid(float v) { return rintf(v * 4096.0f) * (1.0f / 4096.0f); }
+
 // Wave-wide reductions on the DPP path (VALU cross-lane moves, a few cycles each).  __shfl_xor compiles to
 // ds_bpermute_b32 -- an LDS-crossbar round trip of ~100+ cycles per step, 6 dependent steps per reduction: measured
 // 1.2-1.5 us for the four reductions of a fused LayerNorm, which sat on the critical path of every decode GEMV.

@@ -87,8 +87,10 @@ __global__ void embed_kernel(const int* __restrict__ ids, int ids_stride, int t,
                              const float* __restrict__ pos_embed, float* __restrict__ x_out, int d) {
     const int b = blockIdx.x;
     const int tok = ids[(size_t)b * ids_stride + t];
-    for (int k = threadIdx.x; k < d; k += blockDim.x)
-        x_out[(size_t)b * d + k] = Act<T>::ld(embed + (size_t)tok * d + k) + pos_embed[(size_t)t * d + k];
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        const float v = Act<T>::ld(embed + (size_t)tok * d + k) + pos_embed[(size_t)t * d + k];
+        x_out[(size_t)b * d + k] = sizeof(T) == 2 ? resid_grid(v) : v;     // bf16 engine: residual stream on the 2^-12 grid
+    }
 }
 
 __global__ void set_pos_kernel(int* pos, int value, int B) {
@@ -256,7 +258,10 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
     if (p.x_out && t < max_length) {
         const T* e = (const T*)p.embed + (size_t)tok * p.d;
         const float* pe = p.pos_embed + (size_t)t * p.d;
-        for (int k = tid; k < p.d; k += blockDim.x) p.x_out[(size_t)b * p.d + k] = Act<T>::ld(e + k) + pe[k];
+        for (int k = tid; k < p.d; k += blockDim.x) {
+            const float v = Act<T>::ld(e + k) + pe[k];
+            p.x_out[(size_t)b * p.d + k] = sizeof(T) == 2 ? resid_grid(v) : v;
+        }
     }
 }
 

@@ -593,7 +593,12 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const float* __restrict_
 #pragma unroll
                     for (int w = 0; w < 4; ++w) v += red[((w * 4 + t) * 4 + r) * 64 + lane];
                     int m = t * 16 + g * 4 + r;
-                    if (m < Mb && n < N) epi_store1<bf16_t, EPI>(ep, m, n, v);
+                    if (m < Mb && n < N) {
+                        if (EPI == EPI_RESID_F32) {      // keep the residual stream on the 2^-12 grid (see resid_grid)
+                            EpiParams e2 = ep; e2.bias = nullptr;
+                            epi_store1<bf16_t, EPI>(e2, m, n, resid_grid(v + (ep.bias ? ep.bias[n] : 0.f)));
+                        } else epi_store1<bf16_t, EPI>(ep, m, n, v);
+                    }
                 }
             }
         }
@@ -796,11 +801,11 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
         const int m = g * 4 + r;
         if (m < Mb && n < N) {
             if (ATOMIC) {
-                atomicAdd(ep.outf + (size_t)(m_base + m) * ep.ldo + n, v + (blockIdx.y == 0 ? bias_v : 0.f));
+                atomicAdd(ep.outf + (size_t)(m_base + m) * ep.ldo + n, resid_grid(v + (blockIdx.y == 0 ? bias_v : 0.f)));
             } else {
                 EpiParams e2 = ep;
                 e2.bias = nullptr;                       // bias was prefetched at kernel entry
-                epi_store1<bf16_t, EPI>(e2, m_base + m, n, v + bias_v);
+                epi_store1<bf16_t, EPI>(e2, m_base + m, n, EPI == EPI_RESID_F32 ? resid_grid(v + bias_v) : v + bias_v);
             }
         }
     }
@@ -956,11 +961,11 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
         const int m = t * 16 + g * 4 + r;
         if (m < Mb && n < N) {
             if (ATOMIC) {
-                atomicAdd(ep.outf + (size_t)m * ep.ldo + n, v + (blockIdx.y == 0 ? bias_v : 0.f));
+                atomicAdd(ep.outf + (size_t)m * ep.ldo + n, resid_grid(v + (blockIdx.y == 0 ? bias_v : 0.f)));
             } else {
                 EpiParams e2 = ep;
                 e2.bias = nullptr;
-                epi_store1<bf16_t, EPI>(e2, m, n, v + bias_v);
+                epi_store1<bf16_t, EPI>(e2, m, n, EPI == EPI_RESID_F32 ? resid_grid(v + bias_v) : v + bias_v);
             }
         }
     }

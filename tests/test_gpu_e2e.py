@@ -528,3 +528,39 @@ def test_pipeline_from_checkpoint_directory_without_transformers_objects(tiny, t
         assert ok, why
     finally:
         pipe.engine.close()
+
+
+def test_bf16_engine_is_bit_reproducible_run_to_run():
+    """The bf16 engine accumulates K-split GEMV partials into the residual stream with f32 atomics; the stream lives on
+    a 2^-12 grid (common.h: resid_grid) so those additions are exact and their order cannot matter.  Large-v3 shapes
+    (K-split 2 and 4 active), 8 rows, 48 free-running greedy steps, three runs (+ one on a second context): identical
+    token ids and bit-identical logits of every step."""
+    g, v = syn.large_v3_geometry()
+    g.enc_layers = g.dec_layers = 2
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19)]
+    W = syn.random_weights(g, seed=11)
+    B, T = 8, 3 + 48
+    clips = [syn.synth_audio(400 + i, 480000 - 30000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(B)]
+    prompt = np.tile(np.array([[v.sot, v.lang_id("en"), v.transcribe]], np.int32), (B, 1))
+    runs = []
+    engs = [Engine(spec, dtype="bf16", max_batch=B) for _ in range(2)]
+    try:
+        for e in engs:
+            e.load_state_dict(W)
+        for rep, e in enumerate([engs[0], engs[0], engs[0], engs[1]]):
+            e.mel(clips)
+            e.encode(list(range(B)), [0] * B, [3000] * B)
+            cap = e.capture_logits(B, T) if rep != 1 else None          # rep 1 goes through the captured hipGraph
+            seqs, lens, _ = e.decode(prompt, max_length=T, min_new_tokens=48)
+            if cap is not None:
+                e.stop_capture()
+            runs.append((seqs[:, :T].copy(), None if cap is None else cap[:T - 3].copy(), e.token_timestamps(B, T - 1, 3, [3000] * B)))
+        for seqs, cap, ts in runs[1:]:
+            assert np.array_equal(seqs, runs[0][0])
+            assert np.array_equal(ts, runs[0][2])
+            if cap is not None:
+                assert np.array_equal(cap, runs[0][1])
+    finally:
+        for e in engs:
+            e.close()
