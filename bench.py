@@ -206,7 +206,7 @@ def main():
 
     # roofline of the decode-step kernels, HIP events on the engine's own stream
     roof = {}
-    for which, kname in ((0, "gemv_bf16_kernel<EPI_GELU_F32> (decoder fc1 + fused LayerNorm)"),
+    for which, kname in ((0, "gemv2_bf16_kernel<EPI_GELU_F32> (decoder fc1 + fused LayerNorm)"),
                          (1, ("attn_cross_split_fp8_kernel (cross-attention over the e4m3 cache, 1500 frames, 6-way key split)" if a.cross_kv == "fp8" else
                               "attn_cross_split_kernel<bf16> (cross-attention, 1500 frames, 6-way key split)"))):
         ms, by = eng.time_kernel(which, B, a.kernel_iters)
