@@ -637,7 +637,7 @@ extern "C" int cw_debug_phases(unsigned long long* out) {
 #define PH(i) do { } while (0)
 #endif
 
-template <int EPI, int RPW, bool ATOMIC, bool COMBINE, int NSLOT, int PER_LANE>
+template <int EPI, int RPW, bool ATOMIC, bool COMBINE, int NSLOT, int PER_LANE, int NT = 1 /* 16-column tiles per block */>
 __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict__ x, int Mb, int K, int Kb,
                                                          const bf16_t* __restrict__ W, int N,
                                                          const float* __restrict__ ln_g,
@@ -647,21 +647,24 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     x += (size_t)m_base * K;                                  // this launch handles batch rows m_base .. m_base+Mb-1
     const int xs_stride = Kb + 8;
     bf16_t* xs = (bf16_t*)smem2;                              // [16][Kb+8]
-    float* red = (float*)(smem2 + (size_t)16 * xs_stride * 2); // [4 waves][4][64]
+    float* red = (float*)(smem2 + (size_t)16 * xs_stride * 2); // [4 waves][NT][4][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16 * NT;
     const int kbase = blockIdx.y * Kb;
     const int steps = Kb >> 7;
-    const int n = n0 + l15;
-    const int nc = n < N ? n : N - 1;                         // clamped column (results of n >= N are dropped)
+    int nn[NT], ncl[NT];                                      // this lane's column in each tile, clamped (n >= N is dropped)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { nn[t] = n0 + t * 16 + l15; ncl[t] = nn[t] < N ? nn[t] : N - 1; }
     const int nvec = Kb >> 2;                                 // float4 per row slice
     const bool has_ln = ln_g != nullptr;
 
     PH(0);                                                    // kernel entry
-    const float bias_v = ep.bias ? ep.bias[nc] : 0.f;
+    float bias_v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias_v[t] = ep.bias ? ep.bias[ncl[t]] : 0.f;
 
     // activation rows -> registers
     float4 xv[RPW][PER_LANE];
@@ -716,16 +719,17 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
         }
     }
     // weight stream: steps wave, wave+4, wave+8 (clamped: a tail wave re-reads a step another wave owns)
-    u32x4_t wq[NSLOT][4];
-    {
-        const bf16_t* wrow = W + (size_t)nc * K + kbase + g * 8;   // MFMA j covers k = j*32 + g*8 .. +7
+    u32x4_t wq[NT][NSLOT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bf16_t* wrow = W + (size_t)ncl[t] * K + kbase + g * 8;   // MFMA j covers k = j*32 + g*8 .. +7
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             int step = wave + 4 * s;
             step = step < steps ? step : steps - 1;
             const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * 4];      // +32 bf16
+            for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * 4];   // +32 bf16
         }
     }
 
@@ -775,7 +779,9 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     __syncthreads();
     PH(3);
 
-    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int step = wave + 4 * s;
@@ -784,28 +790,32 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
-                acc = mfma16(a, __builtin_bit_cast(bf16x8_t, wq[s][j]), acc);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma16(a, __builtin_bit_cast(bf16x8_t, wq[t][s][j]), acc[t]);
             }
         }
     }
     // D[row = batch g*4 + r][col = l15]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
     PH(4);                                                    // weights arrived, MFMAs done
     __syncthreads();
     PH(5);
-    {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
         const int r = tid >> 6;
-        float v = red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane] + red[(2 * 4 + r) * 64 + lane] +
-                  red[(3 * 4 + r) * 64 + lane];
-        const int m = g * 4 + r;
+        float v = red[((0 * NT + t) * 4 + r) * 64 + lane] + red[((1 * NT + t) * 4 + r) * 64 + lane] +
+                  red[((2 * NT + t) * 4 + r) * 64 + lane] + red[((3 * NT + t) * 4 + r) * 64 + lane];
+        const int m = g * 4 + r, n = nn[t];
         if (m < Mb && n < N) {
             if (ATOMIC) {
-                atomicAdd(ep.outf + (size_t)(m_base + m) * ep.ldo + n, resid_grid(v + (blockIdx.y == 0 ? bias_v : 0.f)));
+                atomicAdd(ep.outf + (size_t)(m_base + m) * ep.ldo + n, resid_grid(v + (blockIdx.y == 0 ? bias_v[t] : 0.f)));
             } else {
                 EpiParams e2 = ep;
                 e2.bias = nullptr;                       // bias was prefetched at kernel entry
-                epi_store1<bf16_t, EPI>(e2, m_base + m, n, EPI == EPI_RESID_F32 ? resid_grid(v + bias_v) : v + bias_v);
+                epi_store1<bf16_t, EPI>(e2, m_base + m, n, EPI == EPI_RESID_F32 ? resid_grid(v + bias_v[t]) : v + bias_v[t]);
             }
         }
     }
@@ -1077,6 +1087,14 @@ static void launch_gemv2_shape(dim3 grid, size_t lds, int ksplit, const float* x
         hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x,
                            Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
     } else {
+        // wide LayerNorm GEMVs (fc1: 320 16-column tiles on 256 CUs put two blocks on 64 CUs, whose 2 x 120 KB of loads are
+        // the kernel's critical path): two column tiles per block share the activation rows and the LayerNorm work,
+        // every CU gets at most one block
+        if (ln_g && ksplit == 1 && N % 32 == 0 && grid.x > 256 && grid.x / 2 >= 128) {
+            dim3 g2(grid.x / 2, 1);
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false, NSLOT, PER_LANE, 2>), g2, dim3(256), lds + 4 * 4 * 64 * 4, st,
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
+        } else
         hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x, Mb, K,
                            Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
     }
