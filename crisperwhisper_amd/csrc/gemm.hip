@@ -1084,6 +1084,11 @@ static void launch_gemv2_shape(dim3 grid, size_t lds, int ksplit, const float* x
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, false, true, NSLOT, PER_LANE>), grid, dim3(256), lds, st,
                                x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
     } else if (EPI == EPI_RESID_F32 && ksplit > 1) {
+        if (N % 32 == 0 && (int)(grid.x * grid.y) > 256 && (int)(grid.x * grid.y) / 2 >= 128) {   // fc2: (80, 4) -> (40, 4)
+            dim3 g2(grid.x / 2, grid.y);
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE, 2>), g2, dim3(256),
+                               lds + 4 * 4 * 64 * 4, st, x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
+        } else
         hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x,
                            Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
     } else {
