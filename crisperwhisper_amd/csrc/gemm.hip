@@ -6,12 +6,17 @@
 //                      activation (implicit GEMM for conv1 / conv2, TF/models/whisper/modeling_whisper.py:618-619).
 //                      Operands are swapped in the MFMA (D = W_frag x A_frag) so every lane owns 4 *consecutive
 //                      output columns* of one row -> vectorised epilogues (epi_store4).
-//   gemm_bf16_kernel   register-staged variant of the same tiling (fallback, CW_NO_GLDS=1).
+//   gemm_bf16_256_kernel  the same with 256x256x64 tiles and 8 waves (128x64 per wave) for the large encoder shapes
+//                      (>= 200 tiles): below the per-CU LDS-read and L1->LDS limits the 128 tile sits on.
+//   gemm_bf16_kernel   register-staged variant of the 128 tiling (fallback, CW_NO_GLDS=1).
 //   gemm_f32_kernel    same contract in plain f32 VALU (parity mode + on-device reference).
 //   gemv2_bf16_kernel  decode-time skinny GEMM (batch rows <= 16 per launch, row groups beyond): weights streamed once
 //                      from HBM straight into MFMA B fragments, activations pulled to registers with a wave-local
 //                      LayerNorm (TF modeling_whisper.py:470,485,498) and parked in LDS as bf16; in-place residual
-//                      epilogue with K split + f32 atomics; optional combination of split-attention partials.
+//                      epilogue with K split + f32 atomics (exact on the 2^-12 residual grid); optional combination of
+//                      split-attention partials; one or two 16-column tiles per block.
+//   gemv_prep_kernel / gemv_mt_kernel  17..64 batch rows: activations laid out once in MFMA fragment-major order,
+//                      one weight pass feeding up to 4 MFMA row tiles.
 //   gemv_bf16_kernel   first-generation decode GEMV (any batch <= 64, K chunks through LDS); kept for shapes
 //                      gemv2 does not take.
 //   gemv_f32_kernel    f32 parity flavour of the same.
