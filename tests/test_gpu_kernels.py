@@ -72,7 +72,7 @@ def test_gemm_256_tile_kernel(engines, M, N, K):
 
 @pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("Mb,N,K", [(1, 128, 128), (3, 200, 256), (8, 1769, 128), (16, 64, 1280), (20, 128, 512), (40, 96, 1280), (64, 80, 256),
-                                     (8, 5120, 1280), (5, 4160, 256)])   # the last two: two column tiles per block (wide LayerNorm GEMV)
+                                     (8, 5120, 1280), (5, 4160, 256), (12, 5120, 1280)])   # the last three: two column tiles per block (wide LayerNorm GEMV)
 def test_gemv_with_layernorm(engines, dt, tol, Mb, N, K):
     rng = np.random.default_rng(Mb * 7 + N + K)
     x = (rng.standard_normal((Mb, K)) * 2 + 0.5).astype(np.float32)
