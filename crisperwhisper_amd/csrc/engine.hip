@@ -1108,12 +1108,15 @@ int64_t cw_resampled_length(int64_t n, int32_t sr_in, int32_t sr_out) {
 
 // torchaudio's _get_sinc_resample_kernel with dtype=None (f64 arithmetic, rounded to f32 at the end): K[p][j],
 // p in 0..new-1, j in 0..2*width+orig-1
-static void resample_taps(int sr_in, int sr_out, std::vector<float>& K, int& orig, int& nw, int& width) {
+// false: the rate pair needs an unreasonably large polyphase table (coprime rates in the MHz range, corrupted headers)
+static bool resample_taps(int sr_in, int sr_out, std::vector<float>& K, int& orig, int& nw, int& width) {
     const int g = igcd(sr_in, sr_out);
     orig = sr_in / g; nw = sr_out / g;
     const double lpw = 6.0, rolloff = 0.99;
     const double base_freq = (double)(orig < nw ? orig : nw) * rolloff;
-    width = (int)ceil(lpw * orig / base_freq);
+    const double w = ceil(lpw * orig / base_freq);
+    if (w > 1e6 || ((double)nw * (2.0 * w + orig)) > (double)(1 << 26)) return false;   // 64 M taps = 256 MB
+    width = (int)w;
     const int n_taps = 2 * width + orig;
     K.assign((size_t)nw * n_taps, 0.f);
     const double scale = base_freq / orig;
@@ -1128,14 +1131,15 @@ static void resample_taps(int sr_in, int sr_out, std::vector<float>& K, int& ori
             const double sinc = t == 0.0 ? 1.0 : sin(t) / t;
             K[(size_t)p * n_taps + j] = (float)(sinc * window * scale);
         }
+    return true;
 }
 
 int32_t cw_resample_taps(int32_t sr_in, int32_t sr_out, float* taps, int32_t cap, int32_t* orig, int32_t* nw,
                          int32_t* width) {
     if (sr_in <= 0 || sr_out <= 0) return CW_ERR_INVALID;
     std::vector<float> K;
-    int o, w, wd;
-    resample_taps(sr_in, sr_out, K, o, w, wd);
+    int o = 0, w = 0, wd = 0;
+    if (!resample_taps(sr_in, sr_out, K, o, w, wd)) return CW_ERR_INVALID;
     if (orig) *orig = o;
     if (nw) *nw = w;
     if (width) *width = wd;
@@ -1169,8 +1173,11 @@ int32_t cw_ingest(cw_ctx* c, const void* raw, int32_t fmt, int32_t channels, int
     const float* d_res = d_mono;
     if (rc == CW_OK && sr_in != sr_out) {                       // F.resample returns its input when the rates agree
         std::vector<float> K, Kt;
-        int orig, nw, width;
-        resample_taps(sr_in, sr_out, K, orig, nw, width);
+        int orig = 0, nw = 0, width = 0;
+        if (!resample_taps(sr_in, sr_out, K, orig, nw, width)) {
+            cleanup();
+            return fail(c, CW_ERR_INVALID, "unsupported sampling-rate pair %d -> %d Hz (polyphase table too large)", sr_in, sr_out);
+        }
         const int n_taps = 2 * width + orig;
         Kt.resize(K.size());
         for (int p = 0; p < nw; ++p) for (int j = 0; j < n_taps; ++j) Kt[(size_t)j * nw + p] = K[(size_t)p * n_taps + j];

@@ -164,3 +164,42 @@ def test_gpu_app_normalisation_and_wav_file_path(eng, tmp_path):
     assert np.abs(got_n - want_n).max() < 2e-5
     with pytest.raises(Exception):
         eng.ingest(b"", audio.PCM_S16, 1, 0, 16000, 16000)
+
+
+def test_riff_parser_never_crashes_on_corrupted_headers():
+    """Fuzz: truncations and byte flips of valid WAV files either parse to a consistent description or raise ValueError
+    (the reference's "Soundfile is either not in the correct format or is malformed" path) -- never another exception."""
+    rng = np.random.default_rng(99)
+    base = [_wav_bytes((rng.standard_normal((300, 2)) * 3000).astype(np.int16), 44100),
+            _wav_bytes(rng.standard_normal(257).astype(np.float32), 8000),
+            _s24_extensible_wav(rng.integers(-8388608, 8388607, size=64), 48000, 2)]
+    n_ok = n_bad = 0
+    for trial in range(600):
+        b = bytearray(base[trial % 3])
+        if trial % 2 == 0:
+            b = b[: int(rng.integers(0, len(b)))]
+        for _ in range(int(rng.integers(1, 4))):
+            if len(b):
+                b[int(rng.integers(0, min(len(b), 64)))] = int(rng.integers(0, 256))
+        try:
+            fmt, ch, sr, frames, payload = audio.parse_wav(bytes(b))
+        except ValueError:
+            n_bad += 1
+            continue
+        n_ok += 1
+        bytes_per = {audio.PCM_U8: 1, audio.PCM_S16: 2, audio.PCM_S24: 3, audio.PCM_S32: 4, audio.PCM_F32: 4, audio.PCM_F64: 8}[fmt]
+        assert ch >= 1 and sr >= 1 and frames >= 1 and len(payload) == frames * ch * bytes_per
+    assert n_ok > 0 and n_bad > 0
+
+
+def test_resampler_rejects_absurd_rate_pairs_without_allocating():
+    """A corrupted header can claim any sampling rate: coprime MHz-range rates would need a multi-GB polyphase table;
+    the library answers with an error code (checked through the context-free cw_resample_taps entry point)."""
+    import ctypes as C
+    from crisperwhisper_amd import _native
+    lib = _native.load()
+    o, n, w = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.cw_resample_taps(2147483647, 16000, None, 0, C.byref(o), C.byref(n), C.byref(w)) != 0
+    assert lib.cw_resample_taps(1000003, 999983, None, 0, C.byref(o), C.byref(n), C.byref(w)) != 0
+    assert lib.cw_resample_taps(44100, 16000, None, 0, C.byref(o), C.byref(n), C.byref(w)) == 0 and (o.value, n.value, w.value) == (441, 160, 17)
+    assert lib.cw_resampled_length(441000, 44100, 16000) == 160000
