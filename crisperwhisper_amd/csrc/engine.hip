@@ -1115,7 +1115,7 @@ static bool resample_taps(int sr_in, int sr_out, std::vector<float>& K, int& ori
     const double lpw = 6.0, rolloff = 0.99;
     const double base_freq = (double)(orig < nw ? orig : nw) * rolloff;
     const double w = ceil(lpw * orig / base_freq);
-    if (w > 1e6 || ((double)nw * (2.0 * w + orig)) > (double)(1 << 26)) return false;   // 64 M taps = 256 MB
+    if (w > 1e6 || ((double)nw * (2.0 * w + orig)) > 536870912.0) return false;   // 512 M taps = 2 GB
     width = (int)w;
     const int n_taps = 2 * width + orig;
     K.assign((size_t)nw * n_taps, 0.f);
