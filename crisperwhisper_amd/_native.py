@@ -49,6 +49,7 @@ _SIGS = {
     "cw_last_error": (C.c_char_p, [_P]),
     "cw_sync": (_I, [_P]),
     "cw_load_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "cw_check_weights": (_I, [_P]),
     "cw_set_generation": (_I, [_P, C.POINTER(GenCfg)]),
     "cw_mel": (_I, [_P, _P, _I, _P, _P, _P]),
     "cw_upload_pcm": (_I, [_P, _P, _I, _P]),
@@ -81,6 +82,7 @@ _SIGS = {
     "cw_test_gemm": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "cw_test_gemv": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "cw_test_attention": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "cw_test_sample": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "cw_stage_times": (_I, [_P, _P, _P, _I]),
     "cw_time_kernel": (_I, [_P, _I, _I, _I, _P, _P]),
 }

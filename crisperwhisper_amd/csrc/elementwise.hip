@@ -241,6 +241,9 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
         int choice;
         if (force_ts || !(bt.v > -INFINITY)) choice = bs.i;
         else choice = arg_better(bt, bs).i;
+        // no finite candidate at all (every token masked, or NaN logits): torch.argmax of an all -inf row is index 0;
+        // never hand an out-of-range id to the next step's embedding gather
+        if (!(M > -INFINITY) || choice < 0 || choice >= p.V) choice = 0;
         if (p.argmax_trace) p.argmax_trace[(size_t)b * p.ids_stride + t] = choice;
         int tok = (forced >= 0) ? forced : choice;
         if (was_finished) tok = p.pad;                                  // utils.py:2928-2929

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,8 @@ struct cw_ctx {
     char err[512] = "";
     bool err_set = false;      // a specific message is pending (set by fail(), cleared by cw_last_error)
     std::vector<int> align_layers, align_heads;
+    std::set<std::string> loaded;   // HF tensor names received through cw_load_tensor
+    bool weights_ok = false;        // every tensor of the geometry has been loaded (checked once, see cw_check_weights)
 
     // weights
     void *conv1_w = nullptr, *conv2_w = nullptr, *embed = nullptr;
@@ -403,7 +406,48 @@ void cw_destroy(cw_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // weights
 // ------------------------------------------------------------------------------------------------
+static int load_tensor_impl(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+
 int32_t cw_load_tensor(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!name || !data || !shape) return fail(c, CW_ERR_INVALID, "cw_load_tensor: null argument");
+    const int r = load_tensor_impl(c, name, data, shape, ndim);
+    if (r == CW_OK) { c->loaded.insert(name); c->weights_ok = false; }
+    return r;
+}
+
+// Every tensor of WhisperForConditionalGeneration.state_dict() for this geometry (k_proj has no bias,
+// modeling_whisper.py:279; proj_out is tied).  Device buffers start zero-filled, so a checkpoint with a missing shard
+// would otherwise run and return garbage: the first cw_encode refuses to start until the list is complete.
+int32_t cw_check_weights(cw_ctx* c) {
+    if (c->weights_ok) return CW_OK;
+    std::vector<std::string> want = {
+        "model.encoder.conv1.weight", "model.encoder.conv1.bias", "model.encoder.conv2.weight", "model.encoder.conv2.bias",
+        "model.encoder.embed_positions.weight", "model.encoder.layer_norm.weight", "model.encoder.layer_norm.bias",
+        "model.decoder.embed_tokens.weight", "model.decoder.embed_positions.weight", "model.decoder.layer_norm.weight",
+        "model.decoder.layer_norm.bias"};
+    auto attn = [&](const std::string& p) {
+        for (const char* t : {".q_proj.weight", ".q_proj.bias", ".k_proj.weight", ".v_proj.weight", ".v_proj.bias",
+                              ".out_proj.weight", ".out_proj.bias"}) want.push_back(p + t);
+    };
+    auto pair = [&](const std::string& p) { want.push_back(p + ".weight"); want.push_back(p + ".bias"); };
+    for (int stack = 0; stack < 2; ++stack) {
+        const int nl = stack ? c->d.dec_layers : c->d.enc_layers;
+        for (int l = 0; l < nl; ++l) {
+            const std::string p = std::string(stack ? "model.decoder.layers." : "model.encoder.layers.") + std::to_string(l);
+            attn(p + ".self_attn"); pair(p + ".self_attn_layer_norm");
+            if (stack) { attn(p + ".encoder_attn"); pair(p + ".encoder_attn_layer_norm"); }
+            pair(p + ".fc1"); pair(p + ".fc2"); pair(p + ".final_layer_norm");
+        }
+    }
+    std::string missing; int n_missing = 0;
+    for (const auto& w : want)
+        if (!c->loaded.count(w)) { if (n_missing < 4) missing += (n_missing ? ", " : "") + w; ++n_missing; }
+    if (n_missing) return fail(c, CW_ERR_STATE, "%d of %zu weight tensors were never loaded (e.g. %s): incomplete checkpoint", n_missing, want.size(), missing.c_str());
+    c->weights_ok = true;
+    return CW_OK;
+}
+
+static int load_tensor_impl(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
     const int D = c->d.d_model, F = c->d.ffn_dim, V = c->d.vocab_size, NM = c->d.n_mels;
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
@@ -570,6 +614,7 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
         off[i] = item[i] * CW_N_FRAMES + seek[i];
         val[i] = n_frames[i];
     }
+    CWCHK(c, cw_check_weights(c));
     HIPCHK(c, hipMemcpyAsync(c->d_row_off, off.data(), nb * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(c->d_row_valid, val.data(), nb * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));  // host vectors go out of scope
@@ -1281,6 +1326,39 @@ int32_t cw_test_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, const floa
     if (r == CW_OK) r = download_T(c, dout, 0, out, (size_t)B * S * H * 64);
     hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout);
     return r;
+}
+
+// One call of the fused logits-processor + argmax kernel (sample_kernel) on caller-supplied rows: logits [nb][V],
+// ids [nb][t] = prompt + generated so far (the kernel's grammar state is rebuilt from it), choice_out [nb] = the
+// token the kernel picks for index t.  Differential test against TF/generation/logits_process.py:203-260, 1816-2047.
+int32_t cw_test_sample(cw_ctx* c, int32_t nb, const float* logits, const int32_t* ids, int32_t t, int32_t n_prompt,
+                       int32_t min_new_tokens, int32_t max_length, int32_t* choice_out) {
+    const int V = c->d.vocab_size, TGT = c->d.max_target_positions;
+    if (!c->gen_set) return fail(c, CW_ERR_STATE, "cw_set_generation not called");
+    if (nb < 1 || nb > c->Bm || t < n_prompt || t < 1 || t >= TGT || n_prompt < 1) return fail(c, CW_ERR_INVALID, "test_sample: bad args");
+    const int tb = c->gen.no_timestamps_token_id + 1;
+    std::vector<int> hid((size_t)nb * TGT, c->gen.pad_token_id), last(nb, -1), posv(64, t - 1);
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < t; ++k) {
+            const int tok = ids[(size_t)b * t + k];
+            if (tok < 0 || tok >= V) return fail(c, CW_ERR_INVALID, "test_sample: token %d out of range", tok);
+            hid[(size_t)b * TGT + k] = tok;
+            if (k >= n_prompt && tok >= tb) last[b] = tok;
+        }
+    HIPCHK(c, hipMemcpy(c->d_ids, hid.data(), hid.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_last_ts, last.data(), nb * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_pos, posv.data(), 64 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(c->d_finished, 0, nb * 4));
+    HIPCHK(c, hipMemset(c->d_argmax, 0xff, (size_t)nb * TGT * 4));
+    const int cfg[4] = {n_prompt, min_new_tokens, max_length, 0};
+    HIPCHK(c, hipMemcpy(c->d_cfg, cfg, sizeof(cfg), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy2D(c->dlogits, (size_t)c->Vpad * 4, logits, (size_t)V * 4, (size_t)V * 4, nb, hipMemcpyHostToDevice));
+    CWCHK(c, launch_sample(c, nb, false));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    std::vector<int> am((size_t)nb * TGT);
+    HIPCHK(c, hipMemcpy(am.data(), c->d_argmax, am.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; ++b) choice_out[b] = am[(size_t)b * TGT + t];
+    return CW_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -46,6 +46,10 @@ class ModelSpec:
     lang_to_id: Dict[str, int] = dataclasses.field(default_factory=dict)
     task_to_id: Dict[str, int] = dataclasses.field(default_factory=dict)
     max_length: int = 448
+    # generation_config defaults that seed the decoder prompt (generation_whisper.py:1488-1525)
+    forced_decoder_ids: Optional[Sequence[Sequence[Optional[int]]]] = None
+    language: Optional[str] = None
+    task: Optional[str] = None
 
     @property
     def timestamp_begin(self) -> int:
@@ -119,8 +123,13 @@ class Engine:
         self._chk(self.lib.cw_load_tensor(self.ctx, name.encode(), _ptr(a), shape, a.ndim))
 
     def load_state_dict(self, weights: Dict[str, np.ndarray]):
+        """Uploads every tensor, then fails loudly (naming the absent tensors) if the checkpoint was incomplete."""
         for k, v in weights.items():
             self.load_tensor(k, v)
+        self.check_weights()
+
+    def check_weights(self):
+        self._chk(self.lib.cw_check_weights(self.ctx))
 
     # ------------------------------------------------------------------ stages
     def mel(self, clips: List[np.ndarray], return_features: bool = False):
@@ -280,6 +289,17 @@ class Engine:
         B, H, S, _ = q.shape
         out = np.zeros((B, S, H * 64), np.float32)
         self._chk(self.lib.cw_test_attention(self.ctx, B, H, S, _ptr(q), _ptr(k), _ptr(v), _ptr(out)))
+        return out
+
+    def test_sample(self, logits: np.ndarray, ids: np.ndarray, n_prompt: int, min_new_tokens: int = 0,
+                    max_length: Optional[int] = None) -> np.ndarray:
+        """One launch of the fused logits processors + greedy choice on caller rows (cw_test_sample)."""
+        lg = np.ascontiguousarray(logits, np.float32)
+        ids = _i32(ids)
+        nb, t = ids.shape
+        out = np.zeros(nb, np.int32)
+        self._chk(self.lib.cw_test_sample(self.ctx, nb, _ptr(lg), _ptr(ids), t, int(n_prompt), int(min_new_tokens),
+                                          int(max_length or self.spec.max_target_positions), _ptr(out)))
         return out
 
     # ------------------------------------------------------------------ measurement

@@ -44,24 +44,87 @@ def detect_language(engine: Engine, n_items: int) -> np.ndarray:
     return lang_ids[np.argmax(logits[:, lang_ids], axis=-1)]
 
 
+def language_to_id(spec, language: str) -> int:
+    """``language_to_id`` of ``_retrieve_init_tokens`` (:1466-1486): '<|en|>', 'en' and 'english' (any case) all work."""
+    from .languages import TO_LANGUAGE_CODE
+    language = language.lower()
+    if language in spec.lang_to_id:
+        tag = language
+    elif language in TO_LANGUAGE_CODE:
+        tag = f"<|{TO_LANGUAGE_CODE[language]}|>"
+    elif language in TO_LANGUAGE_CODE.values():
+        tag = f"<|{language}|>"
+    else:
+        is_code = len(language) == 2
+        raise ValueError(f"Unsupported language: {language}. Language should be one of:"
+                         f" {list(TO_LANGUAGE_CODE.values()) if is_code else list(TO_LANGUAGE_CODE.keys())}.")
+    if tag not in spec.lang_to_id:
+        raise ValueError(f"{tag} is not supported by this specific model as it is not in the "
+                         "`generation_config.lang_to_id`. (You should just add it to the generation config)")
+    return spec.lang_to_id[tag]
+
+
+def resolve_prompt(spec, language: Optional[str], task: Optional[str]):
+    """``_retrieve_init_tokens`` (:1455-1608) for ``return_timestamps=True``: the decoder prompt as a list whose slot 1
+    is ``None`` when the language has to be detected per item.  ``language`` / ``task`` are the call's generate_kwargs;
+    the generation config's own ``language`` / ``task`` are their defaults, and when both are unset the (deprecated but
+    still shipped) ``forced_decoder_ids`` of the checkpoint seed the prompt, e.g. [[1, None], [2, <|transcribe|>]]."""
+    from .languages import TASK_IDS
+    task = task if task is not None else getattr(spec, "task", None)
+    language = language if language is not None else getattr(spec, "language", None)
+    if isinstance(language, (list, tuple)):
+        raise ValueError("per-item language lists are not supported on the native path: pass one language or None")
+    init: List[Optional[int]] = [spec.decoder_start_token_id]
+    if task is None and language is None:
+        forced = getattr(spec, "forced_decoder_ids", None)
+        if forced is not None:
+            forced = [list(f) for f in forced]
+            if forced and forced[0][0] == 1:
+                i = 1
+                while forced and forced[0][0] == i:
+                    init.append(forced[0][1])
+                    forced = forced[1:]
+                    i += 1
+                if forced:
+                    raise ValueError(f"You are using token ids in `forced_decoder_ids` that do not seem to correctly follow "
+                                     f"the prompt pattern of Whisper. Make sure that {forced} has an entry for all "
+                                     f"indices >= 1 and < {forced[0][0]}.")
+    lang_undefined = len(init) <= 1 or init[1] is None
+    lang_id: Optional[int] = None
+    detect = False
+    if language is not None:
+        lang_id = language_to_id(spec, language)
+    elif spec.lang_to_id and lang_undefined:
+        detect = True
+    if lang_id is not None or detect:
+        if len(init) > 1:
+            init[1] = None if detect else lang_id
+        else:
+            init.append(None if detect else lang_id)
+    if task is not None:
+        if task not in TASK_IDS or task not in spec.task_to_id:
+            raise ValueError(f"The `{task}` task is not supported. The task should be one of `{TASK_IDS}`")
+        init.append(spec.task_to_id[task])
+    elif language is not None and spec.task_to_id:
+        if not any(t in init for t in spec.task_to_id.values()):
+            init.append(spec.task_to_id["transcribe"])
+    if init[-1] == spec.no_timestamps_token_id:          # return_timestamps=True drops a trailing <|notimestamps|>
+        init = init[:-1]
+    head, rest = init[:2], [t for t in init[2:] if t is not None]
+    if len(head) == 2 and head[1] is None and not detect:
+        head = head[:1]                                    # a None language nobody fills in is dropped like any None
+    return head + rest, detect
+
+
 def init_tokens(spec, language: Optional[str], task: Optional[str], lang_id: Optional[int] = None) -> List[int]:
-    """<|startoftranscript|><|lang|><|task|> (no <|notimestamps|>: return_timestamps=True)."""
-    if language is None:
+    """<|startoftranscript|><|lang|><|task|> (no <|notimestamps|>: return_timestamps=True); ``lang_id`` fills the
+    language slot when it has to be detected."""
+    toks, detect = resolve_prompt(spec, language, task)
+    if detect:
         if lang_id is None:
             raise ValueError("language is None and no detected language id was supplied")
-        # with a detected language HF appends the task token only when `task` was given (:1575-1590)
-        if task is None:
-            return [spec.decoder_start_token_id, int(lang_id)]
-        if task not in spec.task_to_id:
-            raise ValueError(f"The `{task}` task is not supported. The task should be one of `{sorted(spec.task_to_id)}`")
-        return [spec.decoder_start_token_id, int(lang_id), spec.task_to_id[task]]
-    lang = language if language in spec.lang_to_id else f"<|{language}|>"
-    if lang not in spec.lang_to_id:
-        raise ValueError(f"Unsupported language: {language}. Language should be one of: {sorted(spec.lang_to_id)}.")
-    task = task or "transcribe"
-    if task not in spec.task_to_id:
-        raise ValueError(f"The `{task}` task is not supported. The task should be one of `{sorted(spec.task_to_id)}`")
-    return [spec.decoder_start_token_id, spec.lang_to_id[lang], spec.task_to_id[task]]
+        toks = [toks[0], int(lang_id)] + toks[2:]
+    return [int(t) for t in toks]
 
 
 def split_segments(seq: np.ndarray, token_ts: np.ndarray, time_offset: float, timestamp_begin: int,
@@ -115,14 +178,14 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
     if native is None:
         native = hasattr(engine, "transcribe")
     if native:
-        if language is None:
-            if not spec.lang_to_id:
-                raise ValueError("Cannot detect language for an English-only checkpoint: the generation config has no `lang_to_id`.")
-            if task is not None and task not in spec.task_to_id:
-                raise ValueError(f"The `{task}` task is not supported. The task should be one of `{sorted(spec.task_to_id)}`")
-            lang_tok, task_tok = -1, (spec.task_to_id[task] if task is not None else -1)
-        else:
-            _, lang_tok, task_tok = init_tokens(spec, language, task)
+        toks, detect = resolve_prompt(spec, language, task)
+        if detect and not spec.lang_to_id:
+            raise ValueError("Cannot detect language for an English-only checkpoint: the generation config has no `lang_to_id`.")
+        if len(toks) < 2 or len(toks) > 3:
+            raise ValueError(f"unsupported decoder prompt {toks}: the native path decodes from "
+                             "<|startoftranscript|><|lang|>[<|task|>]")
+        lang_tok = -1 if detect else int(toks[1])
+        task_tok = int(toks[2]) if len(toks) > 2 else -1
         toks, tts, n_calls = engine.transcribe(
             n_items, num_frames, sot=spec.decoder_start_token_id, language_token=lang_tok, task_token=task_tok,
             max_new_tokens=-1 if max_new_tokens is None else int(max_new_tokens), min_new_tokens=min_new_tokens or 0,
@@ -135,11 +198,12 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
             sequences[i, :len(s)] = s
         return {"sequences": sequences, "token_timestamps": tts, "segments": None}
     pre_encoded = False
-    if language is None:
+    _, detect = resolve_prompt(spec, language, task)
+    if detect:
         # language auto-detection (the reference does not pass `language`, REF/transcribe.py:33)
         engine.encode(list(range(n_items)), np.zeros(n_items, np.int64), np.full(n_items, N_FRAMES, np.int64))
         langs = detect_language(engine, n_items)
-        init = np.asarray([init_tokens(spec, None, task, lang_id=l) for l in langs], dtype=np.int32)
+        init = np.asarray([init_tokens(spec, language, task, lang_id=l) for l in langs], dtype=np.int32)
         pre_encoded = True
     else:
         init = np.tile(np.asarray(init_tokens(spec, language, task), dtype=np.int32), (n_items, 1))

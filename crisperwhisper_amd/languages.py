@@ -21,3 +21,9 @@ LANGUAGES = {
     "as": "assamese", "tt": "tatar", "haw": "hawaiian", "ln": "lingala", "ha": "hausa", "ba": "bashkir",
     "jw": "javanese", "su": "sundanese", "yue": "cantonese",
 }
+
+# TF/models/whisper/tokenization_whisper.py:144-157
+TO_LANGUAGE_CODE = {**{name: code for code, name in LANGUAGES.items()}, "burmese": "my", "valencian": "ca", "flemish": "nl",
+                    "haitian": "ht", "letzeburgesch": "lb", "pushto": "ps", "panjabi": "pa", "moldavian": "ro", "moldovan": "ro",
+                    "sinhalese": "si", "castilian": "es", "mandarin": "zh"}
+TASK_IDS = ["translate", "transcribe"]

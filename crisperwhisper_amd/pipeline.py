@@ -52,7 +52,10 @@ class ModelBundle:
             max_initial_timestamp_index=getattr(gc, "max_initial_timestamp_index", None),
             suppress_tokens=list(gc.suppress_tokens or []), begin_suppress_tokens=list(gc.begin_suppress_tokens or []),
             lang_to_id=dict(getattr(gc, "lang_to_id", {}) or {}), task_to_id=dict(getattr(gc, "task_to_id", {}) or {}),
-            max_length=gc.max_length or cfg.max_target_positions)
+            max_length=gc.max_length or cfg.max_target_positions,
+            forced_decoder_ids=(getattr(gc, "forced_decoder_ids", None) if getattr(gc, "forced_decoder_ids", None) is not None
+                                else getattr(cfg, "forced_decoder_ids", None)),
+            language=getattr(gc, "language", None), task=getattr(gc, "task", None))
         weights = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items() if k != "proj_out.weight"}
         return cls(spec, weights)
 
@@ -89,7 +92,9 @@ class ModelBundle:
             max_initial_timestamp_index=gc.get("max_initial_timestamp_index"),
             suppress_tokens=list(gc.get("suppress_tokens") or []), begin_suppress_tokens=list(gc.get("begin_suppress_tokens") or []),
             lang_to_id=dict(gc.get("lang_to_id") or {}), task_to_id=dict(gc.get("task_to_id") or {}),
-            max_length=gc.get("max_length") or cfg.get("max_target_positions", 448))
+            max_length=gc.get("max_length") or cfg.get("max_target_positions", 448),
+            forced_decoder_ids=gc.get("forced_decoder_ids") if gc.get("forced_decoder_ids") is not None else cfg.get("forced_decoder_ids"),
+            language=gc.get("language"), task=gc.get("task"))
         return cls(spec, _SafetensorsWeights(path))
 
 

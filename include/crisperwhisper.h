@@ -63,6 +63,9 @@ int32_t cw_sync(cw_ctx* ctx);
  * The context fuses q/k/v projections, folds the 1/8 query scale (modeling_whisper.py:309) and re-lays
  * the conv kernels for implicit GEMM.  proj_out.weight is tied to embed_tokens (:965) and ignored.     */
 int32_t cw_load_tensor(cw_ctx* ctx, const char* hf_name, const float* data, const int64_t* shape, int32_t ndim);
+/* 0 when every tensor of the geometry has been received, else CW_ERR_STATE with the missing names in cw_last_error
+ * (also enforced by the first cw_encode: device buffers start zero-filled, a partial checkpoint must not run).     */
+int32_t cw_check_weights(cw_ctx* ctx);
 int32_t cw_set_generation(cw_ctx* ctx, const cw_gen_cfg* cfg);
 /* Context options (before cw_encode).  "cross_kv_fp8" = 1: the cross-attention K/V cache is additionally stored in OCP
  * e4m3 with one scale per (chunk, head, K|V) and the decode step streams that copy (half the bytes of the dominant
@@ -191,6 +194,12 @@ int32_t cw_test_gemv(cw_ctx* ctx, int32_t Mb, int32_t N, int32_t K, const float*
                      const float* bias, const float* ln_g, const float* ln_b, int32_t gelu, float* out);
 int32_t cw_test_attention(cw_ctx* ctx, int32_t B, int32_t H, int32_t S, const float* q, const float* k,
                           const float* v, float* out /* [B][S][H*64] */);
+/* One launch of the fused logits processors + greedy choice (MinNewTokensLength, SuppressTokensAtBegin, SuppressTokens,
+ * WhisperTimeStamp: TF/generation/logits_process.py:203-260, 1816-2047; argmax TF/generation/utils.py:2925) on
+ * caller-supplied rows: logits [nb][vocab], ids [nb][t] = prompt + tokens generated so far; choice_out [nb] = token for
+ * sequence index t.  Uses the lists installed by cw_set_generation.                                               */
+int32_t cw_test_sample(cw_ctx* ctx, int32_t nb, const float* logits, const int32_t* ids, int32_t t, int32_t n_prompt,
+                       int32_t min_new_tokens, int32_t max_length, int32_t* choice_out);
 
 /* ---- measurement -------------------------------------------------------------------------------------- */
 #define CW_STAGE_MEL 0

@@ -222,9 +222,78 @@ def test_c_abi_error_behaviour(engines):
             fresh.decode(np.array([[v.sot, v.lang_id("en"), v.transcribe]]), max_length=8)   # nothing encoded yet
         with pytest.raises(EngineError):
             fresh.mel([np.zeros(480001, np.float32)])       # longer than one 30 s window
+        # an incomplete checkpoint must not run on the zero-filled device buffers
+        fresh.mel([np.zeros(16000, np.float32)])
+        with pytest.raises(EngineError, match="never loaded"):
+            fresh.encode([0], [0], [3000])
+        partial = {k: W[k] for k in W if not k.endswith("layers.1.fc2.bias")}
+        with pytest.raises(EngineError, match="fc2.bias"):
+            fresh.load_state_dict(partial)
+        fresh.load_state_dict(W)
+        fresh.encode([0], [0], [3000])
     finally:
         fresh.close()
     bad = syn.model_spec(*syn.tiny_geometry(), 3)
     bad.alignment_heads = [[99, 0]]
     with pytest.raises(EngineError, match="alignment head"):
         Engine(bad, dtype="f32", max_batch=1)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_sample_kernel_vs_oracle_processors(engines, dt):
+    """sample_kernel (all logits processors collapsed into one predicate + rewritten logsumexp rule + argmax) against
+    oracle/logits.py (pinned to transformers' processor objects on the same rows in tests/test_oracle_vs_golden.py):
+    the chosen token must be identical on every crafted and random row, one row per launch and batched."""
+    from oracle import logits as OL
+    from tests import sampler_cases as SC
+    g, v = syn.tiny_geometry()
+    eng = engines[dt]
+    cs = SC.cases(v, v.size)
+    want = []
+    for name, ids, lg, mn in cs:
+        spec = OL.ProcessorSpec(eos=v.eos, no_timestamps=v.notimestamps, suppress=v.suppress_tokens(),
+                                begin_suppress=v.begin_suppress_tokens(), max_initial_timestamp_index=50, min_new_tokens=mn)
+        with np.errstate(invalid="ignore"):
+            o = OL.process(spec, ids[None], lg[None], SC.N_PROMPT, SC.N_PROMPT)
+        want.append(int(np.argmax(o[0])))
+        got = eng.test_sample(lg[None], ids[None], SC.N_PROMPT, min_new_tokens=mn)
+        assert int(got[0]) == want[-1], (name, int(got[0]), want[-1])
+    # batched launch: rows sharing (t, min_new_tokens) go through one call
+    groups = {}
+    for i, (name, ids, lg, mn) in enumerate(cs):
+        groups.setdefault((len(ids), mn), []).append(i)
+    for (t, mn), idx in groups.items():
+        for lo in range(0, len(idx), 4):
+            sel = idx[lo:lo + 4]
+            got = eng.test_sample(np.stack([cs[i][2] for i in sel]), np.stack([cs[i][1] for i in sel]), SC.N_PROMPT, min_new_tokens=mn)
+            assert got.tolist() == [want[i] for i in sel], [cs[i][0] for i in sel]
+
+
+def test_sample_kernel_large_vocab_vs_oracle():
+    """Same differential at the BASELINE vocabulary (51866 columns: padded row stride, 4-deep load loop, 1024-thread
+    block reductions): random rows + exact ties at the far end of the row."""
+    from oracle import logits as OL
+    g, v = syn.large_v3_geometry()
+    g.enc_layers = g.dec_layers = 1
+    spec = syn.model_spec(g, v, n_align=1)
+    spec.alignment_heads = [[0, 0]]
+    eng = Engine(spec, dtype="bf16", max_batch=8)
+    try:
+        rng = np.random.default_rng(5)
+        tb = v.timestamp_begin
+        prompt = [v.sot, v.lang_id("en"), v.transcribe]
+        ospec = OL.ProcessorSpec(eos=v.eos, no_timestamps=v.notimestamps, suppress=v.suppress_tokens(),
+                                 begin_suppress=v.begin_suppress_tokens(), max_initial_timestamp_index=50)
+        for gen in ([], [tb], [tb, 300], [tb, 300, tb + 7], [tb, 300, tb + 7, tb + 7], [tb, 300, tb + 7, tb + 7, 41000]):
+            ids = np.tile(np.asarray(prompt + gen, np.int64), (8, 1))
+            lg = (rng.standard_normal((8, g.vocab)) * 3).astype(np.float32)
+            lg[0, g.vocab - 1] = lg[0, tb + 100] = 40.0                  # tie between two timestamps, last column
+            lg[1, 50000] = lg[1, 49999] = 41.0                           # tie between two text tokens
+            lg[2, tb:] -= 100.0
+            lg[3, :tb] -= 100.0
+            with np.errstate(invalid="ignore"):
+                o = OL.process(ospec, ids, lg, 3, 3)
+            got = eng.test_sample(lg, ids, 3)
+            assert got.tolist() == np.argmax(o, -1).tolist(), gen
+    finally:
+        eng.close()

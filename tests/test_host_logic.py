@@ -126,6 +126,56 @@ def test_init_tokens_errors_mirror_reference():
         generation.init_tokens(spec, "<|en|>", "summarize")
 
 
+def test_language_names_and_case_like_reference():
+    g, v, W, spec = Hh.tiny_setup()
+    for name in ("English", "english", "en", "EN", "<|en|>"):
+        assert generation.init_tokens(spec, name, None) == [v.sot, v.lang_id("en"), v.transcribe]
+    assert generation.init_tokens(spec, "Castilian", "translate") == [v.sot, v.lang_id("es"), v.translate]
+    with pytest.raises(ValueError, match="Unsupported language"):
+        generation.init_tokens(spec, "klingon", None)
+    with pytest.raises(ValueError, match="not supported by this specific model"):
+        generation.init_tokens(spec, "french", None)          # valid Whisper language, absent from this lang_to_id
+
+
+def test_prompt_resolution_matches_transformers_retrieve_init_tokens():
+    """``generation.resolve_prompt`` against ``WhisperGenerationMixin._retrieve_init_tokens`` (generation_whisper.py:1455-1608)
+    over the checkpoint-side settings the reference never overrides (REF/transcribe.py:33 passes no generate_kwargs):
+    ``forced_decoder_ids`` as shipped by the original Whisper checkpoints ([[1, None], [2, <|transcribe|>]]), a fixed
+    language in them, a trailing <|notimestamps|>, generation_config.language / .task, and the call's own kwargs."""
+    pytest.importorskip("transformers")
+    import copy
+    import torch
+    from tests.golden import hf_synth as H
+    g, v, W, spec0 = Hh.tiny_setup()
+    model = H.build_model(g, v, n_align=3)
+    detected = v.lang_id("de")
+    model.detect_language = lambda **kw: torch.tensor([detected])
+    forced_variants = [None, [[1, None], [2, v.transcribe]], [[1, v.lang_id("es")], [2, v.translate]],
+                       [[1, None], [2, v.transcribe], [3, v.notimestamps]], [[1, v.lang_id("zh")]], [[2, v.transcribe]]]
+    n = 0
+    for forced in forced_variants:
+        for gc_lang, gc_task in ((None, None), ("<|es|>", None), (None, "translate"), ("german", "transcribe")):
+            for kw_lang, kw_task in ((None, None), ("en", None), (None, "transcribe"), ("<|zh|>", "translate")):
+                gc = copy.deepcopy(model.generation_config)
+                gc.forced_decoder_ids = forced
+                gc.language = kw_lang if kw_lang is not None else gc_lang       # generate kwargs override the config
+                gc.task = kw_task if kw_task is not None else gc_task
+                gc.return_timestamps = True
+                spec = copy.deepcopy(spec0)
+                spec.forced_decoder_ids, spec.language, spec.task = forced, gc_lang, gc_task
+                try:
+                    want = model._retrieve_init_tokens(torch.zeros(1, g.n_mels, 3000), batch_size=1, generation_config=gc,
+                                                       config=model.config, num_segment_frames=3000, kwargs={})[0].tolist()
+                except ValueError:
+                    with pytest.raises(ValueError):
+                        generation.init_tokens(spec, kw_lang, kw_task, lang_id=detected)
+                    continue
+                got = generation.init_tokens(spec, kw_lang, kw_task, lang_id=detected)
+                assert got == want, (forced, gc_lang, gc_task, kw_lang, kw_task, got, want)
+                n += 1
+    assert n >= 80
+
+
 def test_drop_in_objects_from_transformers():
     """The boundary accepts the reference's own objects (REF/transcribe.py:14-31): a WhisperForConditionalGeneration
     and a WhisperTokenizer are converted to the native ModelSpec / weights / Vocabulary without loss."""

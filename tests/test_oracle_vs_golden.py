@@ -163,3 +163,36 @@ def test_dtw_property_random_shapes_and_ties():
         assert (np.diff(ti) >= 0).all() and (np.diff(tj) >= 0).all() and ((np.diff(ti) + np.diff(tj)) >= 1).all()
 
     check()
+
+
+def test_logits_processors_match_transformers_on_crafted_and_random_rows():
+    """oracle/logits.py against the reference's own processor objects (TF/generation/logits_process.py:164-260,
+    1816-2047) composed in HF's order, + torch.argmax (TF/generation/utils.py:2925): identical -inf masks and identical
+    choices on crafted grammar states (begin, (text, ts), (ts, ts), monotonicity, exact ties text-vs-timestamp,
+    logsumexp == max text, all-masked rows, suppress lists, min_new_tokens) and random rows."""
+    pytest.importorskip("transformers")
+    import torch
+    from types import SimpleNamespace
+    from transformers.generation.logits_process import (MinNewTokensLengthLogitsProcessor, SuppressTokensAtBeginLogitsProcessor,
+                                                        SuppressTokensLogitsProcessor, WhisperTimeStampLogitsProcessor)
+    from oracle import logits as OL
+    from tests import sampler_cases as SC
+    g, v = syn.tiny_geometry()
+    gc = SimpleNamespace(no_timestamps_token_id=v.notimestamps, eos_token_id=v.eos, bos_token_id=v.eos, max_initial_timestamp_index=50)
+    cs = SC.cases(v, v.size)
+    assert len(cs) >= 50
+    for name, ids, lg, mn in cs:
+        procs = []
+        if mn > 0:
+            procs.append(MinNewTokensLengthLogitsProcessor(SC.N_PROMPT, mn, v.eos, device="cpu"))
+        procs += [SuppressTokensAtBeginLogitsProcessor(v.begin_suppress_tokens(), SC.N_PROMPT, device="cpu"),
+                  SuppressTokensLogitsProcessor(v.suppress_tokens(), device="cpu"), WhisperTimeStampLogitsProcessor(gc, SC.N_PROMPT)]
+        s = torch.from_numpy(lg[None].copy())
+        for p in procs:
+            s = p(torch.from_numpy(ids[None]), s)
+        spec = OL.ProcessorSpec(eos=v.eos, no_timestamps=v.notimestamps, suppress=v.suppress_tokens(),
+                                begin_suppress=v.begin_suppress_tokens(), max_initial_timestamp_index=50, min_new_tokens=mn)
+        with np.errstate(invalid="ignore"):
+            o = OL.process(spec, ids[None], lg[None], SC.N_PROMPT, SC.N_PROMPT)
+        assert np.array_equal(np.isneginf(o[0]), np.isneginf(s[0].numpy())), name
+        assert int(np.argmax(o[0])) == int(torch.argmax(s, -1)[0]), name
