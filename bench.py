@@ -25,6 +25,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+PMC_FILE = "r01_pmc_traffic_B8.json"     # latest committed PMC pass (tests/run_gpu_pmc.sh + profiles/summarize_pmc.py)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -36,9 +39,13 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=12)
+    ap.add_argument("--cpu-port", action="store_true", help="also time the numpy/C oracle (kind=port) beside the reference")
     ap.add_argument("--kernel-iters", type=int, default=200)
     ap.add_argument("--cross-kv", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: opt-in e4m3 cross-attention cache (accuracy-gated mode, not the headline)")
+    ap.add_argument("--no-rccl", action="store_true", help="N=1 only: do not create the one-rank RCCL communicator")
+    ap.add_argument("--no-longform", action="store_true", help="skip the BASELINE configs[2] leg (600 s recording sharded over the ranks)")
+    ap.add_argument("--longform-seconds", type=int, default=600)
     ap.add_argument("--contexts", type=int, default=1,
                     help="independent engine contexts per GPU, each with its own batch of --batch chunks, driven by "
                          "host threads (the decode step is latency-bound, so a second batch fills idle CUs); "
@@ -92,6 +99,24 @@ def cpu_baseline(g, v, spec, weights, n_tok_gpu, words_per_chunk, cpu_tokens):
             "rtf": total / 30.0}
 
 
+def cpu_reference(g, v, weights, n_tok, n_align):
+    """The reference's own path on the host cores (kind="reference"): transformers' pipeline called exactly as
+    REF/transcribe.py:21-33 does (CPU, fp32, batch_size=1, word timestamps) + the REF/utils.py pause split, on one 30 s
+    clip of the bench workload with the bench's token count and the same weights as the GPU engine."""
+    from oracle import hf_reference as R
+    from crisperwhisper_amd import synthetic as syn
+    x = syn.synth_audio(0, 480000, "noise")
+    r = R.time_reference_pipeline(g, v, weights.items(), x, n_tok, n_align=n_align, threads=os.cpu_count())
+    st = r["stage_s"]
+    return {"value": r["words"] / r["wall_s"], "unit": "aligned words/s", "cores": r["threads"], "host_cpus": os.cpu_count(),
+            "cpu_model": R.cpu_model_name(), "kind": "reference", "rtf": r["wall_s"] / r["audio_s"],
+            "sample": f"1 x 30 s clip (bench clip 0) through transformers.pipeline('automatic-speech-recognition', chunk_length_s=30, "
+                      f"batch_size=1, return_timestamps='word', fp32, device='cpu') + adjust_pauses, greedy, {n_tok} tokens per generate "
+                      f"call, torch threads {r['threads']}: {r['wall_s']:.1f} s wall for {r['words']} words (encoder {st['encoder']:.1f} s in "
+                      f"{r['stage_calls']['encoder']} passes, decoder {st['decoder']:.1f} s in {r['stage_calls']['decoder']} forwards, "
+                      f"token timestamps {st['token_timestamps']:.1f} s); model build {r['build_s']:.1f} s not counted"}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -102,12 +127,32 @@ def main():
     backend = os.environ.get("CW_DIST_BACKEND", "nccl")       # "gloo": lets 2 ranks share one GPU in a smoke test
     ndev = max(torch.cuda.device_count(), 1)
     dev = local % ndev
+    pg = None            # "nccl" (= RCCL) / "gloo" / None
+    pg_note = None
     if world > 1:
         torch.cuda.set_device(dev)
         if backend == "nccl":
             td.init_process_group("nccl", device_id=torch.device(f"cuda:{dev}"))
         else:
             td.init_process_group(backend)
+        pg = backend
+    elif backend == "nccl" and not a.no_rccl and torch.cuda.is_available():
+        # single GPU: still bring up a one-rank RCCL communicator so the gather of the word records goes through
+        # ncclAllGather on the 1-GPU lease too (the data path is identical at N = 1 and N = 8; only the peer count differs)
+        try:
+            torch.cuda.set_device(dev)
+            if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
+                td.init_process_group("nccl", device_id=torch.device(f"cuda:{dev}"))
+            else:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                      device_id=torch.device(f"cuda:{dev}"))
+            pg = "nccl"
+        except Exception as e:       # never take the bench down with it: report and run without a communicator
+            pg_note = f"RCCL communicator not available at world=1: {e!r}"
     from crisperwhisper_amd import collate, dist, generation, synthetic as syn, utils
     from crisperwhisper_amd.engine import Engine
 
@@ -130,7 +175,7 @@ def main():
     t_load = time.perf_counter() - t0
     vocab = collate.Vocabulary.from_synthetic(v)
     utils.bind_engine(eng)
-    shard = dist.Shard(rank, world, device=f"cuda:{dev}" if (world > 1 and backend == "nccl") else None)
+    shard = dist.Shard(rank, world, device=f"cuda:{dev}" if pg == "nccl" else None, collective_at_world1=(pg is not None))
 
     nfs = []
     for ci, e_ in enumerate(engines):
@@ -178,7 +223,7 @@ def main():
     def fence():
         for e_ in engines:
             e_.sync()
-        if world > 1:
+        if pg is not None:
             td.barrier()
         torch.cuda.synchronize()
 
@@ -195,10 +240,39 @@ def main():
         tokens += t
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}" if backend == "nccl" else "cpu")
+    def max_over_ranks(x):
+        if pg is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=f"cuda:{dev}" if pg == "nccl" else "cpu")
         td.all_reduce(tt, op=td.ReduceOp.MAX)
-        dt = float(tt.item())
+        return float(tt.item())
+
+    dt = max_over_ranks(dt)
+    n_gathers = shard.n_collectives
+
+    # ---- BASELINE configs[2]: one long recording -> 30 s chunks with 5 s strides, chunk-sharded over the ranks
+    # (contiguous blocks, dist.shard_bounds), one all-gather of the per-chunk records, seam merge + pause split on every
+    # rank.  Everything from the host PCM array to the final word list is inside the timed call (PCIe included).
+    longform = None
+    if a.geometry == "large-v3" and not a.no_longform and C == 1:
+        import crisperwhisper_amd as cw
+        pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, {}), tokenizer=vocab, chunk_length_s=30,
+                           batch_size=B, return_timestamps="word", device=f"cuda:{dev}", shard=shard, engines=engines)
+        xl = syn.synth_audio(1000, a.longform_seconds * 16000, "mixed")
+        gk = {"num_beams": 1, "language": "<|en|>", "task": "transcribe", "max_new_tokens": a.tokens, "min_new_tokens": a.tokens}
+        from crisperwhisper_amd import audio as cw_audio
+        n_chunks = len(cw_audio.chunk_windows(len(xl), 480000, 80000, 80000))
+        pipe(xl[: min(len(xl), 100 * 16000)], generate_kwargs=gk)                       # warm-up of this call path
+        fence()
+        t0 = time.perf_counter()
+        res = cw.adjust_pauses_for_hf_pipeline_output(pipe(xl, generate_kwargs=gk), engine=eng)
+        fence()
+        lw = max_over_ranks(time.perf_counter() - t0)
+        longform = {"workload": f"BASELINE configs[2]: {a.longform_seconds} s recording -> {n_chunks} chunks (30 s, 5 s strides), "
+                                f"contiguous chunk shards over {world} rank(s) = {[h - l for l, h in dist.shard_bounds(n_chunks, world)]}, "
+                                f"batch {B}, {a.tokens} tokens/pass, one all-gather of {dist.REC_WORDS * 4}-byte chunk records, seam merge + pause split",
+                    "wall_s": lw, "rtf": lw / a.longform_seconds, "aligned_words_per_s": len(res["chunks"]) / lw, "words": len(res["chunks"]),
+                    "scaling": "strong", "n_gpus": world}
     stages = eng.stage_times()
     for e_ in engines[1:]:
         for k_, (ms_, n_) in e_.stage_times().items():
@@ -215,7 +289,7 @@ def main():
     def pmc_traffic(kernel_substr):
         """HBM bytes per launch of the kernel from the committed rocprofv3 PMC pass (profiles/, same batch)."""
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_B8.json")))
+            t = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             if t.get("batch") != B:
                 return None
             for k, val in t["kernels"].items():
@@ -245,8 +319,13 @@ def main():
             "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1) / C, 3) for k, val in stages.items()},
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
                          "frac": r["achieved"] / 8000.0,
-                         "traffic": pmc_traffic(("attn_cross_split_fp8" if a.cross_kv == "fp8" else "attn_cross_split_kernel") if dom == 1 else "gemv2_bf16_kernelILi7"), "kernel": r["kernel"],
+                         "traffic": pmc_traffic(("attn_cross_split_fp8" if a.cross_kv == "fp8" else "attn_cross_split_kernel") if dom == 1 else "gemv2_bf16_kernelILi7"),
+                         "traffic_source": f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction), not re-measured in this run",
+                         "kernel": r["kernel"],
                          "avg_launch_ms": r["avg_ms"], "algorithmic_bytes_per_launch": r["algo_bytes"]},
+            "collective": {"backend": ("rccl (torch.distributed nccl)" if pg == "nccl" else pg), "all_gathers_in_timed_region": n_gathers,
+                           "note": pg_note},
+            "longform": longform,
             "roofline_other": [{"kernel": roof[k]["kernel"], "achieved_GBps": roof[k]["achieved"],
                                 "avg_launch_ms": roof[k]["avg_ms"], "algorithmic_bytes_per_launch": roof[k]["algo_bytes"]}
                                for k in roof if k != dom],
@@ -288,15 +367,23 @@ def main():
             line["stage_roofline"] = sr
             line["passes_per_step"] = stages["encoder"][1] / max(a.steps, 1)
         if keep:
+            for e_ in engines:                       # free the GPU side first: the CPU legs need the host memory bandwidth
+                e_.close()
+            engines = []
             try:
-                line["cpu_baseline"] = cpu_baseline(g, v, spec, weights, a.tokens, words / max(a.steps * B * C * world, 1), a.cpu_tokens)
+                line["cpu_baseline"] = cpu_reference(g, v, weights, a.tokens, 15 if a.geometry == "large-v3" else 3)
             except Exception as e:  # the baseline leg must never take the GPU number down with it
-                line["cpu_baseline"] = {"value": None, "unit": "aligned words/s", "cores": os.cpu_count(), "kind": "port",
+                line["cpu_baseline"] = {"value": None, "unit": "aligned words/s", "cores": os.cpu_count(), "kind": "reference",
                                         "sample": f"failed: {e!r}"}
+            if a.cpu_port:
+                try:
+                    line["cpu_baseline"]["port"] = cpu_baseline(g, v, spec, weights, a.tokens, words / max(a.steps * B * C * world, 1), a.cpu_tokens)
+                except Exception as e:
+                    line["cpu_baseline"]["port"] = {"value": None, "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(line), flush=True)
     for e_ in engines:
         e_.close()
-    if world > 1:
+    if pg is not None:
         td.destroy_process_group()
 
 

@@ -77,13 +77,18 @@ def unpack_words(rec: np.ndarray):
 class Shard:
     """rank/world + the gather primitive."""
 
-    def __init__(self, rank: int = 0, world: int = 1, device: Optional[str] = None):
+    def __init__(self, rank: int = 0, world: int = 1, device: Optional[str] = None, collective_at_world1: bool = False):
+        """``collective_at_world1``: run the all-gather through the process group even when it has a single rank (the
+        1-GPU bench then exercises the RCCL path end to end instead of short-cutting it)."""
         self.rank, self.world, self.device = rank, world, device
+        self.collective_at_world1 = collective_at_world1
+        self.n_collectives = 0
 
     def all_gather_records(self, recs: np.ndarray, max_per_rank: int) -> np.ndarray:
         """recs [n_local, W] int32 (W = REC_WORDS or WORD_REC) -> [n_total, W] ordered by chunk index."""
-        if self.world == 1:
+        if self.world == 1 and not self.collective_at_world1:
             return recs
+        self.n_collectives += 1
         import torch
         import torch.distributed as dist
         REC_WORDS = recs.shape[1]

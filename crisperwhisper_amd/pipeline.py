@@ -158,7 +158,8 @@ def _device_index(device) -> int:
 class CrisperWhisperPipeline:
     def __init__(self, model, tokenizer=None, feature_extractor=None, chunk_length_s=0, stride_length_s=None,
                  batch_size=1, return_timestamps=None, torch_dtype=None, dtype=None, device=None,
-                 shard: Optional[dist.Shard] = None, contexts: int = 1, cross_kv_dtype: Optional[str] = None, **kwargs):
+                 shard: Optional[dist.Shard] = None, contexts: int = 1, cross_kv_dtype: Optional[str] = None,
+                 engines: Optional[List[Engine]] = None, **kwargs):
         if isinstance(model, str):               # local checkpoint directory: no transformers object needed
             if tokenizer is None:
                 tokenizer = collate.Vocabulary.from_pretrained(model)
@@ -179,11 +180,16 @@ class CrisperWhisperPipeline:
         self.shard = shard or dist.Shard()
         # `contexts` > 1: independent engine contexts on the same GPU, each running its own batches from a host
         # thread -- the decode chain is latency-bound, so a second in-flight batch fills idle CUs.
-        self.engines = [Engine(self.bundle.spec, dtype=_dtype_name(dtype if dtype is not None else torch_dtype),
-                               max_batch=self.batch_size, device=_device_index(device), cross_kv_dtype=cross_kv_dtype)
-                        for _ in range(max(1, int(contexts)))]
-        for e in self.engines:
-            e.load_state_dict(self.bundle.weights)
+        if engines:                                # already created and loaded by the caller (bench.py shares them)
+            self.engines = list(engines)
+            if any(e.max_batch < self.batch_size for e in self.engines):
+                raise ValueError("engines were created with a smaller max_batch than batch_size")
+        else:
+            self.engines = [Engine(self.bundle.spec, dtype=_dtype_name(dtype if dtype is not None else torch_dtype),
+                                   max_batch=self.batch_size, device=_device_index(device), cross_kv_dtype=cross_kv_dtype)
+                            for _ in range(max(1, int(contexts)))]
+            for e in self.engines:
+                e.load_state_dict(self.bundle.weights)
         self.engine = self.engines[0]
         utils.bind_engine(self.engine)
         self.stats: Dict[str, Any] = {}

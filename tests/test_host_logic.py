@@ -277,3 +277,29 @@ def test_checkpoint_directory_loads_without_transformers(tmp_path):
         cw.ModelBundle.from_pretrained(d)
     with pytest.raises(FileNotFoundError):
         collate.Vocabulary.from_pretrained(str(tmp_path))
+
+
+def test_output_writers_vs_reference_vtt_and_formats():
+    """`writers.timestamps_to_vtt` byte for byte against REF/app.py:74-82 (executed by the golden
+    generator, tests/golden/gen_golden.py:gen_vtt), incl. minute / hour carries and the %06.3f rounding; SRT and JSON
+    writers: structure, numbering, comma decimals, lossless round trip."""
+    import json as _json
+    import re
+    from crisperwhisper_amd import writers
+    cases = Hh.gold_json("vtt_golden.json")
+    assert len(cases) >= 5
+    for c in cases:
+        chunks = [{"text": w["text"], "timestamp": tuple(w["timestamp"])} for w in c["chunks"]]
+        assert writers.timestamps_to_vtt(chunks) == c["vtt"]
+        srt = writers.timestamps_to_srt(chunks)
+        blocks = [b for b in srt.split("\n\n") if b.strip()]
+        assert len(blocks) == len(chunks)
+        for i, (b, w) in enumerate(zip(blocks, chunks), 1):
+            lines = b.strip("\n").split("\n")
+            assert lines[0] == str(i)
+            assert re.fullmatch(r"\d+:\d\d:\d\d,\d\d\d --> \d+:\d\d:\d\d,\d\d\d", lines[1]), lines[1]
+            assert lines[2] == w["text"].strip()
+        res = {"text": "".join(w["text"] for w in chunks), "chunks": chunks}
+        back = _json.loads(writers.to_json(res))
+        assert back["text"] == res["text"]
+        assert [(w["text"], tuple(w["timestamp"])) for w in back["chunks"]] == [(w["text"], w["timestamp"]) for w in chunks]
