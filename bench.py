@@ -37,8 +37,15 @@ def parse():
     ap.add_argument("--tokens", type=int, default=128, help="generated tokens per chunk (SURVEY.md 8d)")
     ap.add_argument("--geometry", default="large-v3", choices=["large-v3", "tiny"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--weights", default="aligned", choices=["aligned", "iid"],
+                    help="seeded synthetic weights: 'aligned' = random tensors whose alignment heads are peaked and monotone like a "
+                         "trained checkpoint's (crisperwhisper_amd/synthetic.py); the run is then checked word for word against the "
+                         "committed transformers output for the same clips (tests/golden/e2e_bench_golden.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=12)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the reference leg; 0 = calibrated per stage on "
+                    "the host (oracle/hf_reference.py:calibrate_threads: GEMM-shaped encoder vs M=1 decoder steps)")
+    ap.add_argument("--cpu-timeout", type=int, default=240, help="hard limit (s) of the reference leg")
     ap.add_argument("--cpu-port", action="store_true", help="also time the numpy/C oracle (kind=port) beside the reference")
     ap.add_argument("--kernel-iters", type=int, default=200)
     ap.add_argument("--cross-kv", default="bf16", choices=["bf16", "fp8"],
@@ -99,20 +106,29 @@ def cpu_baseline(g, v, spec, weights, n_tok_gpu, words_per_chunk, cpu_tokens):
             "rtf": total / 30.0}
 
 
-def cpu_reference(g, v, weights, n_tok, n_align):
+def cpu_reference(geometry, n_tok, threads, timeout_s, style="aligned"):
     """The reference's own path on the host cores (kind="reference"): transformers' pipeline called exactly as
     REF/transcribe.py:21-33 does (CPU, fp32, batch_size=1, word timestamps) + the REF/utils.py pause split, on one 30 s
-    clip of the bench workload with the bench's token count and the same weights as the GPU engine."""
-    from oracle import hf_reference as R
-    from crisperwhisper_amd import synthetic as syn
-    x = syn.synth_audio(0, 480000, "noise")
-    r = R.time_reference_pipeline(g, v, weights.items(), x, n_tok, n_align=n_align, threads=os.cpu_count())
+    clip of the bench workload (clip 0) with the bench's token count and the same seeded weights as the GPU engine.
+    Runs as a subprocess (oracle/hf_reference.py) under a hard timeout so that a slow host cannot lose the GPU line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "oracle.hf_reference", "--geometry", geometry, "--tokens", str(n_tok), "--threads", str(threads), "--style", style]
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "aligned words/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "reference",
+                "sample": f"transformers pipeline on the host did not finish one 30 s clip ({n_tok} tokens, {threads} threads) within {timeout_s} s"}
+    line = [l for l in p.stdout.splitlines() if l.startswith("REFJSON ")]
+    if p.returncode != 0 or not line:
+        return {"value": None, "unit": "aligned words/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "reference",
+                "sample": f"failed rc={p.returncode}: {p.stderr[-300:]}"}
+    r = json.loads(line[-1][8:])
     st = r["stage_s"]
-    return {"value": r["words"] / r["wall_s"], "unit": "aligned words/s", "cores": r["threads"], "host_cpus": os.cpu_count(),
-            "cpu_model": R.cpu_model_name(), "kind": "reference", "rtf": r["wall_s"] / r["audio_s"],
+    return {"value": r["words"] / r["wall_s"], "unit": "aligned words/s", "cores": r["threads"], "host_cpus": r["host_cpus"],
+            "cpu_model": r["cpu_model"], "kind": "reference", "rtf": r["wall_s"] / r["audio_s"],
             "sample": f"1 x 30 s clip (bench clip 0) through transformers.pipeline('automatic-speech-recognition', chunk_length_s=30, "
                       f"batch_size=1, return_timestamps='word', fp32, device='cpu') + adjust_pauses, greedy, {n_tok} tokens per generate "
-                      f"call, torch threads {r['threads']}: {r['wall_s']:.1f} s wall for {r['words']} words (encoder {st['encoder']:.1f} s in "
+                      f"call, torch threads {r.get('threads_encoder')} (encoder) / {r.get('threads_decoder')} (decoder), calibrated, of {r['host_cpus']} host CPUs: {r['wall_s']:.1f} s wall for {r['words']} words (encoder {st['encoder']:.1f} s in "
                       f"{r['stage_calls']['encoder']} passes, decoder {st['decoder']:.1f} s in {r['stage_calls']['decoder']} forwards, "
                       f"token timestamps {st['token_timestamps']:.1f} s); model build {r['build_s']:.1f} s not counted"}
 
@@ -164,13 +180,14 @@ def main():
                for _ in range(C)]
     eng = engines[0]
     keep = (not a.no_cpu_baseline) and world == 1 and rank == 0
+    keep_weights = keep and a.cpu_port
     weights = {}
     t0 = time.perf_counter()
     for name, shape in syn.weight_shapes(g).items():
-        w = syn.random_tensor(g, name, shape, seed=0)
+        w = syn.weight_tensor(g, name, shape, 0, a.weights)
         for e_ in engines:
             e_.load_tensor(name, w)
-        if keep:
+        if keep_weights:
             weights[name] = w
     t_load = time.perf_counter() - t0
     vocab = collate.Vocabulary.from_synthetic(v)
@@ -182,6 +199,8 @@ def main():
         clips = [syn.synth_audio((rank * C + ci) * B + i, 480000, "noise") for i in range(B)]
         nfs.append(e_.upload_pcm(clips))             # inputs resident in HBM before the timed region
     audio_s = 30.0 * B * C
+
+    last_raw = {}                                     # rank-local words of the latest step (before the pause split)
 
     def step_ctx(ci):
         eng, nf = engines[ci], nfs[ci]
@@ -198,6 +217,8 @@ def main():
             text, words = collate.decode_asr(vocab, [{"tokens": out["sequences"][k][:n],
                                                       "token_timestamps": out["token_timestamps"][k],
                                                       "stride": (30.0, 0.0, 0.0)}])
+            if ci == 0:
+                last_raw[k] = {"text": text, "chunks": [{"text": w_["text"], "timestamp": tuple(w_["timestamp"])} for w_ in words]}
             res = utils.adjust_pauses_for_hf_pipeline_output({"text": text, "chunks": words}, engine=eng)
             recs.append(dist.pack_words((rank * C + ci) * B + k, res["chunks"]))
         return recs, n_tokens
@@ -249,6 +270,32 @@ def main():
 
     dt = max_over_ranks(dt)
     n_gathers = shard.n_collectives
+    stages = eng.stage_times()
+    for e_ in engines[1:]:
+        for k_, (ms_, n_) in e_.stage_times().items():
+            stages[k_] = (stages[k_][0] + ms_, stages[k_][1] + n_)
+
+    # ---- the timed output against the reference: the clips of rank 0 are the ones tests/golden/gen_golden_bench.py ran
+    # through transformers (CPU, fp32) with the same aligned weights and token count
+    parity = None
+    gpath = os.path.join(ROOT, "tests", "golden", "e2e_bench_golden.json")
+    if rank == 0 and a.weights == "aligned" and a.geometry == "large-v3" and a.dtype == "bf16" and os.path.exists(gpath):
+        gold = json.load(open(gpath))
+        if gold["generate_kwargs"]["max_new_tokens"] == a.tokens and gold.get("weights") == "aligned":
+            n = min(B, len(gold["clips"]))
+            same_text = w_ok = w_tot = 0
+            for k in range(n):
+                gc_, mine = gold["clips"][k], last_raw.get(k)
+                if mine is None:
+                    continue
+                if mine["text"] == gc_["text"] and len(mine["chunks"]) == len(gc_["chunks"]):
+                    same_text += 1
+                    for wa, wb in zip(mine["chunks"], gc_["chunks"]):
+                        w_tot += 1
+                        w_ok += int(wa["text"] == wb["text"] and all(abs(x - y) <= 0.02 + 1e-9 for x, y in zip(wa["timestamp"], wb["timestamp"])))
+            parity = {"against": "tests/golden/e2e_bench_golden.json (transformers 5.15.0 pipeline, CPU fp32, same clips / weights / token count)",
+                      "mode": "free-running greedy, the timed path itself", "clips_with_identical_text": [same_text, n],
+                      "words_identical_and_within_20ms": [w_ok, w_tot]}
 
     # ---- BASELINE configs[2]: one long recording -> 30 s chunks with 5 s strides, chunk-sharded over the ranks
     # (contiguous blocks, dist.shard_bounds), one all-gather of the per-chunk records, seam merge + pause split on every
@@ -273,11 +320,6 @@ def main():
                                 f"batch {B}, {a.tokens} tokens/pass, one all-gather of {dist.REC_WORDS * 4}-byte chunk records, seam merge + pause split",
                     "wall_s": lw, "rtf": lw / a.longform_seconds, "aligned_words_per_s": len(res["chunks"]) / lw, "words": len(res["chunks"]),
                     "scaling": "strong", "n_gpus": world}
-    stages = eng.stage_times()
-    for e_ in engines[1:]:
-        for k_, (ms_, n_) in e_.stage_times().items():
-            stages[k_] = (stages[k_][0] + ms_, stages[k_][1] + n_)
-
     # roofline of the decode-step kernels, HIP events on the engine's own stream
     roof = {}
     for which, kname in ((0, "gemv2_bf16_kernel<EPI_GELU_F32> (decoder fc1 + fused LayerNorm)"),
@@ -312,7 +354,7 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "rtf": dt / total_audio, "tokens_per_s": tokens / dt,
             "config": {"workload": f"BASELINE configs[1]: batch={B} x 30 s synthetic 16 kHz audio per GPU, {a.dtype}, "
-                                   f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, greedy, word timestamps"
+                                   f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, {a.weights} synthetic weights, greedy, word timestamps"
                                    + (", fp8 (e4m3) cross-attention cache [opt-in mode]" if a.cross_kv == "fp8" else ""),
                        "chunks_per_gpu": B * C, "contexts_per_gpu": C, "tokens_per_chunk": a.tokens, "parallelism": f"chunk-dp{world}",
                        "cross_kv_cache": a.cross_kv, "weight_load_s": round(t_load, 1)},
@@ -323,6 +365,7 @@ def main():
                          "traffic_source": f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction), not re-measured in this run",
                          "kernel": r["kernel"],
                          "avg_launch_ms": r["avg_ms"], "algorithmic_bytes_per_launch": r["algo_bytes"]},
+            "parity": parity,
             "collective": {"backend": ("rccl (torch.distributed nccl)" if pg == "nccl" else pg), "all_gathers_in_timed_region": n_gathers,
                            "note": pg_note},
             "longform": longform,
@@ -371,7 +414,7 @@ def main():
                 e_.close()
             engines = []
             try:
-                line["cpu_baseline"] = cpu_reference(g, v, weights, a.tokens, 15 if a.geometry == "large-v3" else 3)
+                line["cpu_baseline"] = cpu_reference(a.geometry, a.tokens, a.cpu_threads, a.cpu_timeout, a.weights)
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "aligned words/s", "cores": os.cpu_count(), "kind": "reference",
                                         "sample": f"failed: {e!r}"}

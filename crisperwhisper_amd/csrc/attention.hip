@@ -23,8 +23,6 @@ __device__ inline f32x4_t mfma16a(bf16x8_t a, bf16x8_t b, f32x4_t c) {
                                                    __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
 }
 
-typedef unsigned int u32x4_so __attribute__((ext_vector_type(4)));
-
 #define KT 64          // keys per LDS tile
 #define RESCALE_THR 8.0f
 #define KS_STRIDE 72   // bf16 per K row in LDS (64 + 8)
@@ -407,177 +405,6 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
         hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
     else
         hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
-    return CW_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Decoder self-attention FUSED with its output projection (bf16 engine, <= 16 rows): removes one of the eight
-// dependent launches of a decoder layer (each costs ~2.6 us of ramp + boundary on top of its work).
-//
-// The out-projection is split over K by HEAD: x[b][:] += Wo[:, h*64:(h+1)*64] . a_h[b]  (+ bias once), and a block
-// that owns head h recomputes that head's attention for every batch row itself -- the self-attention history is tiny
-// (<= 448 keys x 256 B per row), so NC column-chunk blocks per head re-reading it from L2 costs less than a launch.
-// grid (H, NC), 512 threads = 8 waves:
-//   phase 1  wave w: attention of rows w, w + 8 for head h, entirely wave-local (8 lanes per 128-byte key row,
-//            scores in a per-wave LDS strip, DPP reductions, no block barrier); the first 64 keys' K and V rows are
-//            fetched before the position is known; result row -> bf16 -> LDS A tile [16][64];
-//   phase 2  wave w: NT 16-column tiles of this block's chunk: 2 MFMA 16x16x32 per tile against weight fragments that
-//            were requested at kernel entry; partial sums go to the f32 residual with atomics on the 2^-12 grid
-//            (exact, order-independent: common.h resid_grid).
-// ---------------------------------------------------------------------------------------------------
-#define SO_PRE 8           // key iterations (8 keys each) fetched up front
-__device__ inline float dpp_quad_sum8(float d) {   // sum over the 8 lanes sharing lane >> 3
-    d += dpp_mov<0xB1, 0xf>(0.f, d);               // quad_perm [1,0,3,2]
-    d += dpp_mov<0x4E, 0xf>(0.f, d);               // quad_perm [2,3,0,1]
-    d += dpp_mov<0x141, 0xf>(0.f, d);              // row_half_mirror: lane i <- lane 7 - i of its 8-lane half
-    return d;
-}
-__device__ inline float row_ror8_sum(float v) {    // v[lane] + v[lane ^ 8] (16-lane rows)
-    return v + dpp_mov<0x128, 0xf>(0.f, v);        // row_ror:8
-}
-
-template <int NT>
-__global__ __launch_bounds__(512) void attn_self_oproj_kernel(SelfOprojParams p) {
-    __shared__ __attribute__((aligned(16))) float sc_all[8 * 512];       // per-wave score strips (cap <= 512)
-    __shared__ __attribute__((aligned(16))) bf16_t At[16 * 72];          // A tile: 16 rows x 64 k (+8 pad)
-    const int h = blockIdx.x, chunk = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = lane & 7, grp = lane >> 3;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int D = p.H * 64;
-    float* sc = sc_all + wave * 512;
-
-    // ---- weight fragments of phase 2: independent of everything else, requested first
-    u32x4_so wq[NT][2];
-    int ncol[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        ncol[t] = (chunk * 8 * NT + wave * NT + t) * 16 + l15;
-        const int nc = ncol[t] < D ? ncol[t] : D - 1;
-        const bf16_t* wrow = p.Wo + (size_t)nc * D + h * 64 + g * 8;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wq[t][ks] = *(const u32x4_so*)(wrow + ks * 32);
-    }
-    float bias_v[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bias_v[t] = (h == 0 && p.bo) ? p.bo[ncol[t] < D ? ncol[t] : D - 1] : 0.f;
-    // rows this wave does not produce must still be finite in the A tile (they only reach dropped output rows)
-    for (int i = tid; i < 16 * 72; i += 512) At[i] = 0;
-    __syncthreads();
-
-    for (int b = wave; b < p.B; b += 8) {
-        const bf16_t* Kh = p.K + ((size_t)b * p.H + h) * p.cap * 64 + sub * 8;
-        const bf16_t* Vh = p.V + ((size_t)b * p.H + h) * p.cap * 64 + sub * 8;
-        Raw8<bf16_t> kpre[SO_PRE], vpre[SO_PRE];
-#pragma unroll
-        for (int u = 0; u < SO_PRE; ++u) kpre[u].ld(Kh + (size_t)min(u * 8 + grp, p.cap - 1) * 64);
-#pragma unroll
-        for (int u = 0; u < SO_PRE; ++u) vpre[u].ld(Vh + (size_t)min(u * 8 + grp, p.cap - 1) * 64);
-        float qv[8];
-        Row8<float>::ld(p.q + (size_t)b * D + h * 64 + sub * 8, qv);
-        const int n_keys = min(p.pos[b] + 1, p.cap);
-
-        float mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < SO_PRE; ++u) {
-            const int k = u * 8 + grp;
-            float kv[8];
-            kpre[u].cvt(kv);
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[e], d);
-            d = dpp_quad_sum8(d);
-            if (k < n_keys) { if (sub == 0) sc[k] = d; mx = fmaxf(mx, d); }
-        }
-        for (int k0 = SO_PRE * 8; k0 < n_keys; k0 += 32) {            // 4 key iterations in flight
-            float kv[4][8];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) Row8<bf16_t>::ld(Kh + (size_t)min(k0 + u * 8 + grp, n_keys - 1) * 64, kv[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * 8 + grp;
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[u][e], d);
-                d = dpp_quad_sum8(d);
-                if (k < n_keys) { if (sub == 0) sc[k] = d; mx = fmaxf(mx, d); }
-            }
-        }
-        mx = wave_max(mx);
-        __builtin_amdgcn_wave_barrier();            // strip is wave-private: LDS serves one wave's accesses in issue order
-        float sum = 0.f;
-        for (int k = lane; k < n_keys; k += 64) { const float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
-        const float inv = 1.0f / wave_sum(sum);
-        __builtin_amdgcn_wave_barrier();
-
-        float acc[8] = {};
-#pragma unroll
-        for (int u = 0; u < SO_PRE; ++u) {
-            const int k = u * 8 + grp;
-            if (k < n_keys) {                       // stale rows may hold non-finite bit patterns: skip, not scale
-                float vv[8];
-                vpre[u].cvt(vv);
-                const float pk = sc[k];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
-            }
-        }
-        for (int k0 = SO_PRE * 8; k0 < n_keys; k0 += 32) {
-            float vv[4][8];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) Row8<bf16_t>::ld(Vh + (size_t)min(k0 + u * 8 + grp, n_keys - 1) * 64, vv[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * 8 + grp;
-                if (k < n_keys) {
-                    const float pk = sc[k];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[u][e], acc[e]);
-                }
-            }
-        }
-        // reduce over the 8 key groups (lane bits 3, 4, 5), normalise, park the row as bf16
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = xor32_sum(xor16_sum(row_ror8_sum(acc[e]))) * inv;
-        if (grp == 0) {
-            ushort4 lo, hi;
-            lo.x = f32_to_bf16(acc[0]); lo.y = f32_to_bf16(acc[1]); lo.z = f32_to_bf16(acc[2]); lo.w = f32_to_bf16(acc[3]);
-            hi.x = f32_to_bf16(acc[4]); hi.y = f32_to_bf16(acc[5]); hi.z = f32_to_bf16(acc[6]); hi.w = f32_to_bf16(acc[7]);
-            *(ushort4*)(At + b * 72 + sub * 8) = lo;
-            *(ushort4*)(At + b * 72 + sub * 8 + 4) = hi;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 2: x[m][n] += sum_k a[m][k] Wo[n][h*64 + k]
-    bf16x8_t af[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) af[ks] = *(const bf16x8_t*)(At + l15 * 72 + ks * 32 + g * 8);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc = mfma16a(af[ks], __builtin_bit_cast(bf16x8_t, wq[t][ks]), acc);
-        const int n = ncol[t];
-        if (n < D) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = g * 4 + r;
-                if (m < p.B) atomicAdd(p.x + (size_t)m * D + n, resid_grid(acc[r] + bias_v[t]));
-            }
-        }
-    }
-}
-
-int cw_launch_attn_self_oproj(const SelfOprojParams& p, hipStream_t st) {
-    if (p.B < 1 || p.B > 16 || p.cap > 512 || p.H < 1) return CW_ERR_INVALID;
-    const int D = p.H * 64;
-    if (D % 256 == 0 && D >= 1024) {
-        hipLaunchKernelGGL((attn_self_oproj_kernel<2>), dim3(p.H, (D + 255) / 256), dim3(512), 0, st, p);
-    } else {
-        hipLaunchKernelGGL((attn_self_oproj_kernel<1>), dim3(p.H, (D + 127) / 128), dim3(512), 0, st, p);
-    }
     return CW_OK;
 }
 

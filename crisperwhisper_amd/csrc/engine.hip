@@ -78,7 +78,6 @@ struct cw_ctx {
     int *d_pos = nullptr, *d_cfg = nullptr;   // per-row decoder input position; [n_prompt, min_new, max_length, use_forced]
     hipGraphExec_t step_graph[65] = {};       // captured decode step (layers + logits + sampling) per batch size
     bool use_graph = true;
-    bool fuse_self = true;                    // decoder self-attention fused with its out-projection (CW_NO_FUSE_SELF=1: off)
     cw_gen_cfg gen{};
     bool gen_set = false;
     bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
@@ -222,7 +221,6 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
     c->bf16 = d.dtype == CW_DTYPE_BF16;
     if (getenv("CW_NO_GRAPH")) c->use_graph = false;
-    if (getenv("CW_NO_FUSE_SELF")) c->fuse_self = false;
     c->esz = c->bf16 ? 2 : 4;
     c->Bm = Bm;
     c->S_pad = 1536;
@@ -708,14 +706,12 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
             CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, L.ln1_b, ep));
         }
-        if (c->bf16 && nb <= 16 && c->fuse_self) {   // self-attention + out-projection + residual in one launch
-            SelfOprojParams p{c->dq, (const unsigned short*)L.sk, (const unsigned short*)L.sv, TGT, c->d_pos, nb, H,
-                              (const unsigned short*)L.wo, L.bo, c->dx};
-            CWCHK(c, cw_launch_attn_self_oproj(p, c->st));
-        } else {
+        {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
             if (frag) p.out_frag = (unsigned short*)c->d_xfrag2;
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
+        }
+        {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
             if (frag) CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));

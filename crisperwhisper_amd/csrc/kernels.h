@@ -71,20 +71,6 @@ struct DecAttnParams {
 };
 int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st);
 
-// Decoder self-attention + out-projection in one launch (bf16 engine, <= 16 rows): see attention.hip
-struct SelfOprojParams {
-    const float* q;              // [B][H*64] f32, scaled
-    const unsigned short* K;     // [Bm][H][cap][64] bf16 self-attention cache (row pos[b] already appended)
-    const unsigned short* V;
-    int cap;                     // cache rows per (b, h), <= 512
-    const int* pos;              // device [B]: n_keys = pos[b] + 1
-    int B, H;
-    const unsigned short* Wo;    // [D][D] bf16, row n = output column
-    const float* bo;             // [D] or null
-    float* x;                    // [B][D] f32 residual stream, accumulated in place
-};
-int cw_launch_attn_self_oproj(const SelfOprojParams& p, hipStream_t st);
-
 // Cross-attention decode split over the 1500 keys (flash-decoding): ATT_NS blocks per (batch, head) write
 // un-normalised partial outputs + (max, sum); the consumer GEMV combines them while loading its activations,
 // alignment rows are normalised once per generate call by cw_launch_align_normalize.

@@ -67,6 +67,42 @@ def cpu_model_name() -> str:
     return "unknown"
 
 
+def calibrate_threads(d_model: int, ffn: int, candidates=(2, 4, 8, 16, 32, 64, 128, 256)):
+    """torch intra-op thread counts that serve the reference best on this host: one for GEMM-shaped work (the encoder:
+    [1500 x d] @ [d x ffn]) and one for the M = 1 decoder steps (LayerNorm + GEMV chains streaming weights that do not fit
+    the caches -- 16 distinct [ffn x d] matrices are cycled; such steps stop scaling, and on oversubscribed or
+    quota-limited hosts collapse, long before every hardware thread is busy).  Well under a second per candidate; the
+    reference gets the best of each, nothing is held back from the CPU side."""
+    import torch
+    ncpu = os.cpu_count() or 1
+    cands = [c for c in candidates if c <= ncpu] or [1]
+    a = torch.randn(1500, d_model)
+    ws = [torch.randn(ffn, d_model) for _ in range(16)]
+    ln = torch.nn.LayerNorm(d_model)
+    best = {}
+    with torch.no_grad():
+        for kind in ("gemm", "gemv"):
+            res = []
+            for c in cands:
+                torch.set_num_threads(c)
+                dt = None
+                for rep in range(2):                       # first repetition warms the thread team up
+                    t0 = time.perf_counter()
+                    if kind == "gemm":
+                        torch.nn.functional.gelu(a @ ws[0].t())
+                    else:
+                        x = torch.randn(1, d_model)
+                        for w in ws:
+                            h = torch.nn.functional.gelu(ln(x) @ w.t())
+                            x = x + (h @ w) * 1e-3
+                    dt = time.perf_counter() - t0
+                res.append((dt, c))
+                if len(res) >= 2 and dt > 3 * min(r[0] for r in res):     # past the knee: stop before the pathological counts
+                    break
+            best[kind] = min(res)[1]
+    return best["gemm"], best["gemv"]
+
+
 def time_reference_pipeline(geom, vocab, tensors, audio: np.ndarray, n_tok: int, n_align: int = 15,
                             threads: int | None = None) -> Dict:
     """One clip through the reference call (REF/transcribe.py:21-33: chunk_length_s=30, return_timestamps="word";
@@ -80,8 +116,11 @@ def time_reference_pipeline(geom, vocab, tensors, audio: np.ndarray, n_tok: int,
     from oracle import pauses as OP
     transformers.logging.set_verbosity_error()
     from tests.golden import hf_synth as H
-    threads = threads or os.cpu_count() or 1
-    torch.set_num_threads(threads)
+    if threads:
+        t_enc = t_dec = int(threads)
+    else:
+        t_enc, t_dec = calibrate_threads(geom.d_model, geom.ffn)
+    torch.set_num_threads(t_enc)
     t0 = time.perf_counter()
     model = build_model_fast(geom, vocab, tensors, n_align)
     tok = H.build_tokenizer(vocab)
@@ -92,10 +131,12 @@ def time_reference_pipeline(geom, vocab, tensors, audio: np.ndarray, n_tok: int,
     stage = {"encoder": 0.0, "decoder": 0.0, "token_timestamps": 0.0}
     calls = {"encoder": 0, "decoder": 0, "token_timestamps": 0}
 
-    def spy(obj, name, key):
+    def spy(obj, name, key, nthreads=None):
         orig = getattr(obj, name)
 
         def wrapped(*a, **k):
+            if nthreads is not None:
+                torch.set_num_threads(nthreads)
             t = time.perf_counter()
             try:
                 return orig(*a, **k)
@@ -104,14 +145,43 @@ def time_reference_pipeline(geom, vocab, tensors, audio: np.ndarray, n_tok: int,
                 calls[key] += 1
         setattr(obj, name, wrapped)
 
-    spy(model.model.encoder, "forward", "encoder")
-    spy(model.model.decoder, "forward", "decoder")
+    spy(model.model.encoder, "forward", "encoder", t_enc)
+    spy(model.model.decoder, "forward", "decoder", t_dec)
     spy(model, "_extract_token_timestamps", "token_timestamps")
     gk = {"num_beams": 1, "language": "<|en|>", "task": "transcribe", "max_new_tokens": n_tok, "min_new_tokens": n_tok}
     t0 = time.perf_counter()
     res = pipe(audio.copy(), generate_kwargs=gk)
     res = OP.adjust_pauses_for_hf_pipeline_output(res)
     wall = time.perf_counter() - t0
-    return {"wall_s": wall, "words": len(res["chunks"]), "audio_s": len(audio) / 16000.0, "threads": torch.get_num_threads(),
+    return {"wall_s": wall, "words": len(res["chunks"]), "audio_s": len(audio) / 16000.0, "threads": max(t_enc, t_dec),
+            "threads_encoder": t_enc, "threads_decoder": t_dec,
             "build_s": t_build, "stage_s": {k: round(v, 3) for k, v in stage.items()}, "stage_calls": calls,
             "text": res["text"], "chunks": res["chunks"]}
+
+
+def main():
+    """CLI used by bench.py (subprocess with a hard timeout, so a slow host cannot take the GPU line down):
+    python -m oracle.hf_reference --geometry large-v3 --tokens 128 --threads 32  ->  one JSON line."""
+    import argparse
+    import json
+    import sys
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--geometry", default="large-v3", choices=["large-v3", "tiny"])
+    ap.add_argument("--tokens", type=int, default=128)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--style", default="aligned", choices=["iid", "aligned"])
+    a = ap.parse_args()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from crisperwhisper_amd import synthetic as syn
+    g, v = syn.large_v3_geometry() if a.geometry == "large-v3" else syn.tiny_geometry()
+    tensors = ((n, syn.weight_tensor(g, n, shape, 0, a.style)) for n, shape in syn.weight_shapes(g).items())
+    x = syn.synth_audio(0, 480000, "noise")
+    r = time_reference_pipeline(g, v, tensors, x, a.tokens, n_align=15 if a.geometry == "large-v3" else 3, threads=a.threads or None)
+    r.pop("chunks"); r.pop("text")
+    r["cpu_model"] = cpu_model_name()
+    r["host_cpus"] = os.cpu_count()
+    print("REFJSON " + json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()

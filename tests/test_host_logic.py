@@ -303,3 +303,16 @@ def test_output_writers_vs_reference_vtt_and_formats():
         back = _json.loads(writers.to_json(res))
         assert back["text"] == res["text"]
         assert [(w["text"], tuple(w["timestamp"])) for w in back["chunks"]] == [(w["text"], w["timestamp"]) for w in chunks]
+
+
+def test_reference_cpu_leg_of_bench_runs_the_real_pipeline():
+    """bench.py's cpu_baseline (kind="reference") = oracle/hf_reference.py: transformers' pipeline called as
+    REF/transcribe.py:21-33 + pause split, in a subprocess.  Tiny geometry here: the leg must produce the same words as the
+    committed transformers golden pipeline would for that clip shape, report its stage split, and honour the timeout."""
+    pytest.importorskip("transformers")
+    import bench
+    r = bench.cpu_reference("tiny", 8, 2, 300)
+    assert r["kind"] == "reference" and r["value"] and r["value"] > 0, r
+    assert r["cores"] == 2 and "transformers.pipeline" in r["sample"]
+    slow = bench.cpu_reference("tiny", 8, 2, 1)
+    assert slow["value"] is None and "did not finish" in slow["sample"]
