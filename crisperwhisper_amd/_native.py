@@ -65,6 +65,10 @@ _SIGS = {
     "cw_ingest": (_I, [_P, _P, _I, _I, C.c_int64, _I, _I, _I, _P]),
     "cw_resample_taps": (_I, [_I, _I, _P, _I, _P, _P, _P]),
     "cw_token_timestamps": (_I, [_P, _I, _I, _I, _P, _P]),
+    "cw_beam_begin": (_I, [_P, _I, _I, _P, _I, _I, _I]),
+    "cw_beam_step": (_I, [_P, _I, _P, _P]),
+    "cw_beam_advance": (_I, [_P, _P, _P]),
+    "cw_beam_finish": (_I, [_P, _I, _I, _P]),
     "cw_transcribe": (_I, [_P, _I, _P, C.POINTER(TranscribeCfg), _P, _P, _P, _I, _P]),
     "cw_align_matrix": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "cw_dtw": (_I, [_P, _P, _I, _I, _P, _P, _P]),

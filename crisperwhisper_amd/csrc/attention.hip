@@ -286,6 +286,58 @@ template <> struct Raw8<bf16_t> {
 #define DEC_GROUPS (DEC_THREADS / 8)
 #define DEC_PRE 2          // keys per 8-lane group fetched up front (2 x 64 = 128 keys)
 
+// Beam-search self-attention: key k of row b lives in the cache row anc[b][k] (the beam that was in that slot when
+// position k was decoded), so hypotheses are re-ordered by rewriting a small index table instead of copying the caches
+// of 32 layers every step (HF's cache.reorder_cache).  Same arithmetic as the plain kernel; loads are one table lookup
+// deeper, which this (non-headline) path can afford.
+template <typename T>
+__device__ inline void attn_decode_anc(const DecAttnParams& p, int h, int b) {
+    extern __shared__ float dsm[];
+    float* sc = dsm;
+    float* red = dsm + ((p.cap + 63) & ~63);
+    float* scratch = red + DEC_GROUPS * 64;
+    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
+    const int* anc = p.anc + (size_t)b * p.cap;
+    const int n_keys = p.pos[b] + 1;
+    float qv[8];
+    Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
+    float mx = -INFINITY;
+    for (int k = grp; k < n_keys; k += DEC_GROUPS) {
+        const T* kr = (const T*)p.K + (((size_t)anc[k] * p.H + h) * p.cap + k) * 64 + sub * 8;
+        float kv[8];
+        Row8<T>::ld(kr, kv);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[e], d);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if (sub == 0) sc[k] = d;
+        mx = fmaxf(mx, d);
+    }
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int k = tid; k < n_keys; k += DEC_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
+    sum = block_sum(sum, scratch);
+    const float inv = 1.0f / sum;
+    float acc[8] = {};
+    for (int k = grp; k < n_keys; k += DEC_GROUPS) {
+        const T* vr = (const T*)p.V + (((size_t)anc[k] * p.H + h) * p.cap + k) * 64 + sub * 8;
+        float vv[8];
+        Row8<T>::ld(vr, vv);
+        const float pk = sc[k] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[grp * 64 + sub * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        float r = 0.f;
+        for (int gI = 0; gI < DEC_GROUPS; ++gI) r += red[gI * 64 + tid];
+        if (p.out_frag) p.out_frag[frag_index(b, h * 64 + tid, p.H * 64)] = f32_to_bf16(r);
+        else p.out[(size_t)b * p.H * 64 + h * 64 + tid] = r;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams p) {
     extern __shared__ float dsm[];          // scores [cap rounded] | red [DEC_GROUPS][64] | scratch [64]
@@ -294,8 +346,12 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
     float* red = dsm + ((p.cap + 63) & ~63);
     float* scratch = red + DEC_GROUPS * 64;
     const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
-    const T* Kh = (const T*)p.K + ((size_t)b * p.H + h) * p.cap * 64;
-    const T* Vh = (const T*)p.V + ((size_t)b * p.H + h) * p.cap * 64;
+    // cache row of this query row: itself; the audio item it belongs to when several rows (beams) share one encoder
+    // window (kv_div = beams per item); or, per key, the ancestor row that wrote that position (beam search: `anc`)
+    const int bk = p.kv_div > 1 ? b / p.kv_div : b;
+    const T* Kh = (const T*)p.K + ((size_t)bk * p.H + h) * p.cap * 64;
+    const T* Vh = (const T*)p.V + ((size_t)bk * p.H + h) * p.cap * 64;
+    if (p.anc) { attn_decode_anc<T>(p, h, b); return; }
     float qv[8];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
     // The first DEC_PRE keys of every 8-lane group (128 keys in all: the whole self-attention history of a typical
@@ -420,8 +476,9 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
     const int k_lo = sp * per, k_hi = min(p.n_keys, k_lo + per), nk = k_hi - k_lo;
     const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
-    const T* Kh = (const T*)p.K + (((size_t)b * p.H + h) * p.n_keys + k_lo) * 64;
-    const T* Vh = (const T*)p.V + (((size_t)b * p.H + h) * p.n_keys + k_lo) * 64;
+    const int bk = p.kv_div > 1 ? b / p.kv_div : b;            // beams of one audio item share its encoder K/V
+    const T* Kh = (const T*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64;
+    const T* Vh = (const T*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64;
     float qv[8];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
 
@@ -566,9 +623,10 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_fp8_kernel(Cro
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
     const int k_lo = sp * per, k_hi = min(p.n_keys, k_lo + per), nk = k_hi - k_lo;
     const int tid = threadIdx.x, sub = tid & 3, grp = tid >> 2;
-    const unsigned char* Kh = (const unsigned char*)p.K + (((size_t)b * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
-    const unsigned char* Vh = (const unsigned char*)p.V + (((size_t)b * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
-    const float ks = p.kv_scale[((size_t)b * p.H + h) * 2], vs = p.kv_scale[((size_t)b * p.H + h) * 2 + 1];
+    const int bk = p.kv_div > 1 ? b / p.kv_div : b;
+    const unsigned char* Kh = (const unsigned char*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
+    const unsigned char* Vh = (const unsigned char*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
+    const float ks = p.kv_scale[((size_t)bk * p.H + h) * 2], vs = p.kv_scale[((size_t)bk * p.H + h) * 2 + 1];
     float qv[16];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 16, qv);
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 16 + 8, qv + 8);

@@ -268,6 +268,157 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Beam search, device side (TF/generation/utils.py:3208-3520 keeps the bookkeeping on the host side of the C ABI too).
+//
+// beam_topk_kernel: one block per hypothesis row.  log_probs = log_softmax(raw logits) (:3402), the logits processors
+// run on those log-probabilities (:3403; the same -inf predicate as the greedy kernel, the timestamp rule is invariant
+// under the shift), and the n_cand best (value, token) pairs of the row are emitted in (value desc, token asc) order.
+// The host adds the running beam scores and takes the top 2 * num_beams of the union: the global top-k over
+// num_beams * vocab candidates (:3147) is contained in the union of the per-row top-k lists.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void beam_topk_kernel(SampleParams p, int n_cand, float* __restrict__ cand_val,
+                                                         int* __restrict__ cand_id) {
+    __shared__ float s_f[64];
+    __shared__ int s_i[64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const float* lg = p.logits + (size_t)b * p.ldv;
+    const int* ids = p.ids + (size_t)b * p.ids_stride;
+    const int n_prompt = p.cfg[0], min_new_tokens = p.cfg[1];
+    const int t = p.pos[b] + 1, tb = p.timestamp_begin;
+    const int n_gen = t - n_prompt;
+    const bool last_ts = n_gen >= 1 && ids[t - 1] >= tb;
+    const bool penult_ts = n_gen < 2 || ids[t - 2] >= tb;
+    // last timestamp token generated so far (timestamps never decrease, so it is the maximum)
+    float lt = -1.f;
+    for (int k = n_prompt + tid; k < t; k += blockDim.x) if (ids[k] >= tb) lt = fmaxf(lt, (float)ids[k]);
+    const int last_tok = (int)block_max(lt, s_f);
+    __syncthreads();
+    const int ts_floor = (last_tok >= 0) ? ((last_ts && !penult_ts) ? last_tok : last_tok + 1) : tb;
+    const bool at_begin = (n_gen == 0);
+    const int ts_cap = (at_begin && p.max_initial_timestamp_index >= 0) ? tb + p.max_initial_timestamp_index : 0x7fffffff;
+    auto dead = [&](int v) -> bool {
+        const unsigned char mk = p.mask[v];
+        bool d = (mk & 1) || (at_begin && (mk & 2));
+        d |= (v == p.eos && n_gen < min_new_tokens);
+        if (last_ts) d |= penult_ts ? (v >= tb) : (v < p.eos);
+        d |= (v >= tb && v < ts_floor);
+        if (at_begin) d |= (v < tb) || (v > ts_cap);
+        return d;
+    };
+    // raw max / sum (log_softmax normaliser over the whole vocabulary), best allowed text / timestamp value
+    float rmax = -INFINITY, btext = -INFINITY, bts = -INFINITY;
+    for (int v = tid; v < p.V; v += blockDim.x) {
+        const float x = lg[v];
+        rmax = fmaxf(rmax, x);
+        if (!dead(v)) { if (v < tb) btext = fmaxf(btext, x); else bts = fmaxf(bts, x); }
+    }
+    rmax = block_max(rmax, s_f); __syncthreads();
+    btext = block_max(btext, s_f); __syncthreads();
+    bts = block_max(bts, s_f); __syncthreads();
+    float rsum = 0.f, tsum = 0.f;
+    const float M = fmaxf(btext, bts);
+    for (int v = tid; v < p.V; v += blockDim.x) {
+        const float x = lg[v];
+        rsum += expf(x - rmax);
+        if (v >= tb && !dead(v)) tsum += expf(x - M);
+    }
+    rsum = block_sum(rsum, s_f); __syncthreads();
+    tsum = block_sum(tsum, s_f); __syncthreads();
+    const float logz = logf(rsum);
+    const bool force_ts = (tsum > 0.f) && (logf(tsum) > btext - M);
+    // n_cand rounds of block-wide selection in (value desc, token asc) order
+    ArgPair prev = {INFINITY, -1};
+    for (int r = 0; r < n_cand; ++r) {
+        ArgPair best = {-INFINITY, 0x7fffffff};
+        for (int v = tid; v < p.V; v += blockDim.x) {
+            if (dead(v) || (force_ts && v < tb)) continue;
+            const float x = lg[v];
+            if (!(x > -INFINITY)) continue;
+            const bool after = (x < prev.v) || (x == prev.v && v > prev.i);
+            if (after) best = arg_better(best, ArgPair{x, v});
+        }
+        best = wave_argmax(best);
+        __syncthreads();
+        if (lane == 0) { s_f[wave] = best.v; s_i[wave] = best.i; }
+        __syncthreads();
+        best = {-INFINITY, 0x7fffffff};
+        for (int w = 0; w < nw; ++w) best = arg_better(best, ArgPair{s_f[w], s_i[w]});
+        if (tid == 0) {
+            const bool ok = best.v > -INFINITY;
+            cand_val[(size_t)b * n_cand + r] = ok ? (best.v - rmax) - logz : -INFINITY;    // torch: (x - max) - log(sum)
+            cand_id[(size_t)b * n_cand + r] = ok ? best.i : -1;
+        }
+        prev = best;
+        if (!(best.v > -INFINITY)) {                      // fewer allowed tokens than n_cand: pad the rest
+            for (int r2 = r + 1 + tid; r2 < n_cand; r2 += blockDim.x) {
+                cand_val[(size_t)b * n_cand + r2] = -INFINITY; cand_id[(size_t)b * n_cand + r2] = -1;
+            }
+            break;
+        }
+    }
+}
+
+int cw_launch_beam_topk(const SampleParams& p, int n_cand, float* cand_val, int* cand_id, hipStream_t st) {
+    if (n_cand < 1 || n_cand > 64) return CW_ERR_INVALID;
+    if (p.embed_bf16) hipLaunchKernelGGL((beam_topk_kernel<bf16_t>), dim3(p.B), dim3(1024), 0, st, p, n_cand, cand_val, cand_id);
+    else hipLaunchKernelGGL((beam_topk_kernel<float>), dim3(p.B), dim3(1024), 0, st, p, n_cand, cand_val, cand_id);
+    return CW_OK;
+}
+
+// rows <- rows[parent]: token history, cache ancestry (+ the slot the parent just wrote), then the chosen token, its
+// embedding for the next decoder step and the new position.  Two passes through a scratch copy (rows read each other).
+__global__ void beam_gather_kernel(BeamAdvanceParams p) {
+    const int r = blockIdx.x, q = p.parent[r];
+    const int t = p.pos[q] + 1;                                       // all rows share the position
+    for (int k = threadIdx.x; k < p.ids_stride; k += blockDim.x) p.ids_tmp[(size_t)r * p.ids_stride + k] = (k < t) ? p.ids[(size_t)q * p.ids_stride + k] : (k == t ? p.token[r] : p.ids[(size_t)r * p.ids_stride + k]);
+    for (int k = threadIdx.x; k < p.cap; k += blockDim.x)
+        p.anc_tmp[(size_t)r * p.cap + k] = (k < t - 1) ? p.anc[(size_t)q * p.cap + k] : (k == t - 1 ? q : r);
+}
+template <typename T>
+__global__ void beam_commit_kernel(BeamAdvanceParams p) {
+    const int r = blockIdx.x;
+    const int t = p.pos[r] + 1;
+    for (int k = threadIdx.x; k < p.ids_stride; k += blockDim.x) p.ids[(size_t)r * p.ids_stride + k] = p.ids_tmp[(size_t)r * p.ids_stride + k];
+    for (int k = threadIdx.x; k < p.cap; k += blockDim.x) p.anc[(size_t)r * p.cap + k] = p.anc_tmp[(size_t)r * p.cap + k];
+    const int tok = p.token[r];
+    if (t < p.cap) {
+        const T* e = (const T*)p.embed + (size_t)tok * p.d;
+        const float* pe = p.pos_embed + (size_t)t * p.d;
+        for (int k = threadIdx.x; k < p.d; k += blockDim.x) {
+            const float v = Act<T>::ld(e + k) + pe[k];
+            p.x_out[(size_t)r * p.d + k] = sizeof(T) == 2 ? resid_grid(v) : v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) p.pos[r] = t;
+}
+int cw_launch_beam_advance(const BeamAdvanceParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(beam_gather_kernel, dim3(p.rows), dim3(256), 0, st, p);
+    if (p.embed_bf16) hipLaunchKernelGGL((beam_commit_kernel<bf16_t>), dim3(p.rows), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((beam_commit_kernel<float>), dim3(p.rows), dim3(256), 0, st, p);
+    return CW_OK;
+}
+
+// out[i][a][p][:] = align[row_of_pos[i][p]][a][p][:]  (generation_whisper.py:262-303: the cross-attention row of output
+// position p comes from the beam that produced it).  grid (L, n_align, n_items)
+__global__ void align_gather_kernel(const float* __restrict__ align, const int* __restrict__ row_of_pos, int n_align,
+                                    int align_rows, int L, int n_keys, float* __restrict__ out) {
+    const int pI = blockIdx.x, a = blockIdx.y, i = blockIdx.z;
+    const int src = row_of_pos[(size_t)i * L + pI];
+    const float4* s4 = (const float4*)(align + (((size_t)src * n_align + a) * align_rows + pI) * n_keys);
+    float4* d4 = (float4*)(out + (((size_t)i * n_align + a) * align_rows + pI) * n_keys);
+    for (int k = threadIdx.x; k < n_keys / 4; k += blockDim.x) d4[k] = s4[k];
+}
+int cw_launch_align_gather(const float* align, const int* row_of_pos, int n_items, int n_align, int align_rows, int L,
+                           int n_keys, float* out, hipStream_t st) {
+    if (L <= 0 || n_keys % 4) return L <= 0 ? CW_OK : CW_ERR_INVALID;
+    hipLaunchKernelGGL(align_gather_kernel, dim3(L, n_align, n_items), dim3(128), 0, st, align, row_of_pos, n_align, align_rows,
+                       L, n_keys, out);
+    return CW_OK;
+}
+
 int cw_launch_sample(const SampleParams& p, hipStream_t st) {
     hipMemsetAsync(p.n_unfinished, 0, sizeof(int), st);
     if (p.embed_bf16)

@@ -81,6 +81,12 @@ struct cw_ctx {
     cw_gen_cfg gen{};
     bool gen_set = false;
     bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
+    // beam search (cw_beam_*): rows = items x beams; self-attention keys are found through the ancestry table
+    int beam_K = 0, beam_items = 0, beam_n_prompt = 0;
+    int *d_anc = nullptr, *d_anc_tmp = nullptr, *d_ids_tmp = nullptr, *d_parent = nullptr, *d_tok = nullptr, *d_cand_id = nullptr,
+        *d_rowmap = nullptr;
+    float *d_cand_val = nullptr, *d_align_g = nullptr;
+    const float* align_cur = nullptr;     // alignment rows the timestamp stage reads (d_align, or the beam-gathered copy)
     float* logits_capture = nullptr;
     int logits_capture_steps = 0;
     int last_L = 0, last_nb = 0;
@@ -709,6 +715,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
             if (frag) p.out_frag = (unsigned short*)c->d_xfrag2;
+            if (c->beam_K > 0) p.anc = c->d_anc;
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
         }
         {
@@ -725,6 +732,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml,
                                c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_ml, c->d_align_slot + (size_t)l * H,
                                c->d_pos, c->d.n_align, TGT, nb, H};
+            p.kv_div = c->beam_K > 0 ? c->beam_K : 1;
             if (c->kv8) {
                 p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs;
                 CWCHK(c, cw_launch_attn_cross_split_fp8(p, c->st));
@@ -736,6 +744,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn, nb, H);
             p.align_out = c->d.n_align > 0 ? c->d_align : nullptr; p.align_slot = c->d_align_slot + (size_t)l * H;
             p.n_align = c->d.n_align; p.align_rows = TGT;
+            p.kv_div = c->beam_K > 0 ? c->beam_K : 1;
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo_c, D, nullptr, nullptr, ep));
@@ -805,6 +814,8 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
     if (nb < 1 || nb > c->nb_encoded) return fail(c, CW_ERR_STATE, "nb=%d but %d windows encoded", nb, c->nb_encoded);
     if (n_prompt < 1 || n_prompt >= TGT) return fail(c, CW_ERR_INVALID, "n_prompt=%d out of range", n_prompt);
     if (max_length <= n_prompt || max_length > TGT) return fail(c, CW_ERR_INVALID, "max_length=%d out of range (n_prompt %d, max_target %d)", max_length, n_prompt, TGT);
+    c->beam_K = 0;
+    c->align_cur = c->d_align;
     std::vector<int> ids((size_t)nb * TGT, c->gen.pad_token_id);
     for (int b = 0; b < nb; ++b)
         for (int t = 0; t < n_prompt; ++t) {
@@ -907,8 +918,127 @@ int32_t cw_get_alignment(cw_ctx* c, float* out, int32_t nb, int32_t L) {
     for (int b = 0; b < nb; ++b)
         for (int a = 0; a < Ha; ++a)
             HIPCHK(c, hipMemcpy(out + (((size_t)b * Ha + a) * L) * CW_N_CTX,
-                                c->d_align + (((size_t)b * Ha + a) * TGT) * CW_N_CTX, (size_t)L * CW_N_CTX * 4,
+                                c->align_cur + (((size_t)b * Ha + a) * TGT) * CW_N_CTX, (size_t)L * CW_N_CTX * 4,
                                 hipMemcpyDeviceToHost));
+    return CW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// beam search: device half of GenerationMixin._beam_search (TF/generation/utils.py:3208-3520).  The host side of the
+// ABI (crisperwhisper_amd/generation.py) keeps the hypothesis bookkeeping -- running / finished beams, length penalty,
+// early-stopping heuristic -- exactly as HF does; the device runs the decoder on items x beams rows, reduces every row
+// to its best candidates and re-orders the per-row state by rewriting an ancestry table instead of copying KV caches.
+// ------------------------------------------------------------------------------------------------
+static int beam_alloc(cw_ctx* c) {
+    if (c->d_anc) return CW_OK;
+    const int TGT = c->d.max_target_positions, Bm = c->Bm;
+    CWCHK(c, dmalloc(c, &c->d_anc, (size_t)Bm * TGT * 4)); CWCHK(c, dmalloc(c, &c->d_anc_tmp, (size_t)Bm * TGT * 4));
+    CWCHK(c, dmalloc(c, &c->d_ids_tmp, (size_t)Bm * TGT * 4));
+    CWCHK(c, dmalloc(c, &c->d_parent, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_tok, Bm * 4));
+    CWCHK(c, dmalloc(c, &c->d_cand_val, (size_t)Bm * 64 * 4)); CWCHK(c, dmalloc(c, &c->d_cand_id, (size_t)Bm * 64 * 4));
+    CWCHK(c, dmalloc(c, &c->d_rowmap, (size_t)Bm * TGT * 4));
+    return CW_OK;
+}
+
+int32_t cw_beam_begin(cw_ctx* c, int32_t n_items, int32_t num_beams, const int32_t* prompt, int32_t n_prompt,
+                      int32_t max_length, int32_t min_new_tokens) {
+    const int D = c->d.d_model, V = c->d.vocab_size, TGT = c->d.max_target_positions;
+    if (!c->gen_set) return fail(c, CW_ERR_STATE, "cw_set_generation not called");
+    if (num_beams < 1 || n_items < 1 || n_items > c->nb_encoded) return fail(c, CW_ERR_STATE, "beam_begin: %d items but %d windows encoded", n_items, c->nb_encoded);
+    const int rows = n_items * num_beams;
+    if (rows > c->Bm) return fail(c, CW_ERR_INVALID, "beam search needs max_batch >= items x beams = %d (context has %d)", rows, c->Bm);
+    if (n_prompt < 1 || n_prompt >= TGT || max_length <= n_prompt || max_length > TGT) return fail(c, CW_ERR_INVALID, "beam_begin: n_prompt=%d max_length=%d out of range", n_prompt, max_length);
+    CWCHK(c, beam_alloc(c));
+    std::vector<int> ids((size_t)rows * TGT, c->gen.pad_token_id), anc((size_t)rows * TGT);
+    for (int r = 0; r < rows; ++r) {
+        for (int t = 0; t < n_prompt; ++t) {
+            const int tok = prompt[(size_t)(r / num_beams) * n_prompt + t];
+            if (tok < 0 || tok >= V) return fail(c, CW_ERR_INVALID, "prompt token %d out of range", tok);
+            ids[(size_t)r * TGT + t] = tok;
+        }
+        for (int t = 0; t < TGT; ++t) anc[(size_t)r * TGT + t] = r;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->d_anc, anc.data(), anc.size() * 4, hipMemcpyHostToDevice, c->st));
+    const int cfg[4] = {n_prompt, min_new_tokens, max_length, 0};
+    HIPCHK(c, hipMemcpyAsync(c->d_cfg, cfg, sizeof(cfg), hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    c->beam_K = num_beams; c->beam_items = n_items; c->beam_n_prompt = n_prompt;
+    c->align_cur = c->d_align;
+    for (int pos = 0; pos + 1 < n_prompt; ++pos) {          // prompt positions: forward only
+        CWCHK(c, cw_launch_set_pos(c->d_pos, pos, rows, c->st));
+        CWCHK(c, cw_launch_embed(c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, rows, D, c->st));
+        CWCHK(c, decode_step(c, rows, false));
+    }
+    CWCHK(c, cw_launch_set_pos(c->d_pos, n_prompt - 1, rows, c->st));
+    CWCHK(c, cw_launch_embed(c->d_ids, TGT, n_prompt - 1, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, rows, D, c->st));
+    KCHK(c);
+    c->last_nb = rows; c->last_L = n_prompt - 1;
+    return CW_OK;
+}
+
+int32_t cw_beam_step(cw_ctx* c, int32_t n_cand, float* cand_logprob, int32_t* cand_token) {
+    if (c->beam_K <= 0) return fail(c, CW_ERR_STATE, "cw_beam_begin not called");
+    if (n_cand < 1 || n_cand > 64) return fail(c, CW_ERR_INVALID, "n_cand=%d out of range", n_cand);
+    const int rows = c->beam_items * c->beam_K;
+    StageTimer tm(c, CW_STAGE_DECODE);
+    CWCHK(c, decode_step(c, rows, true));
+    SampleParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.logits = c->dlogits; sp.V = c->d.vocab_size; sp.ldv = c->Vpad; sp.B = rows; sp.mask = c->d_mask;
+    sp.eos = c->gen.eos_token_id; sp.pad = c->gen.pad_token_id;
+    sp.timestamp_begin = c->gen.no_timestamps_token_id + 1;
+    sp.max_initial_timestamp_index = c->gen.max_initial_timestamp_index;
+    sp.cfg = c->d_cfg; sp.pos = c->d_pos; sp.ids_stride = c->d.max_target_positions; sp.ids = c->d_ids;
+    sp.embed_bf16 = c->bf16 ? 1 : 0;
+    CWCHK(c, cw_launch_beam_topk(sp, n_cand, c->d_cand_val, c->d_cand_id, c->st));
+    KCHK(c);
+    tm.stop();
+    HIPCHK(c, hipMemcpy(cand_logprob, c->d_cand_val, (size_t)rows * n_cand * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cand_token, c->d_cand_id, (size_t)rows * n_cand * 4, hipMemcpyDeviceToHost));
+    c->last_L += 1;                       // one more decoder input position has its alignment rows
+    c->align_unnormalized = c->bf16 && c->d.n_align > 0;
+    return CW_OK;
+}
+
+int32_t cw_beam_advance(cw_ctx* c, const int32_t* parent, const int32_t* token) {
+    if (c->beam_K <= 0) return fail(c, CW_ERR_STATE, "cw_beam_begin not called");
+    const int rows = c->beam_items * c->beam_K, V = c->d.vocab_size;
+    for (int r = 0; r < rows; ++r) {
+        if (parent[r] < 0 || parent[r] >= rows || parent[r] / c->beam_K != r / c->beam_K) return fail(c, CW_ERR_INVALID, "beam_advance: row %d cannot descend from row %d", r, parent[r]);
+        if (token[r] < 0 || token[r] >= V) return fail(c, CW_ERR_INVALID, "beam_advance: token %d out of range", token[r]);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_parent, parent, rows * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->d_tok, token, rows * 4, hipMemcpyHostToDevice, c->st));
+    BeamAdvanceParams p;
+    memset(&p, 0, sizeof(p));
+    p.ids = c->d_ids; p.ids_tmp = c->d_ids_tmp; p.ids_stride = c->d.max_target_positions;
+    p.anc = c->d_anc; p.anc_tmp = c->d_anc_tmp; p.cap = c->d.max_target_positions;
+    p.parent = c->d_parent; p.token = c->d_tok; p.pos = c->d_pos;
+    p.embed = c->embed; p.pos_embed = c->dec_pos; p.x_out = c->dx; p.d = c->d.d_model; p.embed_bf16 = c->bf16 ? 1 : 0;
+    p.rows = rows;
+    CWCHK(c, cw_launch_beam_advance(p, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));                   // parent / token are caller-owned host buffers
+    return CW_OK;
+}
+
+int32_t cw_beam_finish(cw_ctx* c, int32_t n_items, int32_t L, const int32_t* row_of_pos) {
+    if (c->beam_K <= 0) return fail(c, CW_ERR_STATE, "cw_beam_begin not called");
+    const int rows = c->beam_items * c->beam_K, TGT = c->d.max_target_positions, Ha = c->d.n_align;
+    if (n_items != c->beam_items || L < 0 || L > c->last_L) return fail(c, CW_ERR_INVALID, "beam_finish: %d items x %d rows requested, %d x %d decoded", n_items, L, c->beam_items, c->last_L);
+    for (size_t i = 0; i < (size_t)n_items * L; ++i)
+        if (row_of_pos[i] < 0 || row_of_pos[i] >= rows) return fail(c, CW_ERR_INVALID, "beam_finish: row %d out of range", row_of_pos[i]);
+    if (Ha > 0 && L > 0) {
+        if (!c->d_align_g) CWCHK(c, dmalloc(c, &c->d_align_g, (size_t)c->Bm * Ha * TGT * CW_N_CTX * 4, false));
+        c->last_nb = rows;
+        CWCHK(c, normalize_alignment(c));
+        HIPCHK(c, hipMemcpyAsync(c->d_rowmap, row_of_pos, (size_t)n_items * L * 4, hipMemcpyHostToDevice, c->st));
+        CWCHK(c, cw_launch_align_gather(c->d_align, c->d_rowmap, n_items, Ha, TGT, L, CW_N_CTX, c->d_align_g, c->st));
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        c->align_cur = c->d_align_g;
+    }
+    c->last_nb = n_items; c->last_L = L;
+    c->beam_K = 0;                                            // back to one row per item
     return CW_OK;
 }
 
@@ -948,7 +1078,7 @@ int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, 
     HIPCHK(c, hipStreamSynchronize(c->st));
     StageTimer tm(c, CW_STAGE_TIMESTAMPS);
     CWCHK(c, normalize_alignment(c));
-    CWCHK(c, run_alignment(c, c->d_align, nb, Ha, TGT, S, n_prompt, N, c->d_ncols, c->d.median_filter_width, c->d_mean, c->d_std, c->d_mat));
+    CWCHK(c, run_alignment(c, c->align_cur ? c->align_cur : c->d_align, nb, Ha, TGT, S, n_prompt, N, c->d_ncols, c->d.median_filter_width, c->d_mean, c->d_std, c->d_mat));
     CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->d_path_text, c->d_path_time, c->d_path_len, c->st));
     KCHK(c);
     tm.stop();

@@ -48,6 +48,21 @@ struct SampleParams {
     int embed_bf16;
 };
 int cw_launch_sample(const SampleParams& p, hipStream_t st);
+// beam search (elementwise.hip): per row the n_cand best processed log-probabilities of the next token
+// (log_softmax of the raw logits, then the same processors as the greedy path) ...
+int cw_launch_beam_topk(const SampleParams& p, int n_cand, float* cand_val, int* cand_id, hipStream_t st);
+// ... and the re-ordering of the per-row state after the host picked (parent row, token) for every row
+struct BeamAdvanceParams {
+    int* ids; int* ids_tmp; int ids_stride;      // [rows][stride] token history
+    int* anc; int* anc_tmp; int cap;             // [rows][cap] cache-row ancestry of the self-attention keys
+    const int* parent; const int* token;         // [rows]
+    int* pos;                                    // [rows] position of the last decoder input
+    const void* embed; const float* pos_embed; float* x_out; int d; int embed_bf16;
+    int rows;
+};
+int cw_launch_beam_advance(const BeamAdvanceParams& p, hipStream_t st);
+int cw_launch_align_gather(const float* align, const int* row_of_pos, int n_items, int n_align, int align_rows, int L,
+                           int n_keys, float* out, hipStream_t st);
 int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st);
 int cw_launch_embed(const int* ids, int ids_stride, int t, const void* embed, int embed_bf16, const float* pos_embed,
                     float* x_out, int B, int d, hipStream_t st);
@@ -68,6 +83,8 @@ struct DecAttnParams {
     const int* align_slot; // [H] slot index of each head in this layer (or -1), device
     int n_align, align_rows;            // alignment row written = pos[b]
     int B, H;
+    int kv_div;            // > 1: query rows b share cache row b / kv_div (beams of one audio item; cross-attention)
+    const int* anc;        // non-null: [B][cap] cache row holding key k of query row b (beam-search self-attention)
 };
 int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st);
 
@@ -93,6 +110,7 @@ struct CrossSplitParams {
     const int* pos;        // [B] alignment row to write
     int n_align, align_rows, B, H;
     const float* kv_scale; // fp8 cache only: [B][H][2] dequantisation scales of K and V (null: K/V hold T)
+    int kv_div;            // > 1: rows b share the K/V of audio item b / kv_div (beam search)
 };
 int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st);
 // opt-in fp8 (OCP e4m3) cross-attention cache: quantise one layer's bf16 K/V [B][H][S][64] with a scale per (b, h, K|V)

@@ -236,6 +236,29 @@ class Engine:
         return ([toks[i, :lens[i]].astype(np.int64) for i in range(nb)], [ts[i, :lens[i]].copy() for i in range(nb)],
                 int(passes.value))
 
+    # ------------------------------------------------------------------ beam search (device half; host half: generation.beam_search)
+    def beam_begin(self, prompt: np.ndarray, num_beams: int, max_length: int, min_new_tokens: int = 0):
+        prompt = _i32(prompt)
+        n_items, n_prompt = prompt.shape
+        self._beam_rows = n_items * int(num_beams)
+        self._chk(self.lib.cw_beam_begin(self.ctx, n_items, int(num_beams), _ptr(prompt), n_prompt, int(max_length),
+                                         int(min_new_tokens)))
+
+    def beam_step(self, n_cand: int):
+        """-> (log-probabilities [rows, n_cand] float32 best first, tokens [rows, n_cand] int32; -inf / -1 padded)."""
+        vals = np.empty((self._beam_rows, n_cand), dtype=np.float32)
+        toks = np.empty((self._beam_rows, n_cand), dtype=np.int32)
+        self._chk(self.lib.cw_beam_step(self.ctx, int(n_cand), _ptr(vals), _ptr(toks)))
+        return vals, toks
+
+    def beam_advance(self, parent, token):
+        parent, token = _i32(parent), _i32(token)
+        self._chk(self.lib.cw_beam_advance(self.ctx, _ptr(parent), _ptr(token)))
+
+    def beam_finish(self, row_of_pos: np.ndarray):
+        r = _i32(row_of_pos)
+        self._chk(self.lib.cw_beam_finish(self.ctx, r.shape[0], r.shape[1], _ptr(r)))
+
     def token_timestamps(self, nb: int, L: int, n_prompt: int, num_frames) -> np.ndarray:
         nf = _i32(num_frames)
         out = np.zeros((nb, L + 1), dtype=np.float32)

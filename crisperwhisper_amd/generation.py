@@ -159,6 +159,108 @@ def split_segments(seq: np.ndarray, token_ts: np.ndarray, time_offset: float, ti
     return out, advance
 
 
+def _topk_desc(values: np.ndarray, k: int) -> np.ndarray:
+    """Indices of the k largest entries per row, largest first, ties towards the lower index (torch.topk on CPU)."""
+    order = np.argsort(-values, axis=-1, kind="stable")
+    return order[..., :k]
+
+
+def beam_search(engine: Engine, prompt: np.ndarray, max_length: int, min_new_tokens: int, num_beams: int,
+                length_penalty: float = 1.0, early_stopping=False):
+    """Host half of ``GenerationMixin._beam_search`` (TF/generation/utils.py:3208-3520) -- running / finished
+    hypotheses, length penalty, the early-stopping heuristic (:3009-3053), all in float32 like HF -- over the device half
+    (``Engine.beam_begin / beam_step / beam_advance / beam_finish``: decoder forwards on items x beams rows, log-softmax +
+    logits processors, per-row best candidates, cache ancestry).  Deterministic beam search only (``do_sample=False``).
+
+    Returns (sequences [B, n_prompt + max_generated] int64 padded with pad_token_id, beam_indices [B, max_generated]
+    int32 flat row indices or -1, L = decoder input positions whose alignment rows were gathered for the returned
+    sequences; ``engine.token_timestamps(B, L, n_prompt, ...)`` is valid afterwards)."""
+    spec = engine.spec
+    f32 = np.float32
+    prompt = np.asarray(prompt, dtype=np.int64)
+    B, n_prompt = prompt.shape
+    K, V = int(num_beams), spec.vocab_size
+    eos, pad = spec.eos_token_id, spec.pad_token_id
+    keep = max(2, 1 + 1) * K                                    # beams_to_keep (:3280-3281), one eos token id
+    top_mask = np.arange(keep) < K
+    fill = pad if pad else eos                                   # output_fill_value (:3323)
+    running_seq = np.full((B, K, max_length), fill, dtype=np.int64)
+    running_seq[:, :, :n_prompt] = prompt[:, None, :]
+    sequences = running_seq.copy()
+    running_scores = np.zeros((B, K), f32); running_scores[:, 1:] = f32(-1e9)
+    beam_scores = np.full((B, K), f32(-1e9), f32)
+    is_sent_finished = np.zeros((B, K), bool)
+    unsat = np.ones((B, 1), bool)
+    running_bi = np.full((B, K, max_length - n_prompt), -1, dtype=np.int32)
+    beam_indices = running_bi.copy()
+    cur_len = n_prompt
+    bidx = np.arange(B)[:, None]
+    engine.beam_begin(prompt, K, max_length, min_new_tokens)
+    while True:
+        vals, toks = engine.beam_step(keep)                      # [B*K, keep] processed log-probs, best first
+        vals = vals.reshape(B, K, keep).astype(f32)
+        toks = toks.reshape(B, K, keep).astype(np.int64)
+        acc = (vals + running_scores[:, :, None]).astype(f32)    # :3436
+        acc = np.where(toks >= 0, acc, f32(-np.inf)).reshape(B, K * keep)
+        flat = (np.arange(K)[None, :, None] * V + np.maximum(toks, 0)).reshape(B, K * keep)
+        # top `keep` of the union in (value desc, flattened index asc) order == torch.topk over [B, K * V] (:3147)
+        order = np.lexsort((flat, -acc), axis=-1)[:, :keep]
+        topk_lp = np.take_along_axis(acc, order, axis=1)
+        topk_flat = np.take_along_axis(flat, order, axis=1)
+        topk_beam, topk_ids = topk_flat // V, topk_flat % V
+        topk_seq = running_seq[bidx, topk_beam]                   # [B, keep, max_length]
+        topk_seq[:, :, cur_len] = topk_ids
+        topk_bi = running_bi[bidx, topk_beam]
+        topk_bi[:, :, cur_len - n_prompt] = (topk_beam + np.arange(B)[:, None] * K).astype(np.int32)
+        # d. stopping criteria: eos token, max length (:3456-3462)
+        hits = (topk_ids == eos) | (cur_len + 1 >= max_length)
+        # e. running beams of the next iteration (:3173-3190)
+        run_lp = (topk_lp + hits.astype(f32) * f32(-1.0e9)).astype(f32)
+        nxt = _topk_desc(run_lp, K)
+        running_seq = np.take_along_axis(topk_seq, nxt[:, :, None], axis=1)
+        running_scores = np.take_along_axis(run_lp, nxt, axis=1)
+        running_bi = np.take_along_axis(topk_bi, nxt[:, :, None], axis=1)
+        # f. finished hypotheses (:3192-3245)
+        did_top = hits & top_mask[None, :]
+        lp2 = (topk_lp / f32((cur_len + 1 - n_prompt) ** length_penalty)).astype(f32)
+        full = np.all(is_sent_finished, axis=-1, keepdims=True) & (early_stopping is True)
+        lp2 = (lp2 + full.astype(f32) * f32(-1.0e9)).astype(f32)
+        lp2 = (lp2 + (~unsat).astype(f32) * f32(-1.0e9)).astype(f32)
+        lp2 = (lp2 + (~did_top).astype(f32) * f32(-1.0e9)).astype(f32)
+        m_seq = np.concatenate([sequences, topk_seq], axis=1)
+        m_scores = np.concatenate([beam_scores, lp2], axis=1)
+        m_bi = np.concatenate([beam_indices, topk_bi], axis=1)
+        m_fin = np.concatenate([is_sent_finished, did_top], axis=1)
+        sel = _topk_desc(m_scores, K)
+        sequences = np.take_along_axis(m_seq, sel[:, :, None], axis=1)
+        beam_scores = np.take_along_axis(m_scores, sel, axis=1)
+        beam_indices = np.take_along_axis(m_bi, sel[:, :, None], axis=1)
+        is_sent_finished = np.take_along_axis(m_fin, sel, axis=1)
+        # g. next iteration: cache re-ordering (device), stopping condition of the search as a whole
+        parent = running_bi[:, :, cur_len - n_prompt].reshape(-1)
+        token = running_seq[:, :, cur_len].reshape(-1)
+        cur_len += 1
+        best_len = cur_len - n_prompt                              # early_stopping False / length_penalty: :3042-3053
+        best_possible = (running_scores[:, :1] / f32(best_len ** length_penalty)).astype(f32)
+        worst_finished = np.where(is_sent_finished, beam_scores.min(axis=1, keepdims=True), f32(-1.0e9))
+        unsat = unsat & np.any(best_possible > worst_finished, axis=-1, keepdims=True)
+        go_on = bool(np.any(unsat)) and (not (bool(np.all(is_sent_finished)) and early_stopping is True)) and (not bool(np.all(hits)))
+        if not go_on:
+            break
+        engine.beam_advance(parent, token)
+    seq_out = sequences[:, 0, :]
+    bi_out = beam_indices[:, 0, :]
+    max_gen = int((bi_out != -1).sum(axis=1).max())
+    seq_out = seq_out[:, :n_prompt + max_gen]
+    bi_out = bi_out[:, :max_gen]
+    # cross-attention rows of the returned sequences: HF's unrolled beam_indices (generation_whisper.py:262-303),
+    # -1 (positions after a hypothesis' eos) -> row 0
+    unrolled = np.concatenate([np.repeat(bi_out[:, :1], n_prompt - 1, axis=1), bi_out], axis=1) if n_prompt > 1 else bi_out
+    unrolled = np.where(unrolled == -1, 0, unrolled).astype(np.int32)
+    engine.beam_finish(unrolled)
+    return seq_out, bi_out, unrolled.shape[1]
+
+
 def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str], task: Optional[str] = None,
              max_new_tokens: Optional[int] = None, min_new_tokens: Optional[int] = None,
              num_beams: Optional[int] = 1, stats: Optional[dict] = None, native: Optional[bool] = None):
@@ -171,12 +273,17 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
     (``cw_transcribe``, one C call per batch); ``native=False`` runs the same control flow here, stage by stage
     over ``cw_encode`` / ``cw_decode`` / ``cw_token_timestamps`` -- the two are tested to agree exactly."""
     spec = engine.spec
-    if num_beams not in (None, 1):
-        raise ValueError("the native path implements greedy decoding only: pass generate_kwargs={'num_beams': 1} "
-                         "(transformers 5.x pipelines default to 5 beams; the 2024 reference was greedy)")
+    num_beams = 1 if num_beams is None else int(num_beams)
+    if num_beams < 1:
+        raise ValueError(f"`num_beams` has to be an integer strictly greater than 0, but is {num_beams}")
+    if num_beams * n_items > engine.max_batch:
+        raise ValueError(f"beam search decodes items x beams = {num_beams * n_items} rows; the engine was created with "
+                         f"max_batch = {engine.max_batch}")
     num_frames = np.asarray(num_frames, dtype=np.int64)
     if native is None:
-        native = hasattr(engine, "transcribe")
+        native = hasattr(engine, "transcribe") and num_beams == 1
+    if num_beams > 1:
+        native = False                                  # the seek loop runs here, beam bookkeeping in beam_search()
     if native:
         toks, detect = resolve_prompt(spec, language, task)
         if detect and not spec.lang_to_id:
@@ -223,9 +330,15 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
         if not (pre_encoded and n_calls == 0):            # first pass: windows already encoded for detection
             engine.encode(active, seek[active], seek_num[active])
         max_length = (n_prompt + max_new_tokens) if max_new_tokens is not None else min(spec.max_length, spec.max_target_positions)
-        seqs, lens, _ = engine.decode(init[active], max_length, min_new_tokens or 0)
-        total = int(lens.max())
-        L = total - 1
+        if num_beams > 1:
+            bs, _, L = beam_search(engine, init[active], max_length, min_new_tokens or 0, num_beams)
+            total = bs.shape[1]
+            seqs = np.full((len(active), spec.max_target_positions), spec.pad_token_id, dtype=np.int64)
+            seqs[:, :total] = bs
+        else:
+            seqs, lens, _ = engine.decode(init[active], max_length, min_new_tokens or 0)
+            total = int(lens.max())
+            L = total - 1
         token_ts = engine.token_timestamps(len(active), L, n_prompt, (num_frames - seek)[active])
         n_calls += 1
         for row, i in enumerate(active):

@@ -22,6 +22,14 @@ from ._native import N_SAMPLES
 from .engine import Engine, ModelSpec
 
 logger = logging.getLogger("crisperwhisper_amd")
+DEFAULT_NUM_BEAMS = 5       # TF/pipelines/automatic_speech_recognition.py:160-163 (5.x pipeline default)
+_warned = set()
+
+
+def _warn_once(key: str, msg: str):
+    if key not in _warned:
+        _warned.add(key)
+        logger.warning(msg)
 
 
 class ModelBundle:
@@ -135,10 +143,14 @@ class _SafetensorsWeights(dict):
 
 def _dtype_name(dtype) -> str:
     if dtype is None:
+        _warn_once("dtype", "no torch_dtype given: running the bf16 engine (HF would keep the checkpoint dtype)")
         return "bf16"
     s = str(dtype)
     if "float32" in s or s in ("f32", "fp32"):
         return "f32"
+    if "float16" in s and "bfloat16" not in s:
+        _warn_once("fp16", "torch_dtype=float16 requested (REF/transcribe.py:10): the engine computes in bfloat16 "
+                           "(same MFMA rate on gfx950, 8 instead of 11 significand bits, no fp16 overflow clamp needed)")
     return "bf16"          # float16 / bfloat16 requests run the bf16 MFMA path
 
 
@@ -159,7 +171,12 @@ class CrisperWhisperPipeline:
     def __init__(self, model, tokenizer=None, feature_extractor=None, chunk_length_s=0, stride_length_s=None,
                  batch_size=1, return_timestamps=None, torch_dtype=None, dtype=None, device=None,
                  shard: Optional[dist.Shard] = None, contexts: int = 1, cross_kv_dtype: Optional[str] = None,
-                 engines: Optional[List[Engine]] = None, **kwargs):
+                 engines: Optional[List[Engine]] = None, num_beams: Optional[int] = None, **kwargs):
+        """``num_beams`` (construction time): the widest beam the contexts are provisioned for -- decoder rows =
+        batch_size x num_beams, at most 64.  Default 5 = ``AutomaticSpeechRecognitionPipeline._default_generation_config``
+        of the installed transformers (TF/pipelines/automatic_speech_recognition.py:160-163), which is what a call
+        without ``generate_kwargs`` runs (REF/transcribe.py:33); pass ``generate_kwargs={"num_beams": 1}`` per call for
+        the greedy decoding of the 2024 reference."""
         if isinstance(model, str):               # local checkpoint directory: no transformers object needed
             if tokenizer is None:
                 tokenizer = collate.Vocabulary.from_pretrained(model)
@@ -176,6 +193,9 @@ class CrisperWhisperPipeline:
         self.chunk_length_s = chunk_length_s
         self.stride_length_s = stride_length_s
         self.batch_size = int(batch_size or 1)
+        self.default_num_beams = DEFAULT_NUM_BEAMS
+        self.max_rows = min(64, self.batch_size * int(num_beams or DEFAULT_NUM_BEAMS))
+        self.max_rows = max(self.max_rows, min(64, self.batch_size))
         self.return_timestamps = return_timestamps
         self.shard = shard or dist.Shard()
         # `contexts` > 1: independent engine contexts on the same GPU, each running its own batches from a host
@@ -184,9 +204,10 @@ class CrisperWhisperPipeline:
             self.engines = list(engines)
             if any(e.max_batch < self.batch_size for e in self.engines):
                 raise ValueError("engines were created with a smaller max_batch than batch_size")
+            self.max_rows = min(e.max_batch for e in self.engines)
         else:
             self.engines = [Engine(self.bundle.spec, dtype=_dtype_name(dtype if dtype is not None else torch_dtype),
-                                   max_batch=self.batch_size, device=_device_index(device), cross_kv_dtype=cross_kv_dtype)
+                                   max_batch=self.max_rows, device=_device_index(device), cross_kv_dtype=cross_kv_dtype)
                             for _ in range(max(1, int(contexts)))]
             for e in self.engines:
                 e.load_state_dict(self.bundle.weights)
@@ -241,6 +262,23 @@ class CrisperWhisperPipeline:
         if return_language:
             raise ValueError("return_language is not supported on the native path")
         gk = dict(generate_kwargs or {})
+        for unsupported in ("do_sample", "temperature", "num_return_sequences", "prompt_ids", "assistant_model"):
+            val = gk.get(unsupported)
+            if unsupported == "temperature" and isinstance(val, (tuple, list)):
+                # temperature fallback (generation_whisper.py:970-1116) only fires when a threshold is set
+                if any(gk.get(k_) is not None for k_ in ("compression_ratio_threshold", "logprob_threshold", "no_speech_threshold")):
+                    raise ValueError("temperature fallback with sampling is not implemented on the native path "
+                                     "(stochastic decoding cannot be made bit-comparable with torch's generator)")
+                val = val[0]
+            if val not in (None, False, 0, 0.0, 1, 1.0):
+                raise ValueError(f"generate_kwargs[{unsupported!r}]={gk[unsupported]!r} is not supported on the native path "
+                                 "(deterministic greedy / beam search only)")
+        if "num_beams" not in gk:
+            _warn_once("beams", f"no num_beams given: decoding with {self.default_num_beams} beams like the installed transformers "
+                                "ASR pipeline default; pass generate_kwargs={'num_beams': 1} for the greedy decoding of the 2024 reference")
+        num_beams = int(gk.get("num_beams", self.default_num_beams))
+        if gk.get("length_penalty") not in (None, 1.0) or gk.get("early_stopping") not in (None, False):
+            raise ValueError("only the default length_penalty=1.0 / early_stopping=False beam search is implemented")
         pcm = self._load(inputs)
         cl = self.chunk_length_s if chunk_length_s is None else chunk_length_s
         sl = self.stride_length_s if stride_length_s is None else stride_length_s
@@ -273,7 +311,7 @@ class CrisperWhisperPipeline:
             out = generation.generate(
                 eng, len(idxs), nf, language=gk.get("language"), task=gk.get("task"),
                 max_new_tokens=gk.get("max_new_tokens"), min_new_tokens=gk.get("min_new_tokens"),
-                num_beams=gk.get("num_beams", 1), stats=st)
+                num_beams=num_beams, stats=st)
             rs = []
             for k, i in enumerate(idxs):
                 n_tok = len(out["token_timestamps"][k])
@@ -281,7 +319,16 @@ class CrisperWhisperPipeline:
                 rs.append(dist.pack_record(i, out["sequences"][k][:n_tok], out["token_timestamps"][k], stride))
             return rs, st.get("generate_calls", 0)
 
-        batches = [(n, mine[b0:b0 + self.batch_size]) for n, b0 in enumerate(range(0, len(mine), self.batch_size))]
+        per = self.batch_size
+        if num_beams > 1:
+            if num_beams > self.max_rows:
+                raise ValueError(f"num_beams={num_beams} exceeds the {self.max_rows} decoder rows this pipeline was provisioned "
+                                 "with (constructor argument num_beams / batch_size)")
+            per = max(1, min(self.batch_size, self.max_rows // num_beams))
+            if per < self.batch_size:
+                _warn_once("rows", f"batch_size {self.batch_size} x {num_beams} beams exceeds {self.max_rows} decoder rows: "
+                                   f"generating {per} chunks at a time")
+        batches = [(n, mine[b0:b0 + per]) for n, b0 in enumerate(range(0, len(mine), per))]
         if len(self.engines) > 1 and len(batches) > 1:
             import concurrent.futures as cf
             # one worker per context; batch n always runs on context n % C, so a context is never re-entered

@@ -144,6 +144,24 @@ typedef struct {
 int32_t cw_transcribe(cw_ctx* ctx, int32_t B, const int32_t* num_frames, const cw_transcribe_cfg* cfg,
                       int32_t* tokens, float* token_ts, int32_t* lens, int32_t cap, int32_t* n_passes);
 
+/* ---- beam search (the transformers 5.x ASR pipeline defaults to num_beams = 5,
+ * TF/pipelines/automatic_speech_recognition.py:160-163): device half of GenerationMixin._beam_search
+ * (TF/generation/utils.py:3208-3520) over the encoded windows 0..n_items-1, items x beams decoder rows (row = item *
+ * num_beams + beam; the context must have been created with max_batch >= items x beams).
+ *   cw_beam_begin    prompt [n_items][n_prompt] replicated over the beams, prompt positions forwarded.
+ *   cw_beam_step     one decoder forward for every row + log_softmax + the logits processors (:3402-3403); per row the
+ *                    n_cand (<= 64) best processed log-probabilities and their tokens, best first (-inf / -1 padded).
+ *   cw_beam_advance  the caller chose, for every row, the row it descends from (same item) and its next token
+ *                    (:3125-3170, :3480-3486): token history, self-attention cache ancestry and decoder input follow.
+ *   cw_beam_finish   row_of_pos [n_items][L]: for every returned sequence and decoder input position, the row whose
+ *                    forward pass produced it (HF's unrolled `beam_indices`, generation_whisper.py:262-303): the
+ *                    alignment-head rows are gathered accordingly; cw_token_timestamps(n_items, L, ...) follows.   */
+int32_t cw_beam_begin(cw_ctx* ctx, int32_t n_items, int32_t num_beams, const int32_t* prompt, int32_t n_prompt,
+                      int32_t max_length, int32_t min_new_tokens);
+int32_t cw_beam_step(cw_ctx* ctx, int32_t n_cand, float* cand_logprob, int32_t* cand_token);
+int32_t cw_beam_advance(cw_ctx* ctx, const int32_t* parent, const int32_t* token);
+int32_t cw_beam_finish(cw_ctx* ctx, int32_t n_items, int32_t L, const int32_t* row_of_pos);
+
 /* cw_token_timestamps: _extract_token_timestamps (generation_whisper.py:241-381) on the retained rows:
  * crop to num_frames[b]//2 encoder frames, drop the n_prompt prompt rows, z-score over tokens, median
  * filter, head mean, DTW, jump times.  L = rows retained = max(lengths) - 1.  ts_out [nb][L+1] seconds. */

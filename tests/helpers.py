@@ -107,5 +107,44 @@ class OracleBackedEngine:
         assert self.weights.shape[2] == L
         return OT.extract_token_timestamps(self.weights, num_frames, n_prompt, self.g.median_filter_width)
 
+    # ---- beam search: same contract as Engine.beam_begin / beam_step / beam_advance / beam_finish
+    def beam_begin(self, prompt, num_beams, max_length, min_new_tokens=0):
+        from oracle import logits as OL
+        prompt = np.asarray(prompt, dtype=np.int64)
+        self._bk = int(num_beams)
+        self._b_ids = np.repeat(prompt, self._bk, axis=0)
+        self._b_nprompt = prompt.shape[1]
+        self._b_cache = self.model.new_cache(np.repeat(self.enc[:prompt.shape[0]], self._bk, axis=0))
+        self._b_pending = self._b_ids.copy()
+        self._b_weights = []
+        self._b_spec = OL.ProcessorSpec(eos=self.ospec.eos, no_timestamps=self.ospec.no_timestamps, suppress=self.ospec.suppress,
+                                        begin_suppress=self.ospec.begin_suppress,
+                                        max_initial_timestamp_index=self.ospec.max_initial_timestamp_index,
+                                        min_new_tokens=min_new_tokens)
+
+    def beam_step(self, n_cand):
+        from oracle import logits as OL
+        logits, cross = self.model.decode(self._b_pending, self._b_cache, want_heads=self.ospec.alignment_heads)
+        self._b_weights.append(cross)
+        with np.errstate(invalid="ignore"):
+            lp = OL.process(self._b_spec, self._b_ids, OL.log_softmax(logits), self._b_nprompt, self._b_nprompt)
+        order = np.lexsort((np.broadcast_to(np.arange(lp.shape[1]), lp.shape), -lp), axis=-1)[:, :n_cand]
+        vals = np.take_along_axis(lp, order, axis=1).astype(np.float32)
+        toks = np.where(np.isfinite(vals), order, -1).astype(np.int32)
+        return vals, toks
+
+    def beam_advance(self, parent, token):
+        parent = np.asarray(parent, dtype=np.int64)
+        for key in ("self_k", "self_v"):
+            self._b_cache[key] = [a[parent] for a in self._b_cache[key]]
+        self._b_ids = np.concatenate([self._b_ids[parent], np.asarray(token, dtype=np.int64)[:, None]], axis=1)
+        self._b_pending = self._b_ids[:, -1:]
+
+    def beam_finish(self, row_of_pos):
+        w = np.concatenate(self._b_weights, axis=2)                   # [rows, Ha, positions, S]
+        r = np.asarray(row_of_pos)
+        out = np.stack([np.stack([w[r[i, p], :, p, :] for p in range(r.shape[1])], axis=1) for i in range(r.shape[0])])
+        self.weights = out.astype(np.float32)
+
     def adjust_pauses(self, start, end, thr):
         raise AssertionError("pause splitting must run on the device in product code")

@@ -692,3 +692,49 @@ def test_bf16_engine_is_bit_reproducible_run_to_run():
     finally:
         for e in engs:
             e.close()
+
+
+@pytest.mark.parametrize("name", ["beam5_mixed40_b2_n24", "beam3_noise30_b1_n40", "beam2_chirp12_b1_min16", "beam5_noise50_b3_free",
+                                  "literal_reference_call_noise20"])
+def test_pipeline_beam_search_word_for_word_vs_reference(tiny, name):
+    """SURVEY 8(f).4 on the device: items x beams decoder rows, ancestry-indexed self-attention cache, per-row top-k of the
+    processed log-probabilities, beam-index gather of the alignment rows -- f32 engine through the drop-in pipeline call
+    against transformers run with 2 / 3 / 5 beams, and the LITERAL call of REF/transcribe.py:33 (no generate_kwargs: the
+    installed pipeline's 5 beams + language detection): identical text and words, timestamps within one frame."""
+    g, v, W, spec = tiny
+    meta = Hh.gold_json("e2e_beam_golden.json")[name]
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
+    pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30,
+                       batch_size=meta["batch_size"], return_timestamps="word", torch_dtype="float32", device="cuda:0")
+    try:
+        out = pipe(x, generate_kwargs=dict(meta["generate_kwargs"])) if meta["generate_kwargs"] else pipe(x)
+        assert out["text"] == meta["text"]
+        ok, why = Hh.words_equal(out["chunks"], meta["chunks"], tol=0.02)
+        assert ok, why
+    finally:
+        pipe.engine.close()
+
+
+def test_beam_search_bf16_engine_many_rows_tracks_f32_engine(tiny):
+    """bf16 engine, 4 chunks x 5 beams = 20 decoder rows (the 17..64-row GEMV path + ancestry attention + the key-split
+    cross-attention shared per item): runs, is well formed, and its first generate call picks the f32 engine's hypotheses
+    on most rows (random-weight logits are full of near ties, so this is a sanity bound, not a parity claim)."""
+    g, v, W, spec = tiny
+    x = syn.synth_audio(77, 70 * 16000, "mixed")
+    outs = {}
+    for dt in ("float32", "bfloat16"):
+        pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
+                           tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30, batch_size=4,
+                           return_timestamps="word", torch_dtype=dt, device="cuda:0")
+        try:
+            outs[dt] = pipe(x, generate_kwargs={**Hh.GEN_KW, "num_beams": 5, "max_new_tokens": 12})
+        finally:
+            pipe.engine.close()
+    a, b = outs["float32"], outs["bfloat16"]
+    assert isinstance(b["text"], str) and len(b["chunks"]) > 0
+    assert "".join(c["text"] for c in b["chunks"]) == b["text"]
+    for c in b["chunks"]:
+        assert np.isfinite(c["timestamp"][0]) and c["timestamp"][1] >= c["timestamp"][0]
+    same = sum(1 for p_, q_ in zip(a["chunks"], b["chunks"]) if p_["text"] == q_["text"])
+    assert same >= 0.5 * len(a["chunks"]), (same, len(a["chunks"]))

@@ -316,3 +316,41 @@ def test_reference_cpu_leg_of_bench_runs_the_real_pipeline():
     assert r["cores"] == 2 and "transformers.pipeline" in r["sample"]
     slow = bench.cpu_reference("tiny", 8, 2, 1)
     assert slow["value"] is None and "did not finish" in slow["sample"]
+
+
+BEAM_SCENARIOS = ["beam5_mixed40_b2_n24", "beam3_noise30_b1_n40", "beam2_chirp12_b1_min16", "beam5_noise50_b3_free",
+                  "literal_reference_call_noise20"]
+
+
+@pytest.mark.parametrize("name", BEAM_SCENARIOS)
+def test_beam_search_host_half_word_for_word_vs_transformers(name):
+    """`generation.beam_search` (numpy port of GenerationMixin._beam_search's hypothesis bookkeeping) +
+    the seek loop + beam-index gathering of the alignment rows, over the oracle-backed engine, against the transformers
+    pipeline run with num_beams = 2 / 3 / 5 -- and against the LITERAL reference call (no generate_kwargs: 5 beams,
+    detected language): identical sequences, token timestamps, text and words."""
+    g, v, W, spec = Hh.tiny_setup()
+    meta = Hh.gold_json("e2e_beam_golden.json")[name]
+    z = Hh.gold_npz("e2e_beam_golden.npz")
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
+    eng = Hh.OracleBackedEngine(g, v, W, spec)
+    vocab = collate.Vocabulary.from_synthetic(v)
+    windows = audio.chunk_windows(len(x), 480000, 80000, 80000)
+    gk = meta["generate_kwargs"]
+    outputs, call = [], 0
+    for b0 in range(0, len(windows), meta["batch_size"]):
+        batch = windows[b0:b0 + meta["batch_size"]]
+        _, nf = eng.mel([x[s:s + n] for s, n, _, _ in batch])
+        out = generation.generate(eng, len(batch), nf, language=gk.get("language"), task=gk.get("task"),
+                                  max_new_tokens=gk.get("max_new_tokens"), min_new_tokens=gk.get("min_new_tokens"),
+                                  num_beams=gk.get("num_beams", 5))            # 5 = the installed pipeline's default
+        assert np.array_equal(out["sequences"], z[f"{name}/call{call}/sequences"])
+        for k, (_, _, st, _) in enumerate(batch):
+            assert np.allclose(out["token_timestamps"][k], z[f"{name}/call{call}/tts{k}"], atol=1e-6)
+            n = len(out["token_timestamps"][k])
+            outputs.append({"tokens": out["sequences"][k][:n], "token_timestamps": out["token_timestamps"][k],
+                            "stride": tuple(t / 16000 for t in st)})
+        call += 1
+    text, words = collate.decode_asr(vocab, outputs)
+    assert text == meta["text"]
+    ok, why = Hh.words_equal(words, meta["chunks"])
+    assert ok, why
