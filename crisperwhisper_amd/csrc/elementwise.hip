@@ -146,6 +146,78 @@ __device__ inline ArgPair wave_argmax(ArgPair a) {   // same DPP scan as wave_su
     return r;
 }
 
+// Stage 1 of the sampler: the vocabulary is cut into SAMPLE_NS slices, one block each (a single 1024-thread block per
+// row took 21 us of every decode step for 200 KB of logits: 8 blocks on a 256-CU chip).  Per slice: best allowed text
+// token, best allowed timestamp token, and sum over allowed timestamps of exp(s - slice max); stage 2 (sample_kernel)
+// merges the SAMPLE_NS records of its row.
+#define SAMPLE_NS 16
+struct SamplePart { float bt_v; int bt_i; float bs_v; int bs_i; float ts_sum; float pad[3]; };
+__global__ __launch_bounds__(256) void sample_partial_kernel(SampleParams p, SamplePart* __restrict__ part) {
+    __shared__ float s_f[64];
+    __shared__ int s_i[64];
+    const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* lg = p.logits + (size_t)b * p.ldv;
+    const int* ids = p.ids + (size_t)b * p.ids_stride;
+    const int n_prompt = p.cfg[0], min_new_tokens = p.cfg[1];
+    const int t = p.pos[b] + 1, tb = p.timestamp_begin;
+    const int n_gen = t - n_prompt;
+    const bool last_ts = n_gen >= 1 && ids[t - 1] >= tb;
+    const bool penult_ts = n_gen < 2 || ids[t - 2] >= tb;
+    const int last_tok = p.last_ts_tok[b];
+    const int ts_floor = (last_tok >= 0) ? ((last_ts && !penult_ts) ? last_tok : last_tok + 1) : tb;
+    const bool at_begin = (n_gen == 0);
+    const int ts_cap = (at_begin && p.max_initial_timestamp_index >= 0) ? tb + p.max_initial_timestamp_index : 0x7fffffff;
+    const int per4 = ((p.ldv >> 2) + SAMPLE_NS - 1) / SAMPLE_NS;           // float4 groups per slice
+    const int lo4 = sl * per4, hi4 = min(p.ldv >> 2, lo4 + per4);
+    const float4* lg4 = (const float4*)lg;
+    const uchar4* mk4 = (const uchar4*)p.mask;
+    ArgPair bt = {-INFINITY, 0x7fffffff}, bs = {-INFINITY, 0x7fffffff};
+    float sv[4][4]; int nmine = 0;                                         // this thread's allowed timestamp scores
+    for (int i4 = lo4 + tid, it = 0; i4 < hi4; i4 += 256, ++it) {
+        const float4 x = lg4[i4]; const uchar4 mk = mk4[i4];
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+        const unsigned char ms[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v = i4 * 4 + j;
+            float val = -INFINITY;
+            if (v < p.V) {
+                bool dead = (ms[j] & 1) || (at_begin && (ms[j] & 2));
+                dead |= (v == p.eos && n_gen < min_new_tokens);
+                if (last_ts) dead |= penult_ts ? (v >= tb) : (v < p.eos);
+                dead |= (v >= tb && v < ts_floor);
+                if (at_begin) dead |= (v < tb) || (v > ts_cap);
+                if (!dead) val = xs[j];
+                ArgPair c = {val, v};
+                if (v < tb) bt = arg_better(bt, c); else bs = arg_better(bs, c);
+            }
+            if (it < 4) sv[it][j] = (v >= tb && v < p.V) ? val : -INFINITY;
+        }
+        nmine = it + 1;
+    }
+    bt = wave_argmax(bt);
+    bs = wave_argmax(bs);
+    if (lane == 0) { s_f[wave] = bt.v; s_i[wave] = bt.i; s_f[32 + wave] = bs.v; s_i[32 + wave] = bs.i; }
+    __syncthreads();
+    bt = {-INFINITY, 0x7fffffff}; bs = {-INFINITY, 0x7fffffff};
+    for (int w = 0; w < 4; ++w) {
+        bt = arg_better(bt, ArgPair{s_f[w], s_i[w]});
+        bs = arg_better(bs, ArgPair{s_f[32 + w], s_i[32 + w]});
+    }
+    float acc = 0.f;
+    if (bs.v > -INFINITY) {
+        for (int it = 0; it < nmine && it < 4; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (sv[it][j] > -INFINITY) acc += expf(sv[it][j] - bs.v);
+    }
+    __syncthreads();
+    acc = block_sum(acc, s_f);
+    if (tid == 0) {
+        SamplePart o; o.bt_v = bt.v; o.bt_i = bt.i; o.bs_v = bs.v; o.bs_i = bs.i; o.ts_sum = acc; o.pad[0] = o.pad[1] = o.pad[2] = 0.f;
+        part[(size_t)b * SAMPLE_NS + sl] = o;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
     __shared__ float s_f[64];
@@ -169,72 +241,17 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
     const bool at_begin = (n_gen == 0);
     const int ts_cap = (at_begin && p.max_initial_timestamp_index >= 0) ? tb + p.max_initial_timestamp_index
                                                                          : 0x7fffffff;
-    auto score = [&](int v) -> float {
-        unsigned char mk = p.mask[v];
-        bool dead = (mk & 1) || (at_begin && (mk & 2));
-        dead |= (v == p.eos && n_gen < min_new_tokens);
-        if (last_ts) dead |= penult_ts ? (v >= tb) : (v < p.eos);
-        dead |= (v >= tb && v < ts_floor);
-        if (at_begin) dead |= (v < tb) || (v > ts_cap);
-        return dead ? -INFINITY : lg[v];
-    };
-
-    // pass 1: best text token, best timestamp token -- 4 logits + 4 mask bytes per load, all loads of the
-    // thread issued before use (rows are 16-byte aligned: ldv % 4 == 0)
+    // stage 2: merge the SAMPLE_NS slice records of this row (sample_partial_kernel)
     ArgPair bt = {-INFINITY, 0x7fffffff}, bs = {-INFINITY, 0x7fffffff};
-    {
-        const float4* lg4 = (const float4*)lg;
-        const uchar4* mk4 = (const uchar4*)p.mask;
-        const int n4 = p.ldv >> 2;
-        for (int v4 = tid; v4 < n4; v4 += 4 * (int)blockDim.x) {
-            float4 x[4]; uchar4 mk[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i4 = min(v4 + u * (int)blockDim.x, n4 - 1);
-                x[u] = lg4[i4]; mk[u] = mk4[i4];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i4 = v4 + u * (int)blockDim.x;
-                if (i4 < n4) {
-                    const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
-                    const unsigned char ms[4] = {mk[u].x, mk[u].y, mk[u].z, mk[u].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int v = i4 * 4 + j;
-                        if (v < p.V) {
-                            bool dead = (ms[j] & 1) || (at_begin && (ms[j] & 2));
-                            dead |= (v == p.eos && n_gen < min_new_tokens);
-                            if (last_ts) dead |= penult_ts ? (v >= tb) : (v < p.eos);
-                            dead |= (v >= tb && v < ts_floor);
-                            if (at_begin) dead |= (v < tb) || (v > ts_cap);
-                            ArgPair c = {dead ? -INFINITY : xs[j], v};
-                            if (v < tb) bt = arg_better(bt, c); else bs = arg_better(bs, c);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    bt = wave_argmax(bt);
-    bs = wave_argmax(bs);
-    __syncthreads();
-    if (lane == 0) { s_f[wave] = bt.v; s_i[wave] = bt.i; s_f[32 + wave] = bs.v; s_i[32 + wave] = bs.i; }
-    __syncthreads();
-    bt = {-INFINITY, 0x7fffffff}; bs = {-INFINITY, 0x7fffffff};
-    for (int w = 0; w < nw; ++w) {
-        bt = arg_better(bt, ArgPair{s_f[w], s_i[w]});
-        bs = arg_better(bs, ArgPair{s_f[32 + w], s_i[32 + w]});
+    const SamplePart* pr = p.partials + (size_t)b * SAMPLE_NS;
+    for (int i = 0; i < SAMPLE_NS; ++i) {
+        bt = arg_better(bt, ArgPair{pr[i].bt_v, pr[i].bt_i});
+        bs = arg_better(bs, ArgPair{pr[i].bs_v, pr[i].bs_i});
     }
     const float M = fmaxf(bt.v, bs.v);
-
-    // pass 2: sum over timestamp tokens of exp(s - M)
-    float acc = 0.f;
-    for (int v = tb + tid; v < p.V; v += blockDim.x) {
-        float s = score(v);
-        if (s > -INFINITY) acc += expf(s - M);
-    }
-    acc = block_sum(acc, s_f);
+    float acc = 0.f;                                   // sum over allowed timestamps of exp(s - M)
+    for (int i = 0; i < SAMPLE_NS; ++i)
+        if (pr[i].bs_v > -INFINITY) acc += pr[i].ts_sum * expf(pr[i].bs_v - M);
 
     if (tid == 0) {
         bool force_ts = (acc > 0.f) && (logf(acc) > bt.v - M);
@@ -420,10 +437,12 @@ int cw_launch_align_gather(const float* align, const int* row_of_pos, int n_item
 }
 
 int cw_launch_sample(const SampleParams& p, hipStream_t st) {
+    if (!p.partials || (p.ldv >> 2) > SAMPLE_NS * 1024 || (p.ldv & 3)) return CW_ERR_INVALID;
     hipMemsetAsync(p.n_unfinished, 0, sizeof(int), st);
+    hipLaunchKernelGGL(sample_partial_kernel, dim3(p.B, SAMPLE_NS), dim3(256), 0, st, p, (SamplePart*)p.partials);
     if (p.embed_bf16)
-        hipLaunchKernelGGL((sample_kernel<bf16_t>), dim3(p.B), dim3(1024), 0, st, p);
+        hipLaunchKernelGGL((sample_kernel<bf16_t>), dim3(p.B), dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL((sample_kernel<float>), dim3(p.B), dim3(1024), 0, st, p);
+        hipLaunchKernelGGL((sample_kernel<float>), dim3(p.B), dim3(256), 0, st, p);
     return CW_OK;
 }

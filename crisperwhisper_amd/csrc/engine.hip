@@ -42,6 +42,12 @@ struct cw_ctx {
     char err[512] = "";
     bool err_set = false;      // a specific message is pending (set by fail(), cleared by cw_last_error)
     std::vector<int> align_layers, align_heads;
+    // bf16 decode engine: projections fed by a LayerNorm keep their f32 checkpoint values on the device until every
+    // tensor is in, then the LayerNorm's gamma / beta are folded into them (gemm.hip: fold_layernorm_kernel)
+    struct Fold { float* stage; int N, K; void* w_dst; size_t w_off; float* b_dst; size_t b_off; float scale; int layer, which; };
+    std::vector<Fold> folds;
+    bool ln_folded = false;         // decoder LN-GEMVs run plain normalisation (affine part is inside W / bias)
+    bool fold_enabled = true;       // CW_NO_LN_FOLD=1: keep gamma / beta in the kernels
     std::set<std::string> loaded;   // HF tensor names received through cw_load_tensor
     bool weights_ok = false;        // every tensor of the geometry has been loaded (checked once, see cw_check_weights)
 
@@ -71,6 +77,7 @@ struct cw_ctx {
     int *d_ids = nullptr, *d_forced = nullptr, *d_argmax = nullptr, *d_last_ts = nullptr, *d_finished = nullptr,
         *d_nunf = nullptr, *d_align_slot = nullptr;
     unsigned char* d_mask = nullptr;
+    void* d_sample_part = nullptr;            // [Bm][16] 32-byte slice records of the two-stage sampler
     float* d_align = nullptr;
     float *d_part_o = nullptr, *d_part_ml = nullptr, *d_align_ml = nullptr;   // split cross-attention partials
     bool align_unnormalized = false;
@@ -227,6 +234,7 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
     c->bf16 = d.dtype == CW_DTYPE_BF16;
     if (getenv("CW_NO_GRAPH")) c->use_graph = false;
+    if (getenv("CW_NO_LN_FOLD")) c->fold_enabled = false;
     c->esz = c->bf16 ? 2 : 4;
     c->Bm = Bm;
     c->S_pad = 1536;
@@ -347,6 +355,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_nunf, 4));
     CWCHK(c, dmalloc(c, &c->d_pos, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_cfg, 4 * 4));
     CWCHK(c, dmalloc(c, &c->d_mask, (size_t)V + 16));
+    CWCHK(c, dmalloc(c, &c->d_sample_part, (size_t)Bm * 16 * 32));
     CWCHK(c, dmalloc(c, &c->d_align_slot, (size_t)d.dec_layers * H * 4));
     {
         std::vector<int> slot((size_t)d.dec_layers * H, -1);
@@ -400,6 +409,7 @@ void cw_destroy(cw_ctx* c) {
     hipSetDevice(c->device);
     if (c->st) hipStreamSynchronize(c->st);
     for (auto& ge : c->step_graph) if (ge) hipGraphExecDestroy(ge);
+    for (auto& f : c->folds) hipFree(f.stage);
     for (void* p : c->allocs) hipFree(p);
     if (c->h_nunf) hipHostFree(c->h_nunf);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -413,6 +423,7 @@ void cw_destroy(cw_ctx* c) {
 // weights
 // ------------------------------------------------------------------------------------------------
 static int load_tensor_impl(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+static int apply_folds(cw_ctx* c);
 
 int32_t cw_load_tensor(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
     if (!name || !data || !shape) return fail(c, CW_ERR_INVALID, "cw_load_tensor: null argument");
@@ -449,7 +460,32 @@ int32_t cw_check_weights(cw_ctx* c) {
     for (const auto& w : want)
         if (!c->loaded.count(w)) { if (n_missing < 4) missing += (n_missing ? ", " : "") + w; ++n_missing; }
     if (n_missing) return fail(c, CW_ERR_STATE, "%d of %zu weight tensors were never loaded (e.g. %s): incomplete checkpoint", n_missing, want.size(), missing.c_str());
+    CWCHK(c, apply_folds(c));
     c->weights_ok = true;
+    return CW_OK;
+}
+
+// which: 0 = self-attention LN (q/k/v), 1 = cross-attention LN (q), 2 = final LN (fc1)
+static int stage_fold(cw_ctx* c, int layer, int which, const float* data, int N, int K, void* w_dst, size_t w_off, float* b_dst,
+                      size_t b_off, float scale) {
+    cw_ctx::Fold f{nullptr, N, K, w_dst, w_off, b_dst, b_off, scale, layer, which};
+    HIPCHK(c, hipMalloc((void**)&f.stage, (size_t)N * K * 4));
+    HIPCHK(c, hipMemcpy(f.stage, data, (size_t)N * K * 4, hipMemcpyHostToDevice));
+    c->folds.push_back(f);
+    return CW_OK;
+}
+
+static int apply_folds(cw_ctx* c) {
+    for (auto& f : c->folds) {
+        LayerW& L = c->dec[f.layer];
+        const float* g = f.which == 0 ? L.ln1_g : (f.which == 1 ? L.lnc_g : L.ln2_g);
+        const float* b = f.which == 0 ? L.ln1_b : (f.which == 1 ? L.lnc_b : L.ln2_b);
+        CWCHK(c, cw_launch_fold_layernorm(f.stage, f.N, f.K, g, b, f.scale, (bf16_t*)f.w_dst + f.w_off, f.b_dst + f.b_off, c->st));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    for (auto& f : c->folds) hipFree(f.stage);
+    if (!c->folds.empty()) c->ln_folded = true;
+    c->folds.clear();
     return CW_OK;
 }
 
@@ -493,6 +529,14 @@ static int load_tensor_impl(cw_ctx* c, const char* name, const float* data, cons
     std::string r(rest);
     const float qs = 0.125f;  // head_dim ** -0.5, folded into q projections (exact: power of two)
     const size_t DD = (size_t)D * D;
+    if (is_dec && c->bf16 && c->fold_enabled) {   // LayerNorm-fed decode projections: folded once all tensors are in
+        if (c->ln_folded) return fail(c, CW_ERR_STATE, "weights were already folded: create a new context to load another checkpoint");
+        if (r == "self_attn.q_proj.weight") { CWCHK(c, expect(DD)); return stage_fold(c, li, 0, data, D, D, L.wqkv, 0, L.bqkv, 0, qs); }
+        if (r == "self_attn.k_proj.weight") { CWCHK(c, expect(DD)); return stage_fold(c, li, 0, data, D, D, L.wqkv, DD, L.bqkv, (size_t)D, 1.f); }
+        if (r == "self_attn.v_proj.weight") { CWCHK(c, expect(DD)); return stage_fold(c, li, 0, data, D, D, L.wqkv, 2 * DD, L.bqkv, 2 * (size_t)D, 1.f); }
+        if (r == "encoder_attn.q_proj.weight") { CWCHK(c, expect(DD)); return stage_fold(c, li, 1, data, D, D, L.wq_c, 0, L.bq_c, 0, qs); }
+        if (r == "fc1.weight") { CWCHK(c, expect((size_t)F * D)); return stage_fold(c, li, 2, data, F, D, L.w1, 0, L.b1, 0, 1.f); }
+    }
     if (r == "self_attn.q_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wqkv, 0, data, n, qs); }
     if (r == "self_attn.k_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wqkv, DD, data, n); }
     if (r == "self_attn.v_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wqkv, 2 * DD, data, n); }
@@ -710,7 +754,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
             EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
             ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
-            CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, L.ln1_b, ep));
+            CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep));
         }
         {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
@@ -725,7 +769,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         }
         {   // cross-attention: LN + q projection, attention over the cached encoder K/V
             EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
-            CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, L.lnc_b, ep));
+            CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep));
         }
         if (c->bf16) {
             // keys split over ATT_NS blocks per (row, head); the out-projection GEMV combines the partials
@@ -751,7 +795,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
-            CWCHK(c, gemv_ln(c, frag ? EPI_GELU_FRAG : EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep));
+            CWCHK(c, gemv_ln(c, frag ? EPI_GELU_FRAG : EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, c->ln_folded ? nullptr : L.ln2_b, ep));
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.b2; ep.ldo = D;
@@ -778,6 +822,7 @@ static int launch_sample(cw_ctx* c, int nb, bool forced) {
     sp.argmax_trace = c->d_argmax; sp.last_ts_tok = c->d_last_ts; sp.finished = c->d_finished;
     sp.n_unfinished = c->d_nunf;
     sp.embed = c->embed; sp.pos_embed = c->dec_pos; sp.x_out = c->dx; sp.d = c->d.d_model; sp.embed_bf16 = c->bf16 ? 1 : 0;
+    sp.partials = (const SamplePart*)c->d_sample_part;
     (void)forced;
     return cw_launch_sample(sp, c->st);
 }
@@ -1541,7 +1586,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
         switch (which) {
             case 0: {   // fc1: LN + GEMV + GELU
                 EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
-                return gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, L.ln2_b, ep);
+                return gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, c->ln_folded ? nullptr : L.ln2_b, ep);
             }
             case 1: {   // cross-attention
                 if (c->bf16) {
@@ -1560,11 +1605,11 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
             case 3: {   // LN + qkv + cache append
                 EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
                 ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
-                return gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, L.ln1_b, ep);
+                return gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep);
             }
             case 4: {   // LN + cross q
                 EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
-                return gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, L.lnc_b, ep);
+                return gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep);
             }
             case 5: {   // fc2
                 EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.b2; ep.ldo = D;

@@ -543,12 +543,16 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const float* __restrict_
                 v = *(const float4*)(x + (size_t)m * K + kc0 + k4);
                 if (ln_g) {
                     float mean = stats[2 * m], rstd = stats[2 * m + 1];
-                    const float4 gg = *(const float4*)(ln_g + kc0 + k4);
-                    const float4 bb = *(const float4*)(ln_b + kc0 + k4);
-                    v.x = (v.x - mean) * rstd * gg.x + bb.x;
-                    v.y = (v.y - mean) * rstd * gg.y + bb.y;
-                    v.z = (v.z - mean) * rstd * gg.z + bb.z;
-                    v.w = (v.w - mean) * rstd * gg.w + bb.w;
+                    if (ln_b) {
+                        const float4 gg = *(const float4*)(ln_g + kc0 + k4);
+                        const float4 bb = *(const float4*)(ln_b + kc0 + k4);
+                        v.x = (v.x - mean) * rstd * gg.x + bb.x;
+                        v.y = (v.y - mean) * rstd * gg.y + bb.y;
+                        v.z = (v.z - mean) * rstd * gg.z + bb.z;
+                        v.w = (v.w - mean) * rstd * gg.w + bb.w;
+                    } else {   // affine part folded into the weights (engine.hip: fold_layernorm)
+                        v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+                    }
                 }
             }
             ushort4 o;
@@ -665,6 +669,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     for (int t = 0; t < NT; ++t) { nn[t] = n0 + t * 16 + l15; ncl[t] = nn[t] < N ? nn[t] : N - 1; }
     const int nvec = Kb >> 2;                                 // float4 per row slice
     const bool has_ln = ln_g != nullptr;
+    const bool ln_affine = ln_b != nullptr;                   // false: gamma / beta were folded into W / bias at load time
 
     PH(0);                                                    // kernel entry
     float bias_v[NT];
@@ -714,7 +719,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     }
     // LayerNorm parameters (a valid dummy pointer is passed when there is no LayerNorm; loads are cheap)
     float4 gv[PER_LANE], bv[PER_LANE];
-    if (has_ln) {   // kernel-uniform: the whole block of loads is either issued or not
+    if (has_ln && ln_affine) {   // kernel-uniform: the whole block of loads is either issued or not
 #pragma unroll
         for (int c = 0; c < PER_LANE; ++c) {
             int v4 = lane + 64 * c;
@@ -757,12 +762,20 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
                 q += ok * ((a * a + b * b) + (cc * cc + d * d));
             }
             const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+            if (ln_affine) {
 #pragma unroll
-            for (int c = 0; c < PER_LANE; ++c) {
-                xv[i][c].x = (xv[i][c].x - mean) * rstd * gv[c].x + bv[c].x;
-                xv[i][c].y = (xv[i][c].y - mean) * rstd * gv[c].y + bv[c].y;
-                xv[i][c].z = (xv[i][c].z - mean) * rstd * gv[c].z + bv[c].z;
-                xv[i][c].w = (xv[i][c].w - mean) * rstd * gv[c].w + bv[c].w;
+                for (int c = 0; c < PER_LANE; ++c) {
+                    xv[i][c].x = (xv[i][c].x - mean) * rstd * gv[c].x + bv[c].x;
+                    xv[i][c].y = (xv[i][c].y - mean) * rstd * gv[c].y + bv[c].y;
+                    xv[i][c].z = (xv[i][c].z - mean) * rstd * gv[c].z + bv[c].z;
+                    xv[i][c].w = (xv[i][c].w - mean) * rstd * gv[c].w + bv[c].w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < PER_LANE; ++c) {
+                    xv[i][c].x = (xv[i][c].x - mean) * rstd; xv[i][c].y = (xv[i][c].y - mean) * rstd;
+                    xv[i][c].z = (xv[i][c].z - mean) * rstd; xv[i][c].w = (xv[i][c].w - mean) * rstd;
+                }
             }
         }
     }
@@ -880,7 +893,8 @@ __global__ __launch_bounds__(256) void gemv_prep_kernel(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
             const int v4 = min(tid + 256 * c, nvec - 1);
-            gq[c] = *(const float4*)(ln_g + v4 * 4); bq[c] = *(const float4*)(ln_b + v4 * 4);
+            if (ln_b) { gq[c] = *(const float4*)(ln_g + v4 * 4); bq[c] = *(const float4*)(ln_b + v4 * 4); }
+            else { gq[c] = make_float4(1.f, 1.f, 1.f, 1.f); bq[c] = make_float4(0.f, 0.f, 0.f, 0.f); }   // folded affine part
         }
         float s = 0.f;
 #pragma unroll
@@ -1238,4 +1252,38 @@ int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void
         case EPI_QKV_CACHE: return launch_gemv_epi<EPI_QKV_CACHE>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
         default: return CW_ERR_INVALID;
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm affine folding (bf16 decode engine): a projection fed by LN(x) = n(x) * g + beta is rewritten as
+//     W LN(x) + b = (W diag(g)) n(x) + (b + W beta)
+// once, at weight-load time, from the f32 checkpoint values (single bf16 rounding of W diag(g)), so the decode GEMVs
+// neither fetch the LayerNorm parameters nor apply them (measured 0.3-0.56 us per launch on a 5-7 us latency chain).
+// One wave per output row: w_out[n][:] = bf16(scale * W[n][:] * g[:]),  bias[n] += scale * sum_k W[n][k] beta[k].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ Wf, int N, int K,
+                                                             const float* __restrict__ g, const float* __restrict__ beta,
+                                                             float scale, bf16_t* __restrict__ w_out,
+                                                             float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* wr = Wf + (size_t)n * K;
+    float dot = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 w = *(const float4*)(wr + k), gg = *(const float4*)(g + k), bb = *(const float4*)(beta + k);
+        dot += (w.x * bb.x + w.y * bb.y) + (w.z * bb.z + w.w * bb.w);
+        ushort4 o;
+        o.x = f32_to_bf16(scale * w.x * gg.x); o.y = f32_to_bf16(scale * w.y * gg.y);
+        o.z = f32_to_bf16(scale * w.z * gg.z); o.w = f32_to_bf16(scale * w.w * gg.w);
+        *(ushort4*)(w_out + (size_t)n * K + k) = o;
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) bias[n] += scale * dot;
+}
+int cw_launch_fold_layernorm(const float* Wf, int N, int K, const float* g, const float* beta, float scale, void* w_out,
+                             float* bias, hipStream_t st) {
+    if (K % 4) return CW_ERR_INVALID;
+    hipLaunchKernelGGL(fold_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Wf, N, K, g, beta, scale, (bf16_t*)w_out, bias);
+    return CW_OK;
 }

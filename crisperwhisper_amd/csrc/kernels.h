@@ -16,6 +16,9 @@ int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, 
                    hipStream_t st);
 void cw_gemm_set_256_min_tiles(int n);   // test hook: tile count from which the 256x256 GEMM is used (default 200)
 struct CombineParams;
+// ln_g != null, ln_b == null: plain normalisation (x - mean) * rstd -- the affine part lives in W / bias (fold_layernorm)
+int cw_launch_fold_layernorm(const float* Wf, int N, int K, const float* g, const float* beta, float scale, void* w_out,
+                             float* bias, hipStream_t st);
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
                    const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr,
                    void* scratch = nullptr /* bf16 [64][5120]: enables the one-pass path for 17..64 rows */);
@@ -46,6 +49,7 @@ struct SampleParams {
     float* x_out;              // [B][d] f32
     int d;
     int embed_bf16;
+    const struct SamplePart* partials;   // [B][SAMPLE_NS] slice records (32 bytes each), written by stage 1 of the sampler
 };
 int cw_launch_sample(const SampleParams& p, hipStream_t st);
 // beam search (elementwise.hip): per row the n_cand best processed log-probabilities of the next token
