@@ -293,7 +293,12 @@ def main():
                     for wa, wb in zip(mine["chunks"], gc_["chunks"]):
                         w_tot += 1
                         w_ok += int(wa["text"] == wb["text"] and all(abs(x - y) <= 0.02 + 1e-9 for x, y in zip(wa["timestamp"], wb["timestamp"])))
-            parity = {"against": "tests/golden/e2e_bench_golden.json (transformers 5.15.0 pipeline, CPU fp32, same clips / weights / token count)",
+            # BASELINE configs[5] harness (timestamp F1 / IoU at a 0.2 s collar vs the reference) on the same pairs
+            from crisperwhisper_amd import metrics
+            f1s = [metrics.boundary_f1(gold["clips"][k]["chunks"], last_raw[k]["chunks"], 0.2)[2] for k in range(n) if k in last_raw]
+            ious = [metrics.mean_iou(gold["clips"][k]["chunks"], last_raw[k]["chunks"]) for k in range(n) if k in last_raw]
+            parity = {"timestamp_f1_collar_0.2s": float(np.mean(f1s)) if f1s else None, "mean_word_iou": float(np.mean(ious)) if ious else None,
+                      "against": "tests/golden/e2e_bench_golden.json (transformers 5.15.0 pipeline, CPU fp32, same clips / weights / token count)",
                       "mode": "free-running greedy, the timed path itself", "clips_with_identical_text": [same_text, n],
                       "words_identical_and_within_20ms": [w_ok, w_tot]}
 

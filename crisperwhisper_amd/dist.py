@@ -8,7 +8,7 @@ from typing import List, Optional
 
 import numpy as np
 
-REC_TOKENS = 448
+REC_TOKENS = 4 * 448        # a 30 s chunk is usually one generate pass (<= 445 tokens); the seek loop can add more
 REC_WORDS = 6 + 2 * REC_TOKENS   # chunk_idx, n_tok, n_ts, stride(3 x f32 bits), tokens, ts bits
 
 
@@ -27,7 +27,7 @@ def pack_record(idx: int, tokens: np.ndarray, ts: np.ndarray, stride) -> np.ndar
     rec = np.zeros(REC_WORDS, dtype=np.int32)
     nt, ns = len(tokens), len(ts)
     if nt > REC_TOKENS or ns > REC_TOKENS:
-        raise ValueError("chunk output exceeds max_target_positions")
+        raise ValueError(f"chunk output of {max(nt, ns)} tokens exceeds the record capacity ({REC_TOKENS})")
     rec[0], rec[1], rec[2] = idx, nt, ns
     rec[3:6] = np.asarray(stride, dtype=np.float32).view(np.int32)
     rec[6:6 + nt] = tokens

@@ -76,6 +76,10 @@ def calibrate_threads(d_model: int, ffn: int, candidates=(2, 4, 8, 16, 32, 64, 1
     import torch
     ncpu = os.cpu_count() or 1
     cands = [c for c in candidates if c <= ncpu] or [1]
+    # an M = 1 decoder forward is ~40 small ops per layer (LayerNorm, softmax over [heads, 1500], residual adds) around its
+    # GEMVs; their fork/join cost grows with the team size, which a GEMV-only probe does not see (measured on a 2 x 64-core
+    # EPYC: 8 threads 0.115 s / forward, 32 threads 0.23 s) -- so the probe chains those ops in and stops at 16 threads
+    dec_cands = [c for c in cands if c <= 16] or cands[:1]
     a = torch.randn(1500, d_model)
     ws = [torch.randn(ffn, d_model) for _ in range(16)]
     ln = torch.nn.LayerNorm(d_model)
@@ -83,7 +87,7 @@ def calibrate_threads(d_model: int, ffn: int, candidates=(2, 4, 8, 16, 32, 64, 1
     with torch.no_grad():
         for kind in ("gemm", "gemv"):
             res = []
-            for c in cands:
+            for c in (cands if kind == "gemm" else dec_cands):
                 torch.set_num_threads(c)
                 dt = None
                 for rep in range(2):                       # first repetition warms the thread team up
@@ -92,9 +96,12 @@ def calibrate_threads(d_model: int, ffn: int, candidates=(2, 4, 8, 16, 32, 64, 1
                         torch.nn.functional.gelu(a @ ws[0].t())
                     else:
                         x = torch.randn(1, d_model)
+                        att = torch.randn(20, 1, 1500)
                         for w in ws:
                             h = torch.nn.functional.gelu(ln(x) @ w.t())
                             x = x + (h @ w) * 1e-3
+                            p_ = torch.softmax(att + x[0, 0], dim=-1)
+                            x = ln(x + p_.sum() * 1e-6)
                     dt = time.perf_counter() - t0
                 res.append((dt, c))
                 if len(res) >= 2 and dt > 3 * min(r[0] for r in res):     # past the knee: stop before the pathological counts

@@ -553,6 +553,15 @@ def test_bench_shape_bf16_timestamps_and_words_vs_transformers():
                     tot_words += 1
                     same_words += int(all(abs(x - y) <= 0.02 + 1e-9 for x, y in zip(a["timestamp"], b["timestamp"])))
         print(f"bench-shape bf16 FREE-RUNNING: {same_text}/{B} clips reproduce the reference text, {same_words}/{tot_words} of their words within 0.02 s")
+        # BASELINE configs[5] harness (crisperwhisper_amd/metrics.py) on real pipeline output: boundary F1 at the 0.2 s collar and
+        # mean word IoU of the free-running bf16 transcript against the reference transcript of clip 0
+        from crisperwhisper_amd import metrics
+        n0 = len(out["token_timestamps"][0])
+        _, words0 = collate.decode_asr(vocab, [{"tokens": out["sequences"][0][:n0], "token_timestamps": out["token_timestamps"][0],
+                                                "stride": (30.0, 0.0, 0.0)}])
+        pr_, rc_, f1_ = metrics.boundary_f1(clips_g[0]["chunks"], words0, 0.2)
+        iou_ = metrics.mean_iou(clips_g[0]["chunks"], words0)
+        assert f1_ >= 0.99 and iou_ >= 0.9, (pr_, rc_, f1_, iou_)
         try:                                                # measured numbers for DESIGN.md (pulled back from the GPU box)
             import json
             os.makedirs("gpurun_out", exist_ok=True)
