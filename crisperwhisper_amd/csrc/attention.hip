@@ -338,29 +338,10 @@ __device__ inline void attn_decode_anc(const DecAttnParams& p, int h, int b) {
     }
 }
 
-// NT_O > 0 (bf16 self-attention, <= 16 rows): the out-projection of THIS head's slice is fused behind the attention --
-//   x[b][:] += Wo[:, h*64:(h+1)*64] . a_h[b]  (+ bias from the h = 0 block), partial sums added to the f32 residual
-// with atomics on the 2^-12 grid (order-independent, common.h resid_grid) -- which removes the separate out-projection
-// GEMV launch of every decoder layer.  The 164 KB weight slice (NT_O 16-column tiles x 2 k-steps per wave) is requested
-// at kernel entry, so it streams in underneath the attention; one MFMA row (row 0 = this batch row) carries the vector.
-typedef unsigned int u32x4_att __attribute__((ext_vector_type(4)));
-template <typename T, int NT_O>
+template <typename T>
 __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams p) {
     extern __shared__ float dsm[];          // scores [cap rounded] | red [DEC_GROUPS][64] | scratch [64]
     const int h = blockIdx.x, b = blockIdx.y;
-    u32x4_att wo[NT_O > 0 ? NT_O : 1][2];
-    if (NT_O > 0) {
-        const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const int D_ = p.H * 64;
-#pragma unroll
-        for (int t = 0; t < NT_O; ++t) {
-            int n = (wave_ * NT_O + t) * 16 + (lane_ & 15);
-            n = n < D_ ? n : D_ - 1;
-            const bf16_t* wr = (const bf16_t*)p.Wo + (size_t)n * D_ + h * 64 + (lane_ >> 4) * 8;
-            wo[t][0] = *(const u32x4_att*)wr;
-            wo[t][1] = *(const u32x4_att*)(wr + 32);
-        }
-    }
     float* sc = dsm;
     float* red = dsm + ((p.cap + 63) & ~63);
     float* scratch = red + DEC_GROUPS * 64;
@@ -466,57 +447,20 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[grp * 64 + sub * 8 + e] = acc[e];
     __syncthreads();
-    if (NT_O == 0) {
-        if (tid < 64) {
-            float r = 0.f;
-            for (int gI = 0; gI < DEC_GROUPS; ++gI) r += red[gI * 64 + tid];
-            if (p.out_frag) p.out_frag[frag_index(b, h * 64 + tid, p.H * 64)] = f32_to_bf16(r);
-            else p.out[(size_t)b * p.H * 64 + h * 64 + tid] = r;
-        }
-        return;
-    }
-    // ---- fused out-projection slice
-    bf16_t* av = (bf16_t*)scratch;                          // 64 bf16 (scratch holds 64 floats)
     if (tid < 64) {
         float r = 0.f;
         for (int gI = 0; gI < DEC_GROUPS; ++gI) r += red[gI * 64 + tid];
-        av[tid] = f32_to_bf16(r);
-    }
-    __syncthreads();
-    const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = p.H * 64;
-    bf16x8_t af[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        af[ks] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-        if (l15 == 0) af[ks] = *(const bf16x8_t*)(av + ks * 32 + g * 8);      // MFMA row 0 = this batch row
-    }
-#pragma unroll
-    for (int t = 0; t < NT_O; ++t) {
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc = mfma16a(af[ks], __builtin_bit_cast(bf16x8_t, wo[t][ks]), acc);
-        const int n = (wave * NT_O + t) * 16 + l15;
-        if (g == 0 && n < D)                                 // D[row g*4 + r][col l15]: row 0 lives in lanes 0..15, r = 0
-            atomicAdd(p.x_resid + (size_t)b * D + n, resid_grid(acc[0] + ((h == 0 && p.bo) ? p.bo[n] : 0.f)));
+        if (p.out_frag) p.out_frag[frag_index(b, h * 64 + tid, p.H * 64)] = f32_to_bf16(r);
+        else p.out[(size_t)b * p.H * 64 + h * 64 + tid] = r;
     }
 }
 
 int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
     size_t lds = ((size_t)((p.cap + 63) & ~63) + DEC_GROUPS * 64 + 64) * sizeof(float);
-    if (p.Wo) {                                             // fused out-projection (bf16 self-attention only)
-        const int D = p.H * 64, nt = (D + 127) / 128;       // 8 waves x nt tiles x 16 columns
-        if (!bf16 || p.anc || p.out_frag || !p.x_resid) return CW_ERR_INVALID;
-        if (nt == 10) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 10>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
-        else if (nt == 1) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 1>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
-        else return CW_ERR_INVALID;
-        return CW_OK;
-    }
     if (bf16)
-        hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 0>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+        hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
     else
-        hipLaunchKernelGGL((attn_decode_kernel<float, 0>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+        hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
     return CW_OK;
 }
 

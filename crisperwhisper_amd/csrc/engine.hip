@@ -85,7 +85,6 @@ struct cw_ctx {
     int *d_pos = nullptr, *d_cfg = nullptr;   // per-row decoder input position; [n_prompt, min_new, max_length, use_forced]
     hipGraphExec_t step_graph[65] = {};       // captured decode step (layers + logits + sampling) per batch size
     bool use_graph = true;
-    bool fuse_self = true;                    // self-attention kernel also applies its head's out-projection slice (CW_NO_FUSE_SELF=1: off)
     cw_gen_cfg gen{};
     bool gen_set = false;
     bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
@@ -236,7 +235,6 @@ static int create_impl(cw_ctx* c) {
     c->bf16 = d.dtype == CW_DTYPE_BF16;
     if (getenv("CW_NO_GRAPH")) c->use_graph = false;
     if (getenv("CW_NO_LN_FOLD")) c->fold_enabled = false;
-    if (getenv("CW_NO_FUSE_SELF")) c->fuse_self = false;
     c->esz = c->bf16 ? 2 : 4;
     c->Bm = Bm;
     c->S_pad = 1536;
@@ -758,15 +756,13 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
             CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep));
         }
-        const bool fuse_o = c->bf16 && c->fuse_self && !frag && c->beam_K == 0 && (D == 1280 || D == 128);
         {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
             if (frag) p.out_frag = (unsigned short*)c->d_xfrag2;
             if (c->beam_K > 0) p.anc = c->d_anc;
-            if (fuse_o) { p.Wo = L.wo; p.bo = L.bo; p.x_resid = c->dx; }
             CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
         }
-        if (!fuse_o) {
+        {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
             if (frag) CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));

@@ -89,9 +89,6 @@ struct DecAttnParams {
     int B, H;
     int kv_div;            // > 1: query rows b share cache row b / kv_div (beams of one audio item; cross-attention)
     const int* anc;        // non-null: [B][cap] cache row holding key k of query row b (beam-search self-attention)
-    // fused out-projection (bf16 self-attention, no anc / out_frag): Wo [D][D] bf16 row = output column, bo [D] or null,
-    // x_resid [B][D] f32 residual stream accumulated in place
-    const void* Wo; const float* bo; float* x_resid;
 };
 int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st);
 
