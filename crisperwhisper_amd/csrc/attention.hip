@@ -366,6 +366,68 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
     for (int u = 0; u < DEC_PRE; ++u) vpre[u].ld(Vh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
     const int n_keys = p.pos ? (p.n_keys > 0 ? p.n_keys : p.pos[b] + 1) : p.n_keys;
 
+    if (n_keys <= DEC_PRE * DEC_GROUPS && !p.align_out) {
+        // Short history (<= 128 keys: every key row is already in registers): scores stay in registers, the only block-wide
+        // exchanges are the 8 wave maxima and the final 8 x 64 partial outputs -- 2 barriers instead of 7 and no 64-deep
+        // serial LDS reduction (same structure as attn_cross_split_kernel).
+        float* s_max = scratch;               // [8]
+        float* red8 = red;                    // [8][64] + [8] sums behind it
+        const int lane = tid & 63, wave = tid >> 6;
+        float d[DEC_PRE], mxl = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < DEC_PRE; ++u) {
+            float kv[8];
+            kpre[u].cvt(kv);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t = fmaf(qv[e], kv[e], t);
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+            d[u] = (grp + u * DEC_GROUPS < n_keys) ? t : -INFINITY;
+            mxl = fmaxf(mxl, d[u]);
+        }
+        mxl = wave_max(mxl);
+        if (lane == 0) s_max[wave] = mxl;
+        __syncthreads();
+        mxl = s_max[0];
+#pragma unroll
+        for (int w = 1; w < DEC_THREADS / 64; ++w) mxl = fmaxf(mxl, s_max[w]);
+        float acc[8] = {};
+        float lsum = 0.f;
+#pragma unroll
+        for (int u = 0; u < DEC_PRE; ++u) {
+            if (grp + u * DEC_GROUPS < n_keys) {          // stale rows may hold non-finite bit patterns: skip, not scale
+                const float pk = expf(d[u] - mxl);
+                if (sub == 0) lsum += pk;
+                float vv[8];
+                vpre[u].cvt(vv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                       // sum over the wave's 8 key groups (lane bits 3, 4, 5)
+            float v = acc[e] + dpp_mov<0x128, 0xf>(0.f, acc[e]);
+            acc[e] = xor32_sum(xor16_sum(v));
+        }
+        lsum = wave_sum(lsum);
+        __syncthreads();                                    // s_max (aliases scratch) fully read before red8 / sums are written
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red8[wave * 64 + sub * 8 + e] = acc[e];
+        }
+        if (lane == 0) red8[8 * 64 + wave] = lsum;
+        __syncthreads();
+        if (tid < 64) {
+            float r = 0.f, l = 0.f;
+#pragma unroll
+            for (int w = 0; w < DEC_THREADS / 64; ++w) { r += red8[w * 64 + tid]; l += red8[8 * 64 + w]; }
+            r *= 1.0f / l;
+            if (p.out_frag) p.out_frag[frag_index(b, h * 64 + tid, p.H * 64)] = f32_to_bf16(r);
+            else p.out[(size_t)b * p.H * 64 + h * 64 + tid] = r;
+        }
+        return;
+    }
+
     float mx = -INFINITY;
 #pragma unroll
     for (int u = 0; u < DEC_PRE; ++u) {
@@ -467,90 +529,105 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------
 // Cross-attention decode, split over keys.  grid (H, B, ATT_NS), 512 threads.
 // ---------------------------------------------------------------------------------------------------
+// Round-2 structure: every lane keeps the scores of its (up to 4) keys in registers -- the K pass, the exponentials and
+// the V pass use the same key ownership, so no score ever goes through LDS (the alignment heads write theirs straight
+// to the alignment buffer) -- and the only block-wide exchanges are the running maximum (8 floats) and the final
+// 8 x 64 partial outputs: 2 barriers per block instead of 7, the 64-group serial LDS reduction became three cross-lane
+// steps + 8 adds.  Needs nk <= 4 * 64 keys per block (ATT_NS >= 6 for 1500 frames).
+__device__ inline float row_ror8_add(float v) { return v + dpp_mov<0x128, 0xf>(0.f, v); }   // + lane ^ 8 (row_ror:8)
 template <typename T>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSplitParams p) {
-    __shared__ float sc[512];
-    __shared__ float red[(CROSS_THREADS / 8) * 64];
-    __shared__ float scratch[64];
+    __shared__ float s_max[8];
+    __shared__ float red[8 * 64];
+    __shared__ float red_l[8];
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
     const int k_lo = sp * per, k_hi = min(p.n_keys, k_lo + per), nk = k_hi - k_lo;
-    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
+    const int tid = threadIdx.x, lane = tid & 63, sub = tid & 7, grp = tid >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bk = p.kv_div > 1 ? b / p.kv_div : b;            // beams of one audio item share its encoder K/V
-    const T* Kh = (const T*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64;
-    const T* Vh = (const T*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64;
+    const T* Kh = (const T*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
+    const T* Vh = (const T*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
+    constexpr int G = CROSS_THREADS / 8;                       // 64 key groups
     float qv[8];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
-
+    Raw8<T> kr[4], vr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kr[u].ld(Kh + (size_t)min(grp + u * G, nk - 1) * 64);   // unconditional, clamped
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vr[u].ld(Vh + (size_t)min(grp + u * G, nk - 1) * 64);
+    float d[4];
     float mx = -INFINITY;
-    for (int k0 = grp; k0 < nk; k0 += 4 * (CROSS_THREADS / 8)) {
-        float kv[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {   // unconditional loads (clamped row): no exec-masked blocks, all in flight
-            const int k = min(k0 + u * (CROSS_THREADS / 8), nk - 1);
-            Row8<T>::ld(Kh + (size_t)k * 64 + sub * 8, kv[u]);
-        }
+    for (int u = 0; u < 4; ++u) {
+        float kv[8];
+        kr[u].cvt(kv);
+        float t = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * (CROSS_THREADS / 8);
-            if (k < nk) {
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[u][e], d);
-                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);   // (a DPP quad_perm/half-mirror version measured slower here)
-                if (sub == 0) sc[k] = d;
-                mx = fmaxf(mx, d);
-            }
-        }
+        for (int e = 0; e < 8; ++e) t = fmaf(qv[e], kv[e], t);
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+        d[u] = (grp + u * G < nk) ? t : -INFINITY;
+        mx = fmaxf(mx, d[u]);
     }
-    mx = block_max(mx, scratch);
-    float sum = 0.f;
-    for (int k = tid; k < nk; k += CROSS_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
-    sum = block_sum(sum, scratch);
+    mx = wave_max(mx);
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    mx = s_max[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) mx = fmaxf(mx, s_max[w]);
 
     const int slot = p.align_out ? p.align_slot[h] : -1;
+    float* adst = nullptr;
+    size_t rowi = 0;
     if (slot >= 0) {
-        const int arow = p.pos[b];
-        const size_t rowi = ((size_t)b * p.n_align + slot) * p.align_rows + arow;
-        float* dst = p.align_out + rowi * p.n_keys + k_lo;
-        for (int k = tid; k < nk; k += CROSS_THREADS) dst[k] = sc[k];
-        if (tid == 0) { p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = sum; }
+        rowi = ((size_t)b * p.n_align + slot) * p.align_rows + p.pos[b];
+        adst = p.align_out + rowi * p.n_keys + k_lo;
     }
-    if (tid == 0) {
-        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp) * 2;
-        ml[0] = mx; ml[1] = sum;
-    }
-
     float acc[8] = {};
-    for (int k0 = grp; k0 < nk; k0 += 4 * (CROSS_THREADS / 8)) {
-        float vv[4][8];
+    float lsum = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = min(k0 + u * (CROSS_THREADS / 8), nk - 1);
-            Row8<T>::ld(Vh + (size_t)k * 64 + sub * 8, vv[u]);
+    for (int u = 0; u < 4; ++u) {
+        const int k = grp + u * G;
+        const float pk = (k < nk) ? expf(d[u] - mx) : 0.f;
+        if (sub == 0 && k < nk) {
+            lsum += pk;
+            if (adst) adst[k] = pk;                            // un-normalised; align_normalize_kernel finishes the row
         }
+        if (k < nk) {
+            float vv[8];
+            vr[u].cvt(vv);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * (CROSS_THREADS / 8);
-            if (k < nk) {
-                const float pk = sc[k];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[u][e], acc[e]);
-            }
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
         }
     }
+    // sum over the wave's 8 key groups (lane bits 3, 4, 5)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[grp * 64 + sub * 8 + e] = acc[e];
+    for (int e = 0; e < 8; ++e) acc[e] = xor32_sum(xor16_sum(row_ror8_add(acc[e])));
+    lsum = wave_sum(lsum);
+    if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * 64 + sub * 8 + e] = acc[e];
+    }
+    if (lane == 0) red_l[wave] = lsum;
     __syncthreads();
     if (tid < 64) {
         float r = 0.f;
-        for (int gI = 0; gI < (CROSS_THREADS / 8); ++gI) r += red[gI * 64 + tid];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) r += red[w * 64 + tid];
         p.part_o[((size_t)sp * p.B + b) * p.H * 64 + h * 64 + tid] = r;
+    }
+    if (tid == 64) {
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) l += red_l[w];
+        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp) * 2;
+        ml[0] = mx; ml[1] = l;
+        if (slot >= 0) { p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l; }
     }
 }
 
 int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
-    if ((p.n_keys + ATT_NS - 1) / ATT_NS > 512) return CW_ERR_INVALID;
+    if ((p.n_keys + ATT_NS - 1) / ATT_NS > 4 * (CROSS_THREADS / 8) || CROSS_THREADS != 512) return CW_ERR_INVALID;
     dim3 grid(p.H, p.B, ATT_NS);
     if (bf16) hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t>), grid, dim3(CROSS_THREADS), 0, st, p);
     else hipLaunchKernelGGL((attn_cross_split_kernel<float>), grid, dim3(CROSS_THREADS), 0, st, p);
