@@ -410,7 +410,6 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
             acc[e] = xor32_sum(xor16_sum(v));
         }
         lsum = wave_sum(lsum);
-        __syncthreads();                                    // s_max (aliases scratch) fully read before red8 / sums are written
         if (lane < 8) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) red8[wave * 64 + sub * 8 + e] = acc[e];
