@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(SampleParams p, Sam
     }
     __syncthreads();
     acc = block_sum(acc, s_f);
+    if (tid == 0 && b == 0 && sl == 0) *p.n_unfinished = 0;     // stage 2 (a later launch) counts the running rows into it
     if (tid == 0) {
         SamplePart o; o.bt_v = bt.v; o.bt_i = bt.i; o.bs_v = bs.v; o.bs_i = bs.i; o.ts_sum = acc; o.pad[0] = o.pad[1] = o.pad[2] = 0.f;
         part[(size_t)b * SAMPLE_NS + sl] = o;
@@ -438,7 +439,6 @@ int cw_launch_align_gather(const float* align, const int* row_of_pos, int n_item
 
 int cw_launch_sample(const SampleParams& p, hipStream_t st) {
     if (!p.partials || (p.ldv >> 2) > SAMPLE_NS * 1024 || (p.ldv & 3)) return CW_ERR_INVALID;
-    hipMemsetAsync(p.n_unfinished, 0, sizeof(int), st);
     hipLaunchKernelGGL(sample_partial_kernel, dim3(p.B, SAMPLE_NS), dim3(256), 0, st, p, (SamplePart*)p.partials);
     if (p.embed_bf16)
         hipLaunchKernelGGL((sample_kernel<bf16_t>), dim3(p.B), dim3(256), 0, st, p);
