@@ -164,13 +164,33 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_kernel(const float* __restric
 // Wave-local DTW (round 2).  The block kernel above pays one __syncthreads per anti-diagonal (0.43-0.59 us each, 1627 of
 // them at N = 128) and walks the byte trace back through global memory one dependent load per step.  Here one WAVE owns a
 // sequence: lane l holds rows l*R+1 .. l*R+R, the three cells a cell depends on are either in the lane's own registers
-// or the previous lane's last row (one wave_shr:1 DPP move per diagonal), so a diagonal costs ~R x 15 instructions and no
-// barrier; matrix values arrive as float4 per row every fourth diagonal; the 2-bit trace codes are packed 16 per dword
-// (one LDS / global store per row per 16 diagonals) and the backtrace re-uses a loaded word while it walks along a row.
+// or the previous lane's last row (one wave_shr:1 DPP move per diagonal), so a diagonal is ~R x 12 dependent-free
+// instructions and no barrier.  The cost matrix is first skewed into diagonal-major order (dtw_skew_kernel, parallel and
+// bandwidth-bound), so the wave's operands of diagonal d are one contiguous, coalesced vector that is requested P
+// diagonals (several hundred cycles) before it is needed; the 2-bit trace codes are packed 16 per dword per row (one LDS
+// store per row per 16 diagonals) and the backtrace re-uses a loaded word while it walks along a row.
 // Same arithmetic, tie rule and boundary conventions as dtw_kernel / generation_whisper.py:64-115 (bit-exact paths).
 // ---------------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(64) void dtw_wave_kernel(const float* __restrict__ mat, int N, int S,
+// xd[b][d][c] = -x[b][c][d - c - 2]  for rows c = i - 1 in 0..NP-1 and diagonals d = i + j in 2..N+M (0 off the lattice)
+__global__ void dtw_skew_kernel(const float* __restrict__ mat, int N, int S, const int* __restrict__ n_cols, int NP,
+                                int D_cap, float* __restrict__ xd) {
+    const int b = blockIdx.z, d = blockIdx.x + 2, M = n_cols[b];
+    if (d > N + M) return;
+    const float* x = mat + (size_t)b * N * S;
+    float* dst = xd + ((size_t)b * D_cap + d) * NP;
+    for (int c = threadIdx.x; c < NP; c += blockDim.x) {
+        const int j = d - (c + 1);
+        dst[c] = (c < N && j >= 1 && j <= M) ? -x[(size_t)c * S + (j - 1)] : 0.f;
+    }
+}
+
+template <int R> struct DtwVec;
+template <> struct DtwVec<2> { float v[2]; __device__ inline void ld(const float* p) { const float2 t = *(const float2*)p; v[0] = t.x; v[1] = t.y; } };
+template <> struct DtwVec<4> { float v[4]; __device__ inline void ld(const float* p) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; } };
+template <> struct DtwVec<8> { float v[8]; __device__ inline void ld(const float* p) { const float4 t = *(const float4*)p, u = *(const float4*)(p + 4); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; v[4] = u.x; v[5] = u.y; v[6] = u.z; v[7] = u.w; } };
+
+template <int R, int P>
+__global__ __launch_bounds__(64) void dtw_wave_kernel(const float* __restrict__ xd, int N, int S, int D_cap,
                                                       const int* __restrict__ n_cols, unsigned int* __restrict__ trace_g,
                                                       size_t trace_stride_words, int use_lds, int* __restrict__ first_col,
                                                       int* __restrict__ path_text, int* __restrict__ path_time,
@@ -178,60 +198,55 @@ __global__ __launch_bounds__(64) void dtw_wave_kernel(const float* __restrict__ 
     extern __shared__ unsigned int tr_lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int M = n_cols[b];
-    const float* x = mat + (size_t)b * N * S;
+    constexpr int NP = R * 64;
+    const float* xb = xd + (size_t)b * D_cap * NP + lane * R;
     const int SW = (S + 15) >> 4;                              // trace words per row
     unsigned int* tr = use_lds ? tr_lds : trace_g + (size_t)b * trace_stride_words;
     float v1[R], v2[R];                                        // this lane's rows on diagonals d-1 and d-2
-    float4 xc[R], xn[R];                                       // matrix values j-1 in [4q, 4q+3] (current / next group)
     unsigned int acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        v1[r] = INFINITY; v2[r] = INFINITY; acc[r] = 0u;
-        const int i = lane * R + r + 1;
-        xc[r] = make_float4(0.f, 0.f, 0.f, 0.f); xn[r] = xc[r];
-        if (i <= N && M >= 1) {
-            const float4* row = (const float4*)(x + (size_t)(i - 1) * S);
-            xc[r] = row[0];
-            if (M > 4) xn[r] = row[1];
-        }
-    }
+    for (int r = 0; r < R; ++r) { v1[r] = INFINITY; v2[r] = INFINITY; acc[r] = 0u; }
     float up1 = INFINITY, up2 = INFINITY;                      // previous lane's last row on diagonals d-1 / d-2
-    for (int d = 2; d <= N + M; ++d) {
-        float nv[R];
+    const int d_end = N + M;                                   // last diagonal
+    DtwVec<R> ring[P], nxt[P];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = lane * R + r + 1, j = d - i;
-            const bool on = i <= N && j >= 1 && j <= M;
-            float c0 = (r == 0) ? up2 : v2[r > 0 ? r - 1 : 0];
-            float c1 = (r == 0) ? up1 : v1[r > 0 ? r - 1 : 0];
-            if (i == 1) { c1 = INFINITY; c0 = (j == 1) ? 0.f : INFINITY; }      // row 0 of the DP: cost[0][0] = 0, else inf
-            const float c2 = v1[r];
-            float out = INFINITY;
-            if (on) {
-                const int q = j - 1;
-                const float4 g4 = xc[r];
-                const int e = q & 3;
-                const float xv = -(e == 0 ? g4.x : (e == 1 ? g4.y : (e == 2 ? g4.z : g4.w)));
-                float cm; unsigned int t;
-                if (c0 < c1 && c0 < c2) { cm = c0; t = 0u; }
-                else if (c1 < c0 && c1 < c2) { cm = c1; t = 1u; }
-                else { cm = c2; t = 2u; }
-                out = xv + cm;
-                acc[r] |= t << (2 * (q & 15));
-                if ((q & 15) == 15 || j == M) { tr[(size_t)(i - 1) * SW + (q >> 4)] = acc[r]; acc[r] = 0u; }
-                if (e == 3) {                                   // group consumed: rotate, fetch the one after next
-                    xc[r] = xn[r];
-                    const int qn = q + 5;                       // first element of the group after the next one
-                    if (qn < M) xn[r] = ((const float4*)(x + (size_t)(i - 1) * S))[qn >> 2];
+    for (int u = 0; u < P; ++u) ring[u].ld(xb + (size_t)min(2 + u, D_cap - 1) * NP);
+    for (int d0 = 2; d0 <= d_end; d0 += P) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) nxt[u].ld(xb + (size_t)min(d0 + P + u, D_cap - 1) * NP);     // P diagonals ahead
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const int d = d0 + u;
+            if (d <= d_end) {
+                float nv[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane * R + r + 1, j = d - i;
+                    const bool on = i <= N && j >= 1 && j <= M;
+                    float c0 = (r == 0) ? up2 : v2[r > 0 ? r - 1 : 0];
+                    float c1 = (r == 0) ? up1 : v1[r > 0 ? r - 1 : 0];
+                    if (i == 1) { c1 = INFINITY; c0 = (j == 1) ? 0.f : INFINITY; }     // row 0 of the DP: cost[0][0] = 0, else inf
+                    const float c2 = v1[r];
+                    float cm; unsigned int t;
+                    if (c0 < c1 && c0 < c2) { cm = c0; t = 0u; }
+                    else if (c1 < c0 && c1 < c2) { cm = c1; t = 1u; }
+                    else { cm = c2; t = 2u; }
+                    nv[r] = on ? ring[u].v[r] + cm : INFINITY;
+                    if (on) {
+                        const int q = j - 1;
+                        acc[r] |= t << (2 * (q & 15));
+                        if ((q & 15) == 15 || j == M) { tr[(size_t)(i - 1) * SW + (q >> 4)] = acc[r]; acc[r] = 0u; }
+                    }
                 }
-            }
-            nv[r] = out;
-        }
-        const float last_new = nv[R - 1];
+                const float last_new = nv[R - 1];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { v2[r] = v1[r]; v1[r] = nv[r]; }
-        up2 = up1;
-        up1 = dpp_mov<0x138, 0xf>(INFINITY, last_new);           // wave_shr:1 -- lane l <- lane l-1, lane 0 keeps +inf
+                for (int r = 0; r < R; ++r) { v2[r] = v1[r]; v1[r] = nv[r]; }
+                up2 = up1;
+                up1 = dpp_mov<0x138, 0xf>(INFINITY, last_new);       // wave_shr:1 -- lane l <- lane l-1, lane 0 keeps +inf
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < P; ++u) ring[u] = nxt[u];
     }
     __syncthreads();                                           // single wave: orders the trace stores before the walk
     if (lane == 0) {
@@ -298,30 +313,37 @@ int cw_launch_align_filter(const float* w, int B, int Ha, int rows_cap, int S, i
     return CW_OK;
 }
 
+size_t cw_dtw_skew_floats(int B, int N, int S) {           // workspace of the wave-local DTW: [B][N + S + 1][rows padded to 64 R]
+    const int R = N <= 128 ? 2 : (N <= 256 ? 4 : 8);
+    return (size_t)B * (size_t)(N + S + 1) * (R * 64);
+}
+
 int cw_launch_dtw(const float* mat, int B, int N, int S, const int* n_cols, unsigned char* trace, int* first_col,
-                  int* path_text, int* path_time, int* path_len, hipStream_t st) {
+                  int* path_text, int* path_time, int* path_len, hipStream_t st, float* skew) {
     if (N > DTW_THREADS || N <= 0) return CW_ERR_INVALID;
     static int use_block = -1;
     if (use_block < 0) use_block = getenv("CW_DTW_BLOCK") ? 1 : 0;       // the round-1 block kernel, kept for A/B runs
-    if (use_block || (S & 3)) {
+    if (use_block || !skew) {
         hipLaunchKernelGGL(dtw_kernel, dim3(B), dim3(DTW_THREADS), 0, st, mat, N, S, n_cols, trace, first_col, path_text,
                            path_time, path_len);
         return CW_OK;
     }
+    const int R = N <= 128 ? 2 : (N <= 256 ? 4 : 8), NP = R * 64, D_cap = N + S + 1;
+    hipLaunchKernelGGL(dtw_skew_kernel, dim3(N + S - 1, 1, B), dim3(NP < 256 ? NP : 256), 0, st, mat, N, S, n_cols, NP, D_cap, skew);
     // trace words: N rows x ceil(S/16); in LDS when they fit (N = 128: 48 KB), else in the byte-trace buffer (N*S bytes >= that)
     const size_t words = (size_t)N * ((S + 15) >> 4);
     const int use_lds = words * 4 <= 150 * 1024 ? 1 : 0;
     const size_t lds = use_lds ? words * 4 : 0;
     const size_t stride_words = ((size_t)N * S) / 4;
-#define CW_DTW_LAUNCH(RR)                                                                                              \
+#define CW_DTW_LAUNCH(RR, PP)                                                                                          \
     do {                                                                                                               \
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)dtw_wave_kernel<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((dtw_wave_kernel<RR>), dim3(B), dim3(64), lds, st, mat, N, S, n_cols, (unsigned int*)trace,   \
-                           stride_words, use_lds, first_col, path_text, path_time, path_len);                         \
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)dtw_wave_kernel<RR, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((dtw_wave_kernel<RR, PP>), dim3(B), dim3(64), lds, st, skew, N, S, D_cap, n_cols,            \
+                           (unsigned int*)trace, stride_words, use_lds, first_col, path_text, path_time, path_len);   \
     } while (0)
-    if (N <= 128) CW_DTW_LAUNCH(2);
-    else if (N <= 256) CW_DTW_LAUNCH(4);
-    else CW_DTW_LAUNCH(8);
+    if (R == 2) CW_DTW_LAUNCH(2, 16);
+    else if (R == 4) CW_DTW_LAUNCH(4, 16);
+    else CW_DTW_LAUNCH(8, 8);
 #undef CW_DTW_LAUNCH
     return CW_OK;
 }

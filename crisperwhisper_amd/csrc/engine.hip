@@ -99,7 +99,8 @@ struct cw_ctx {
     int last_L = 0, last_nb = 0;
 
     // timestamps workspace
-    float *d_mean = nullptr, *d_std = nullptr, *d_mat = nullptr;
+    float *d_mean = nullptr, *d_std = nullptr, *d_mat = nullptr, *d_skew = nullptr;
+    size_t skew_cap = 0;
     unsigned char* d_trace = nullptr;
     int *d_first_col = nullptr, *d_path_text = nullptr, *d_path_time = nullptr, *d_path_len = nullptr,
         *d_ncols = nullptr;
@@ -1124,7 +1125,14 @@ int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, 
     StageTimer tm(c, CW_STAGE_TIMESTAMPS);
     CWCHK(c, normalize_alignment(c));
     CWCHK(c, run_alignment(c, c->align_cur ? c->align_cur : c->d_align, nb, Ha, TGT, S, n_prompt, N, c->d_ncols, c->d.median_filter_width, c->d_mean, c->d_std, c->d_mat));
-    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->d_path_text, c->d_path_time, c->d_path_len, c->st));
+    {   // workspace of the wave-local DTW, grown on demand (diagonal-major copy of the cost matrices)
+        const size_t need = cw_dtw_skew_floats(nb, N, S);
+        if (need > c->skew_cap) {
+            CWCHK(c, dmalloc(c, &c->d_skew, need * 4, false));
+            c->skew_cap = need;
+        }
+    }
+    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->d_path_text, c->d_path_time, c->d_path_len, c->st, c->d_skew));
     KCHK(c);
     tm.stop();
     std::vector<int> fc((size_t)nb * N);
@@ -1275,7 +1283,9 @@ int32_t cw_dtw(cw_ctx* c, const float* mat, int32_t N, int32_t M, int32_t* text_
     HIPCHK(c, hipMalloc((void**)&dpj, (size_t)(N + M + 2) * 4)); HIPCHK(c, hipMalloc((void**)&dpl, 4)); HIPCHK(c, hipMalloc((void**)&dn, 4));
     HIPCHK(c, hipMemcpy(dmat, mat, (size_t)N * M * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dn, &M, 4, hipMemcpyHostToDevice));
-    int r = cw_launch_dtw(dmat, 1, N, M, dn, dtr, dfc, dpt, dpj, dpl, c->st);
+    float* dskew = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dskew, cw_dtw_skew_floats(1, N, M) * 4));
+    int r = cw_launch_dtw(dmat, 1, N, M, dn, dtr, dfc, dpt, dpj, dpl, c->st, dskew);
     if (r == CW_OK) {
         std::vector<int> pt(N + M + 2), pj(N + M + 2);
         int n = 0;
@@ -1291,7 +1301,7 @@ int32_t cw_dtw(cw_ctx* c, const float* mat, int32_t N, int32_t M, int32_t* text_
     } else {
         fail(c, r, "dtw launch rejected N=%d", N);
     }
-    hipFree(dmat); hipFree(dtr); hipFree(dfc); hipFree(dpt); hipFree(dpj); hipFree(dpl); hipFree(dn);
+    hipFree(dmat); hipFree(dtr); hipFree(dfc); hipFree(dpt); hipFree(dpj); hipFree(dpl); hipFree(dn); hipFree(dskew);
     return r;
 }
 

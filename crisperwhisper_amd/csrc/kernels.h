@@ -152,6 +152,8 @@ int cw_launch_align_stats(const float* w, int B, int Ha, int rows_cap, int S, in
                           float* mean, float* stdv, hipStream_t st);
 int cw_launch_align_filter(const float* w, int B, int Ha, int rows_cap, int S, int row0, int N, const int* n_cols,
                            const float* mean, const float* stdv, int width, float* mat, hipStream_t st);
+// skew: workspace of cw_dtw_skew_floats(B, N, S) floats (null: round-1 block kernel)
+size_t cw_dtw_skew_floats(int B, int N, int S);
 int cw_launch_dtw(const float* mat, int B, int N, int S, const int* n_cols, unsigned char* trace, int* first_col,
-                  int* path_text, int* path_time, int* path_len, hipStream_t st);
+                  int* path_text, int* path_time, int* path_len, hipStream_t st, float* skew = nullptr);
 int cw_launch_pauses(double* start, double* end, int W, double thr, hipStream_t st);
