@@ -251,11 +251,12 @@ __global__ __launch_bounds__(64) void dtw_wave_kernel(const float* __restrict__ 
     __syncthreads();                                           // single wave: orders the trace stores before the walk
     if (lane == 0) {
         int ii = N, jj = M, n = 0;
-        int* pt = path_text + (size_t)b * (N + S + 2);
-        int* pj = path_time + (size_t)b * (N + S + 2);
+        int* pt = path_text ? path_text + (size_t)b * (N + S + 2) : nullptr;    // full path only for the stand-alone cw_dtw
+        int* pj = path_time ? path_time + (size_t)b * (N + S + 2) : nullptr;
         int wrow = -1, widx = -1; unsigned int word = 0u;
         while (ii > 0 || jj > 0) {
-            pt[n] = ii - 1; pj[n] = jj - 1; ++n;
+            if (pt) { pt[n] = ii - 1; pj[n] = jj - 1; }
+            ++n;
             if (ii > 0 && jj > 0) first_col[(size_t)b * N + (ii - 1)] = jj - 1;
             unsigned int t;
             if (ii == 0) t = 2u;

@@ -1132,7 +1132,7 @@ int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, 
             c->skew_cap = need;
         }
     }
-    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->d_path_text, c->d_path_time, c->d_path_len, c->st, c->d_skew));
+    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, getenv("CW_DTW_BLOCK") ? c->d_path_text : nullptr, getenv("CW_DTW_BLOCK") ? c->d_path_time : nullptr, c->d_path_len, c->st, c->d_skew));
     KCHK(c);
     tm.stop();
     std::vector<int> fc((size_t)nb * N);
