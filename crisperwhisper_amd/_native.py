@@ -64,6 +64,9 @@ _SIGS = {
     "cw_resampled_length": (C.c_int64, [C.c_int64, _I, _I]),
     "cw_ingest": (_I, [_P, _P, _I, _I, C.c_int64, _I, _I, _I, _P]),
     "cw_resample_taps": (_I, [_I, _I, _P, _I, _P, _P, _P]),
+    "cw_flac_info": (_I, [_P, C.c_int64, _P, _P, _P, _P]),
+    "cw_flac_decode": (_I, [_P, C.c_int64, _P, C.c_int64, _P]),
+    "cw_flac_last_error": (C.c_char_p, []),
     "cw_token_timestamps": (_I, [_P, _I, _I, _I, _P, _P]),
     "cw_beam_begin": (_I, [_P, _I, _I, _P, _I, _I, _I]),
     "cw_beam_step": (_I, [_P, _I, _P, _P]),

@@ -2,9 +2,10 @@
 
 ``chunk_windows`` follows TF/pipelines/automatic_speech_recognition.py:61-84 (chunk_iter) and
 :432-448 (chunk/stride lengths): 30 s windows, chunk_length_s/6 stride each side, hop = chunk - 2*stride.
-``read_audio`` / ``decode_wav_bytes`` replace the ffmpeg subprocess of TF/pipelines/audio_utils.py:9-45 for WAV
-input: the RIFF container is parsed here (integer header fields only); sample decoding, mono mixdown and resampling
-run on the device (``cw_ingest``, csrc/ingest.hip).  ``resample`` is ``torchaudio.functional.resample`` with its
+``read_audio`` / ``decode_wav_bytes`` replace the ffmpeg subprocess of TF/pipelines/audio_utils.py:9-45 for WAV and FLAC
+input: the RIFF container is parsed here (integer header fields only), FLAC streams go through the native decoder
+(``cw_flac_decode``, csrc/flac.cpp); sample scaling, mono mixdown and resampling run on the device (``cw_ingest``,
+csrc/ingest.hip).  ``resample`` is ``torchaudio.functional.resample`` with its
 defaults (TF/pipelines/automatic_speech_recognition.py:398-412), on the device as well.  Other containers raise like
 the reference does when ffmpeg is missing.
 """
@@ -40,7 +41,7 @@ def chunk_windows(n_samples: int, chunk_len: int, stride_left: int, stride_right
 PCM_U8, PCM_S16, PCM_S24, PCM_S32, PCM_F32, PCM_F64 = range(6)
 _NP_FMT = {np.dtype(np.uint8): PCM_U8, np.dtype(np.int16): PCM_S16, np.dtype(np.int32): PCM_S32,
            np.dtype(np.float32): PCM_F32, np.dtype(np.float64): PCM_F64}
-_MALFORMED = ("Soundfile is either not in the correct format or is malformed. Only RIFF/WAV input is decoded natively "
+_MALFORMED = ("Soundfile is either not in the correct format or is malformed. RIFF/WAV and FLAC input is decoded natively "
               "(the reference needs ffmpeg for anything else).")
 
 
@@ -76,6 +77,26 @@ def parse_wav(data: bytes):
     return code, ch, sr, n_frames, payload[: n_frames * ch * (bits // 8)]
 
 
+def decode_flac(data: bytes):
+    """FLAC bytes -> (int32 samples [frames, channels] left-justified to 32 bits, sample rate) through the native decoder
+    (csrc/flac.cpp: RFC 9639 incl. CRC and MD5 verification; raises ValueError with the decoder's message)."""
+    import ctypes as C
+    from . import _native as N
+    lib = N.load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    sr, ch, bps = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    total, n = C.c_int64(0), C.c_int64(0)
+    ptr = buf.ctypes.data_as(C.c_void_p)
+    if lib.cw_flac_info(ptr, len(buf), C.byref(sr), C.byref(ch), C.byref(bps), C.byref(total)) != 0:
+        raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
+    if lib.cw_flac_decode(ptr, len(buf), None, 0, C.byref(n)) != 0:
+        raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
+    out = np.empty((int(n.value), int(ch.value)), dtype=np.int32)
+    if lib.cw_flac_decode(ptr, len(buf), out.ctypes.data_as(C.c_void_p), int(n.value), C.byref(n)) != 0:
+        raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
+    return out, int(sr.value)
+
+
 def _need(engine):
     if engine is None or not hasattr(engine, "ingest"):
         raise RuntimeError("audio ingest runs on the device: pass the pipeline's Engine (there is no host fallback)")
@@ -92,6 +113,9 @@ def resample(x: np.ndarray, sr_in: int, sr_out: int = SAMPLING_RATE, engine=None
 def decode_wav_bytes(data: bytes, sampling_rate: int = SAMPLING_RATE, engine=None, normalise: bool = False) -> np.ndarray:
     """WAV bytes -> mono float32 at ``sampling_rate``.  ``normalise=True`` applies REF/app.py:85-93
     ((y - mean) / std / 8 before resampling)."""
+    if data[:4] == b"fLaC":                      # FLAC: container + entropy decoding on the host, the rest on the device
+        pcm, sr = decode_flac(data)
+        return _need(engine).ingest(pcm, PCM_S32, pcm.shape[1], pcm.shape[0], sr, sampling_rate, normalise=normalise)
     code, ch, sr, n_frames, payload = parse_wav(data)
     return _need(engine).ingest(payload, code, ch, n_frames, sr, sampling_rate, normalise=normalise)
 

@@ -92,6 +92,16 @@ int32_t cw_ingest(cw_ctx* ctx, const void* raw, int32_t fmt, int32_t channels, i
 int32_t cw_resample_taps(int32_t sr_in, int32_t sr_out, float* taps, int32_t cap, int32_t* orig, int32_t* nw,
                          int32_t* width);
 
+/* FLAC container (host, no GPU): the part of `ffmpeg_read` (TF/pipelines/audio_utils.py:9-45) that turns a .flac file into
+ * integer samples -- RFC 9639 decoder with CRC-8 / CRC-16 / STREAMINFO-MD5 verification (csrc/flac.cpp).  cw_flac_decode writes
+ * interleaved samples left-justified to 32 bits ([frames][channels] int32: exactly what cw_ingest(CW_PCM_S32) scales by
+ * 2^-31, i.e. ffmpeg's s16 / s32 -> f32 conversion); pcm_s32 == NULL only reports the frame count.  Errors: negative
+ * code, text in cw_flac_last_error().                                                                                 */
+int32_t cw_flac_info(const uint8_t* data, int64_t n_bytes, int32_t* sample_rate, int32_t* channels,
+                     int32_t* bits_per_sample, int64_t* total_frames);
+int32_t cw_flac_decode(const uint8_t* data, int64_t n_bytes, int32_t* pcm_s32, int64_t cap_frames, int64_t* n_frames);
+const char* cw_flac_last_error(void);
+
 /* ---- seam 1: feature extractor (WhisperFeatureExtractor.__call__, feature_extraction_whisper.py:193-346)
  * pcm: [B][n_samples[b]] packed back to back (each <= CW_N_SAMPLES; zero-padded to 30 s on device).
  * feats_out (nullable): [B][n_mels][3000] f32, HF layout.  n_frames_out (nullable): attention_mask.sum(-1).

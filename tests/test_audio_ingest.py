@@ -203,3 +203,148 @@ def test_resampler_rejects_absurd_rate_pairs_without_allocating():
     assert lib.cw_resample_taps(1000003, 999983, None, 0, C.byref(o), C.byref(n), C.byref(w)) != 0
     assert lib.cw_resample_taps(44100, 16000, None, 0, C.byref(o), C.byref(n), C.byref(w)) == 0 and (o.value, n.value, w.value) == (441, 160, 17)
     assert lib.cw_resampled_length(441000, 44100, 16000) == 160000
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FLAC: native decoder (csrc/flac.cpp) against an independent bit-level writer (tests/flac_writer.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def _flac_signal(rng, n, bps, nch, kind):
+    t = np.arange(n)
+    amp = (1 << (bps - 1)) - 1
+    chans = []
+    for c in range(nch):
+        if kind == "tone":
+            x = 0.6 * amp * np.sin(2 * np.pi * (0.01 + 0.003 * c) * t + c) + 0.02 * amp * rng.standard_normal(n)
+        elif kind == "noise":
+            x = rng.integers(-amp, amp, n).astype(np.float64)
+        else:   # correlated stereo
+            base = 0.5 * amp * np.sin(2 * np.pi * 0.007 * t)
+            x = base + (0.05 * amp * rng.standard_normal(n) if c else 0)
+        chans.append(np.clip(np.round(x), -amp - 1, amp).astype(np.int64))
+    return chans
+
+
+def _decode(data):
+    from crisperwhisper_amd import audio
+    pcm, sr = audio.decode_flac(data)
+    return pcm, sr
+
+
+def test_flac_decoder_every_subframe_type_and_stereo_mode_round_trips():
+    """CONSTANT / VERBATIM / FIXED 0-4 / LPC (orders 1, 8, 32) subframes, Rice and Rice2 with partition orders 0-4 and escape
+    partitions, wasted bits, the four channel assignments, 8 / 16 / 24 / 32-bit samples, STREAMINFO MD5 verified: the decoded
+    samples equal the encoder's input exactly (left-justified to 32 bits)."""
+    from tests import flac_writer as FW
+    rng = np.random.default_rng(0)
+    cases = 0
+    for bps in (8, 16, 24, 32):
+        for stereo in ("independent", "left_side", "side_right", "mid_side"):
+            nch = 2
+            n_blocks = [1024, 256, 4096, 192, 576, 100, 1000]
+            total = sum(n_blocks)
+            chans = _flac_signal(rng, total, bps if bps < 32 else 31, nch, "stereo" if stereo != "independent" else "tone")
+            if bps == 32 and stereo != "independent":
+                continue                                        # the side channel would need 33 bits of 32-bit input: own test below
+            frames, pos = [], 0
+            kinds = [("fixed", dict(order=2, method=0, porder=2)), ("lpc", None), ("verbatim", {}), ("fixed", dict(order=4, method=1, porder=0, escape_parts=(0,))),
+                     ("fixed", dict(order=0, method=0, porder=3, escape_parts=(1, 5))), ("fixed", dict(order=1, method=1, porder=1)), ("fixed", dict(order=3, method=0, porder=3))]
+            for nb, (kind, kw) in zip(n_blocks, kinds):
+                plans = []
+                for c in range(nch):
+                    seg = chans[c][pos: pos + nb]
+                    if kind == "lpc":
+                        order = (1, 8, 32)[(cases + c) % 3]
+                        # the subframe the writer emits is the (possibly decorrelated) channel: plan the LPC on the raw one, valid anyway
+                        plans.append(dict(kind="lpc", order=order, method=c % 2, porder=2 if nb % 4 == 0 and nb // 4 >= order else 0,
+                                          lpc=FW.lpc_plan(seg, order, prec=12 if bps <= 16 else 15)))
+                    else:
+                        plans.append(dict(kind=kind, **kw))
+                frames.append(dict(n=nb, stereo=stereo, plans=plans))
+                pos += nb
+            data = FW.write_stream(chans, bps, 44100, frames)
+            pcm, sr = _decode(data)
+            assert sr == 44100 and pcm.shape == (total, nch)
+            want = np.stack(chans, axis=1).astype(np.int64) << (32 - bps)
+            assert np.array_equal(pcm.astype(np.int64), want), (bps, stereo)
+            cases += 1
+    assert cases >= 13
+
+
+def test_flac_decoder_header_variants_constant_wasted_bits_and_unknown_length():
+    """Mono / 3-channel streams, CONSTANT subframes, wasted bits, explicit 8- and 16-bit block sizes, sample rates given by the
+    8-bit kHz / 16-bit Hz / 16-bit daHz codes or taken from STREAMINFO, variable-blocksize streams (sample numbers up to 5 coded
+    bytes), a frame number that needs 3 coded bytes, extra metadata blocks in front of the audio, no MD5, unknown total length."""
+    from tests import flac_writer as FW
+    rng = np.random.default_rng(1)
+    for sr in (16000, 37000, 12345, 655350, 48000):
+        for nch in (1, 3):
+            n_blocks = [200, 4096, 4096, 17]
+            total = sum(n_blocks)
+            chans = _flac_signal(rng, total, 16, nch, "tone")
+            chans[0][:200] = 1234                                 # CONSTANT block
+            for c in chans:
+                c[200:4296] &= ~7                                 # 3 wasted bits in the second block
+            frames, pos = [], 0
+            for k, nb in enumerate(n_blocks):
+                plans = []
+                for c in range(nch):
+                    if k == 0 and c == 0:
+                        plans.append(dict(kind="constant"))
+                    elif k == 1:
+                        plans.append(dict(kind="fixed", order=2, method=0, porder=4, wasted=3))
+                    else:
+                        plans.append(dict(kind="fixed", order=c % 5, method=1, porder=0))
+                frames.append(dict(n=nb, plans=plans, variable=(sr == 12345), use_streaminfo_sr=(sr == 48000 and k % 2 == 0),
+                                   use_streaminfo_bps=(k == 2)))
+                pos += nb
+            extra = [(4, bytes(40)), (1, bytes(1000))]      # VORBIS_COMMENT-typed and PADDING blocks: skipped
+            data = FW.write_stream(chans, 16, sr, frames, with_md5=(nch == 1), total_known=(nch == 3), extra_blocks=extra,
+                                   first_number=70000)
+            pcm, got_sr = _decode(data)
+            assert got_sr == sr and pcm.shape == (total, nch)
+            assert np.array_equal(pcm.astype(np.int64), np.stack(chans, axis=1).astype(np.int64) << 16), (sr, nch)
+
+
+def test_flac_decoder_fails_loudly_on_corruption():
+    """Flipped payload byte -> CRC-16, flipped header byte -> CRC-8 / sync, wrong MD5, truncation, not-FLAC: ValueError with the
+    decoder's message, never wrong audio."""
+    from tests import flac_writer as FW
+    rng = np.random.default_rng(2)
+    chans = _flac_signal(rng, 2048, 16, 2, "stereo")
+    frames = [dict(n=1024, stereo="mid_side", plans=[dict(kind="fixed", order=2, method=0, porder=2)] * 2)] * 2
+    good = FW.write_stream(chans, 16, 16000, frames)
+    pcm, _ = _decode(good)
+    assert pcm.shape == (2048, 2)
+    audio_off = good.index(bytes([0xFF, 0xF8]))
+    for mutate, msg in ((lambda b: b[:audio_off + 40] + bytes([b[audio_off + 40] ^ 0x10]) + b[audio_off + 41:], "CRC-16|residual|subframe|sync"),
+                        (lambda b: b[:audio_off + 2] + bytes([b[audio_off + 2] ^ 0x01]) + b[audio_off + 3:], "CRC-8|reserved|sync"),
+                        (lambda b: b[:26] + bytes([b[26] ^ 0xFF]) + b[27:], "MD5"),
+                        (lambda b: b[:len(b) - 300], "truncated|ends before|CRC|sync"),
+                        (lambda b: b"RIFF" + b[4:], "fLaC")):
+        with pytest.raises(ValueError, match=msg):
+            _decode(mutate(good))
+
+
+@pytest.mark.gpu
+def test_gpu_flac_path_equals_wav_path(eng, tmp_path):
+    """A .flac file and the .wav file holding the same 16-bit stereo 44.1 kHz samples come out of `read_audio` (container decode
+    on the host, sample scaling + mono mixdown + resampling on the device) bit-identical; 24-bit FLAC matches the f64 oracle."""
+    from tests import flac_writer as FW
+    rng = np.random.default_rng(4)
+    n = 44100
+    chans = _flac_signal(rng, n, 16, 2, "stereo")
+    frames, pos = [], 0
+    while pos < n:
+        nb = min(4096, n - pos)
+        frames.append(dict(n=nb, stereo="mid_side", plans=[dict(kind="fixed", order=2, method=0, porder=0)] * 2))
+        pos += nb
+    fl = tmp_path / "a.flac"; fl.write_bytes(FW.write_stream(chans, 16, 44100, frames))
+    wv = tmp_path / "a.wav"; wv.write_bytes(_wav_bytes(np.stack(chans, axis=1).astype(np.int16), 44100))
+    a = audio.read_audio(str(fl), 16000, eng)
+    b = audio.read_audio(str(wv), 16000, eng)
+    assert a.shape == b.shape == (16000,)
+    assert np.array_equal(a, b)
+    c24 = _flac_signal(rng, 8192, 24, 1, "tone")
+    data = FW.write_stream(c24, 24, 16000, [dict(n=4096, plans=[dict(kind="fixed", order=3, method=1, porder=2)])] * 2)
+    got = audio.decode_wav_bytes(data, 16000, eng)
+    assert np.array_equal(got, (c24[0].astype(np.float64) / (1 << 23)).astype(np.float32))
