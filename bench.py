@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="30 s chunks in flight per GPU (BASELINE config[1]: 8)")
     ap.add_argument("--tokens", type=int, default=128, help="generated tokens per chunk (SURVEY.md 8d)")
     ap.add_argument("--geometry", default="large-v3", choices=["large-v3", "tiny"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--weights", default="aligned", choices=["aligned", "iid"],
                     help="seeded synthetic weights: 'aligned' = random tensors whose alignment heads are peaked and monotone like a "
                          "trained checkpoint's (crisperwhisper_amd/synthetic.py); the run is then checked word for word against the "
@@ -279,7 +279,7 @@ def main():
     # through transformers (CPU, fp32) with the same aligned weights and token count
     parity = None
     gpath = os.path.join(ROOT, "tests", "golden", "e2e_bench_golden.json")
-    if rank == 0 and a.weights == "aligned" and a.geometry == "large-v3" and a.dtype == "bf16" and os.path.exists(gpath):
+    if rank == 0 and a.weights == "aligned" and a.geometry == "large-v3" and a.dtype in ("bf16", "f16") and os.path.exists(gpath):
         gold = json.load(open(gpath))
         if gold["generate_kwargs"]["max_new_tokens"] == a.tokens and gold.get("weights") == "aligned":
             n = min(B, len(gold["clips"]))

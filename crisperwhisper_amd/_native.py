@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrisperwhisper.so")
 
-CW_DTYPE_F32, CW_DTYPE_BF16 = 0, 1
+CW_DTYPE_F32, CW_DTYPE_BF16, CW_DTYPE_F16 = 0, 1, 2
 N_SAMPLES, N_FRAMES, N_CTX = 480000, 3000, 1500
 STAGES = ("mel", "encoder", "cross_kv", "decode", "timestamps")
 

@@ -17,11 +17,9 @@
 #include "common.h"
 #include "kernels.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
-__device__ inline f32x4_t mfma16a(bf16x8_t a, bf16x8_t b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a),
-                                                   __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
-}
+namespace CW_NS {
+
+__device__ inline f32x4_t mfma16a(bf16x8_t a, bf16x8_t b, f32x4_t c) { return cw_mfma_16x16x32(a, b, c); }
 
 #define KT 64          // keys per LDS tile
 #define RESCALE_THR 8.0f
@@ -257,10 +255,7 @@ template <> struct Row8<float> {
 template <> struct Row8<bf16_t> {
     __device__ static inline void ld(const bf16_t* p, float* o) {
         uint4 a = *(const uint4*)p;
-        o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
-        o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
-        o[4] = __uint_as_float(a.z << 16); o[5] = __uint_as_float(a.z & 0xffff0000u);
-        o[6] = __uint_as_float(a.w << 16); o[7] = __uint_as_float(a.w & 0xffff0000u);
+        h16_unpack8(a, o);
     }
 };
 
@@ -274,12 +269,7 @@ template <> struct Raw8<float> {
 template <> struct Raw8<bf16_t> {
     uint4 a;
     __device__ inline void ld(const bf16_t* p) { a = *(const uint4*)p; }
-    __device__ inline void cvt(float* o) const {
-        o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
-        o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
-        o[4] = __uint_as_float(a.z << 16); o[5] = __uint_as_float(a.z & 0xffff0000u);
-        o[6] = __uint_as_float(a.w << 16); o[7] = __uint_as_float(a.w & 0xffff0000u);
-    }
+    __device__ inline void cvt(float* o) const { h16_unpack8(a, o); }
 };
 
 #define DEC_THREADS 512
@@ -804,3 +794,5 @@ int cw_launch_align_normalize(float* align, const float* align_ml, int B, int n_
                        align_rows, n_keys);
     return CW_OK;
 }
+
+}  // namespace CW_NS

@@ -6,27 +6,113 @@
 #include <stdio.h>
 #include <math.h>
 
-typedef unsigned short bf16_t;  // raw bfloat16 storage
+// The engine's 16-bit storage type.  The dtype-dependent translation units (gemm / attention / elementwise / mel) are compiled
+// twice: as is -> bfloat16 (namespace cw_bf16), and with -DCW_F16 -> IEEE binary16, the reference's GPU dtype
+// (REF/transcribe.py:10; namespace cw_f16).  The names `bf16_t`, `f32_to_bf16`, `Act<bf16_t>` ... therefore mean "the 16-bit type
+// of this build"; only the conversions and the MFMA opcode differ (f32 accumulation, f32 residual stream, f32 softmax / LN
+// statistics in both).  binary16 has 3 more significand bits and a 65504 range: every 16-bit tensor of the path (weights, LN
+// outputs, attention probabilities <= e^8 under the deferred rescale, K/V, MLP activations) stays far inside it, and the f32
+// residual stream makes HF's fp16 overflow clamp (modeling_whisper.py:409-411) unnecessary.
+typedef unsigned short bf16_t;
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;  // one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;   // one MFMA 16x16 C/D fragment
 
 #define CW_WAVE 64
 
-__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+// host conversions of both formats (the engine TU uploads weights for either build)
+static inline float cw_host_bf16_to_f32(unsigned short v) { union { uint32_t u; float f; } x; x.u = ((uint32_t)v) << 16; return x.f; }
+static inline unsigned short cw_host_f32_to_bf16(float f) {   // round-nearest-even (NaN stays quiet NaN)
+    union { uint32_t u; float f; } x; x.f = f;
+    const uint32_t rounded = (x.u + 0x7fffu + ((x.u >> 16) & 1u)) >> 16;
+    const uint32_t nan = (x.u >> 16) | 0x40u;
+    return (unsigned short)(((x.u & 0x7fffffffu) > 0x7f800000u) ? nan : rounded);
+}
+static inline unsigned short cw_host_f32_to_f16(float f) {    // IEEE binary16, round-nearest-even, overflow -> inf
+    union { uint32_t u; float f; } x; x.f = f;
+    const uint32_t sign = (x.u >> 16) & 0x8000u;
+    uint32_t a = x.u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (unsigned short)(sign | 0x7e00u);             // NaN
+    if (a >= 0x47800000u) return (unsigned short)(sign | 0x7c00u);            // >= 65536 (or inf) -> inf
+    if (a < 0x33000000u) return (unsigned short)sign;                          // < 2^-25 -> 0
+    if (a < 0x38800000u) {                                                     // subnormal half
+        const int shift = 126 - (int)(a >> 23);                               // 14..24
+        uint32_t m = (a & 0x7fffffu) | 0x800000u;
+        const uint32_t rnd = 1u << (shift - 1), rest = m & ((1u << shift) - 1u);
+        m >>= shift;
+        if (rest > rnd || (rest == rnd && (m & 1u))) ++m;
+        return (unsigned short)(sign | m);
+    }
+    uint32_t h = ((a - 0x38000000u) >> 13);
+    const uint32_t rest = a & 0x1fffu;
+    if (rest > 0x1000u || (rest == 0x1000u && (h & 1u))) ++h;                 // may carry into the exponent (-> inf at the top)
+    return (unsigned short)(sign | h);
+}
+static inline float cw_host_f16_to_f32(unsigned short v) {
+    const uint32_t sign = ((uint32_t)v & 0x8000u) << 16, e = (v >> 10) & 0x1f, m = v & 0x3ff;
+    union { uint32_t u; float f; } x;
+    if (e == 0) {
+        if (m == 0) { x.u = sign; return x.f; }
+        float f = (float)m * (1.0f / 16777216.0f);                            // m * 2^-24
+        return sign ? -f : f;
+    }
+    if (e == 31) { x.u = sign | 0x7f800000u | (m << 13); return x.f; }
+    x.u = sign | ((e + 112) << 23) | (m << 13);
+    return x.f;
+}
+
+#ifdef CW_F16
+#define CW_NS cw_f16
+typedef __attribute__((ext_vector_type(8))) _Float16 cw_mfma16x8;
+__host__ __device__ static inline float bf16_to_f32(bf16_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)__builtin_bit_cast(_Float16, v);
+#else
+    return cw_host_f16_to_f32(v);
+#endif
+}
+__host__ __device__ static inline bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(bf16_t, (_Float16)f);                           // v_cvt_f16_f32, round-nearest-even
+#else
+    return cw_host_f32_to_f16(f);
+#endif
+}
+__device__ static inline void h16_unpack8(const uint4& a, float* o) {         // 8 consecutive 16-bit elements -> f32
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] & 0xffffu));
+        o[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(w[i] >> 16));
+    }
+}
+__device__ static inline f32x4_t cw_mfma_16x16x32(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cw_mfma16x8, a), __builtin_bit_cast(cw_mfma16x8, b), c, 0, 0, 0);
+}
+#else
+#define CW_NS cw_bf16
+typedef __attribute__((ext_vector_type(8))) __bf16 cw_mfma16x8;
+__host__ __device__ static inline float bf16_to_f32(bf16_t v) {
     union { uint32_t u; float f; } x; x.u = ((uint32_t)v) << 16; return x.f;
 }
-__host__ __device__ inline bf16_t f32_to_bf16(float f) {   // round-nearest-even (NaN stays quiet NaN)
+__host__ __device__ static inline bf16_t f32_to_bf16(float f) {   // round-nearest-even (NaN stays quiet NaN)
 #if defined(__HIP_DEVICE_COMPILE__)
     // gfx950 has a hardware converter: the cast lowers to v_cvt_pk_bf16_f32 (pairs are packed by the compiler)
     return __builtin_bit_cast(bf16_t, (__bf16)f);
 #else
-    union { uint32_t u; float f; } x; x.f = f;
-    const uint32_t rounded = (x.u + 0x7fffu + ((x.u >> 16) & 1u)) >> 16;
-    const uint32_t nan = (x.u >> 16) | 0x40u;
-    return (bf16_t)(((x.u & 0x7fffffffu) > 0x7f800000u) ? nan : rounded);
+    return cw_host_f32_to_bf16(f);
 #endif
 }
+__device__ static inline void h16_unpack8(const uint4& a, float* o) {         // 8 consecutive 16-bit elements -> f32
+    o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
+    o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
+    o[4] = __uint_as_float(a.z << 16); o[5] = __uint_as_float(a.z & 0xffff0000u);
+    o[6] = __uint_as_float(a.w << 16); o[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ static inline f32x4_t cw_mfma_16x16x32(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cw_mfma16x8, a), __builtin_bit_cast(cw_mfma16x8, b), c, 0, 0, 0);
+}
+#endif
 
 // Activation storage trait: the engine runs either fully in f32 (parity mode) or with bf16
 // weights/activations (performance mode); memory-bound kernels are templated on the storage type.

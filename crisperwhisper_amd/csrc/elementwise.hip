@@ -3,6 +3,8 @@
 #include "common.h"
 #include "kernels.h"
 
+namespace CW_NS {
+
 // One wave per row (rows of d_model f32 from the residual stream), vectorised float4 loads,
 // two-pass statistics (mean, then variance) like nn.LayerNorm, eps = 1e-5.
 template <typename T>
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
                                                                          : 0x7fffffff;
     // stage 2: merge the SAMPLE_NS slice records of this row (sample_partial_kernel)
     ArgPair bt = {-INFINITY, 0x7fffffff}, bs = {-INFINITY, 0x7fffffff};
-    const SamplePart* pr = p.partials + (size_t)b * SAMPLE_NS;
+    const SamplePart* pr = (const SamplePart*)p.partials + (size_t)b * SAMPLE_NS;
     for (int i = 0; i < SAMPLE_NS; ++i) {
         bt = arg_better(bt, ArgPair{pr[i].bt_v, pr[i].bt_i});
         bs = arg_better(bs, ArgPair{pr[i].bs_v, pr[i].bs_i});
@@ -446,3 +448,5 @@ int cw_launch_sample(const SampleParams& p, hipStream_t st) {
         hipLaunchKernelGGL((sample_kernel<float>), dim3(p.B), dim3(256), 0, st, p);
     return CW_OK;
 }
+
+}  // namespace CW_NS

@@ -14,6 +14,10 @@
 
 static thread_local char g_err[512] = "";
 
+// dtype dispatch: the 16-bit kernels exist twice (namespace cw_bf16 / cw_f16, see kernels.h); the f32 parity kernels are
+// identical in both builds
+#define KD(c, fn, ...) ((c)->f16 ? cw_f16::fn(__VA_ARGS__) : cw_bf16::fn(__VA_ARGS__))
+
 struct LayerW {
     void* wqkv = nullptr; float* bqkv = nullptr;
     void* wo = nullptr; float* bo = nullptr;
@@ -33,7 +37,8 @@ struct LayerW {
 
 struct cw_ctx {
     cw_model_desc d;
-    bool bf16 = false;
+    bool bf16 = false;         // 16-bit engine (bfloat16 or, with f16, IEEE binary16 -- the reference's GPU dtype)
+    bool f16 = false;
     int device = 0;
     int Bm = 0, S_pad = 0, Vpad = 0;
     size_t esz = 4;
@@ -158,7 +163,8 @@ static int dmalloc(cw_ctx* c, P** p, size_t bytes, bool zero = true) {
 static int upload_T(cw_ctx* c, void* dst, size_t off, const float* src, size_t n, float scale = 1.0f) {
     if (c->bf16) {
         std::vector<bf16_t> tmp(n);
-        for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16(src[i] * scale);
+        if (c->f16) for (size_t i = 0; i < n; ++i) tmp[i] = cw_host_f32_to_f16(src[i] * scale);
+        else for (size_t i = 0; i < n; ++i) tmp[i] = cw_host_f32_to_bf16(src[i] * scale);
         HIPCHK(c, hipMemcpy((bf16_t*)dst + off, tmp.data(), n * 2, hipMemcpyHostToDevice));
     } else if (scale != 1.0f) {
         std::vector<float> tmp(n);
@@ -184,7 +190,7 @@ static int download_T(cw_ctx* c, const void* src, size_t off, float* dst, size_t
     if (c->bf16) {
         std::vector<bf16_t> tmp(n);
         HIPCHK(c, hipMemcpy(tmp.data(), (const bf16_t*)src + off, n * 2, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) dst[i] = bf16_to_f32(tmp[i]);
+        for (size_t i = 0; i < n; ++i) dst[i] = c->f16 ? cw_host_f16_to_f32(tmp[i]) : cw_host_bf16_to_f32(tmp[i]);
     } else {
         HIPCHK(c, hipMemcpy(dst, (const float*)src + off, n * 4, hipMemcpyDeviceToHost));
     }
@@ -233,7 +239,9 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_step[0], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_step[1], hipEventDisableTiming));
     HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
-    c->bf16 = d.dtype == CW_DTYPE_BF16;
+    if (d.dtype != CW_DTYPE_F32 && d.dtype != CW_DTYPE_BF16 && d.dtype != CW_DTYPE_F16) return fail(c, CW_ERR_INVALID, "unknown dtype %d", d.dtype);
+    c->f16 = d.dtype == CW_DTYPE_F16;
+    c->bf16 = d.dtype == CW_DTYPE_BF16 || c->f16;
     if (getenv("CW_NO_GRAPH")) c->use_graph = false;
     if (getenv("CW_NO_LN_FOLD")) c->fold_enabled = false;
     c->esz = c->bf16 ? 2 : 4;
@@ -481,7 +489,7 @@ static int apply_folds(cw_ctx* c) {
         LayerW& L = c->dec[f.layer];
         const float* g = f.which == 0 ? L.ln1_g : (f.which == 1 ? L.lnc_g : L.ln2_g);
         const float* b = f.which == 0 ? L.ln1_b : (f.which == 1 ? L.lnc_b : L.ln2_b);
-        CWCHK(c, cw_launch_fold_layernorm(f.stage, f.N, f.K, g, b, f.scale, (bf16_t*)f.w_dst + f.w_off, f.b_dst + f.b_off, c->st));
+        CWCHK(c, KD(c, cw_launch_fold_layernorm, f.stage, f.N, f.K, g, b, f.scale, (bf16_t*)f.w_dst + f.w_off, f.b_dst + f.b_off, c->st));
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
     for (auto& f : c->folds) hipFree(f.stage);
@@ -612,8 +620,8 @@ int32_t cw_upload_pcm(cw_ctx* c, const float* pcm, int32_t B, const int32_t* n_s
 int32_t cw_mel_resident(cw_ctx* c, int32_t B) {
     if (B < 1 || B > c->Bm) return fail(c, CW_ERR_INVALID, "B=%d out of range", B);
     StageTimer tm(c, CW_STAGE_MEL);
-    CWCHK(c, cw_launch_mel(c->mel, c->d_pcm, B, c->d.n_mels, c->d_logspec, c->d_gmax, c->st));
-    CWCHK(c, cw_launch_mel_finish(c->d_logspec, c->d_gmax, B, c->d.n_mels, c->d_feats_tm, c->bf16 ? 1 : 0, c->d_feats_hf, c->st));
+    CWCHK(c, KD(c, cw_launch_mel, c->mel, c->d_pcm, B, c->d.n_mels, c->d_logspec, c->d_gmax, c->st));
+    CWCHK(c, KD(c, cw_launch_mel_finish, c->d_logspec, c->d_gmax, B, c->d.n_mels, c->d_feats_tm, c->bf16 ? 1 : 0, c->d_feats_hf, c->st));
     KCHK(c);
     tm.stop();
     return CW_OK;
@@ -674,42 +682,42 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
     {   // conv1 + GELU (modeling_whisper.py:618) as implicit GEMM over time-major features
         AParams ap{c->d_feats_tm, 0, 1, CW_N_FRAMES, NM, 1, c->d_row_off, c->d_row_valid};
         EpiParams ep = epi0(); ep.out = c->c1; ep.bias = c->conv1_b; ep.ldo = D;
-        CWCHK(c, cw_launch_gemm(bf, EPI_GELU, ap, c->conv1_w, nb * CW_N_FRAMES, D, 3 * NM, ep, c->st));
+        CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_GELU, ap, c->conv1_w, nb * CW_N_FRAMES, D, 3 * NM, ep, c->st));
     }
     {   // conv2 (stride 2) + GELU + sinusoidal positions (:619-624) -> f32 residual stream
         AParams ap{c->c1, 0, 1, S, D, 2, c->d_row_off2, c->d_row_valid2};
         EpiParams ep = epi0(); ep.outf = c->x; ep.bias = c->conv2_b; ep.ldo = D; ep.pos = c->enc_pos; ep.T = S;
-        CWCHK(c, cw_launch_gemm(bf, EPI_GELU_POS_F32, ap, c->conv2_w, nb * S, D, 3 * D, ep, c->st));
+        CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_GELU_POS_F32, ap, c->conv2_w, nb * S, D, 3 * D, ep, c->st));
     }
     const int M = nb * S;
     for (int l = 0; l < c->d.enc_layers; ++l) {
         LayerW& L = c->enc[l];
-        CWCHK(c, cw_launch_layernorm(bf, c->x, L.ln1_g, L.ln1_b, c->h, M, D, c->st));
+        CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, L.ln1_g, L.ln1_b, c->h, M, D, c->st));
         {
             AParams ap{c->h, D, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.out = c->qb; ep.out1 = c->kb; ep.out2 = c->vb; ep.bias = L.bqkv;
             ep.T = S; ep.S_pad = c->S_pad; ep.H = H; ep.d_model = D;
-            CWCHK(c, cw_launch_gemm(bf, EPI_HEADS, ap, L.wqkv, M, 3 * D, D, ep, c->st));
+            CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_HEADS, ap, L.wqkv, M, 3 * D, D, ep, c->st));
         }
-        CWCHK(c, cw_launch_attn_encoder(bf, c->qb, c->kb, c->vb, c->ao, nb, H, S, c->S_pad, c->st));
+        CWCHK(c, KD(c, cw_launch_attn_encoder, bf, c->qb, c->kb, c->vb, c->ao, nb, H, S, c->S_pad, c->st));
         {
             AParams ap{c->ao, D, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.outf = c->x; ep.resid = c->x; ep.bias = L.bo; ep.ldo = D;
-            CWCHK(c, cw_launch_gemm(bf, EPI_RESID_F32, ap, L.wo, M, D, D, ep, c->st));
+            CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_RESID_F32, ap, L.wo, M, D, D, ep, c->st));
         }
-        CWCHK(c, cw_launch_layernorm(bf, c->x, L.ln2_g, L.ln2_b, c->h, M, D, c->st));
+        CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, L.ln2_g, L.ln2_b, c->h, M, D, c->st));
         {
             AParams ap{c->h, D, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.out = c->mid; ep.bias = L.b1; ep.ldo = F;
-            CWCHK(c, cw_launch_gemm(bf, EPI_GELU, ap, L.w1, M, F, D, ep, c->st));
+            CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_GELU, ap, L.w1, M, F, D, ep, c->st));
         }
         {
             AParams ap{c->mid, F, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.outf = c->x; ep.resid = c->x; ep.bias = L.b2; ep.ldo = D;
-            CWCHK(c, cw_launch_gemm(bf, EPI_RESID_F32, ap, L.w2, M, D, F, ep, c->st));
+            CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_RESID_F32, ap, L.w2, M, D, F, ep, c->st));
         }
     }
-    CWCHK(c, cw_launch_layernorm(bf, c->x, c->enc_ln_g, c->enc_ln_b, c->enc_out, M, D, c->st));
+    CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, c->enc_ln_g, c->enc_ln_b, c->enc_out, M, D, c->st));
     KCHK(c);
     tm.stop();
     StageTimer tk(c, CW_STAGE_CROSS_KV);
@@ -718,8 +726,8 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
         AParams ap{c->enc_out, D, 0, 0, 0, 0, nullptr, nullptr};
         EpiParams ep = epi0(); ep.out = L.ck; ep.out1 = L.cv; ep.bias = L.bkv_c;
         ep.T = S; ep.S_pad = S; ep.H = H; ep.d_model = D;
-        CWCHK(c, cw_launch_gemm(bf, EPI_HEADS, ap, L.wkv_c, M, 2 * D, D, ep, c->st));
-        if (c->kv8) CWCHK(c, cw_launch_kv_quant_fp8(L.ck, L.cv, L.ck8, L.cv8, L.kvs, nb, H, S, c->st));
+        CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_HEADS, ap, L.wkv_c, M, 2 * D, D, ep, c->st));
+        if (c->kv8) CWCHK(c, KD(c, cw_launch_kv_quant_fp8, L.ck, L.cv, L.ck8, L.cv8, L.kvs, nb, H, S, c->st));
     }
     KCHK(c);
     tk.stop();
@@ -738,10 +746,10 @@ int32_t cw_get_encoder_output(cw_ctx* c, float* out, int32_t nb) {
 // ------------------------------------------------------------------------------------------------
 static int gemv_ln(cw_ctx* c, int epi, const float* x, int Mb, int K, const void* W, int N, const float* g,
                    const float* b, const EpiParams& ep) {
-    if (c->bf16 || !g) return cw_launch_gemv(c->bf16, epi, x, Mb, K, W, N, g, b, ep, c->st, nullptr, c->d_xfrag);
-    int r = cw_launch_layernorm_f32(x, g, b, c->dxn, Mb, K, c->st);   // f32 parity mode: unfused LN
+    if (c->bf16 || !g) return KD(c, cw_launch_gemv, c->bf16, epi, x, Mb, K, W, N, g, b, ep, c->st, nullptr, c->d_xfrag);
+    int r = KD(c, cw_launch_layernorm_f32, x, g, b, c->dxn, Mb, K, c->st);   // f32 parity mode: unfused LN
     if (r != CW_OK) return r;
-    return cw_launch_gemv(false, epi, c->dxn, Mb, K, W, N, nullptr, nullptr, ep, c->st);
+    return KD(c, cw_launch_gemv, false, epi, c->dxn, Mb, K, W, N, nullptr, nullptr, ep, c->st);
 }
 
 // One decoder forward for the nb rows at the positions held in c->d_pos (device): 8 launches per layer.
@@ -761,11 +769,11 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
             if (frag) p.out_frag = (unsigned short*)c->d_xfrag2;
             if (c->beam_K > 0) p.anc = c->d_anc;
-            CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
+            CWCHK(c, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
-            if (frag) CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
+            if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));
         }
         {   // cross-attention: LN + q projection, attention over the cached encoder K/V
@@ -780,17 +788,17 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             p.kv_div = c->beam_K > 0 ? c->beam_K : 1;
             if (c->kv8) {
                 p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs;
-                CWCHK(c, cw_launch_attn_cross_split_fp8(p, c->st));
-            } else CWCHK(c, cw_launch_attn_cross_split(true, p, c->st));
+                CWCHK(c, KD(c, cw_launch_attn_cross_split_fp8, p, c->st));
+            } else CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CombineParams cb{c->d_part_ml, H, nb * D};
-            CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
+            CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
         } else {
             DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn, nb, H);
             p.align_out = c->d.n_align > 0 ? c->d_align : nullptr; p.align_slot = c->d_align_slot + (size_t)l * H;
             p.n_align = c->d.n_align; p.align_rows = TGT;
             p.kv_div = c->beam_K > 0 ? c->beam_K : 1;
-            CWCHK(c, cw_launch_attn_decode(c->bf16, p, c->st));
+            CWCHK(c, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo_c, D, nullptr, nullptr, ep));
         }
@@ -800,7 +808,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.b2; ep.ldo = D;
-            if (frag) CWCHK(c, cw_launch_gemv(true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
+            if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
         }
     }
@@ -823,9 +831,9 @@ static int launch_sample(cw_ctx* c, int nb, bool forced) {
     sp.argmax_trace = c->d_argmax; sp.last_ts_tok = c->d_last_ts; sp.finished = c->d_finished;
     sp.n_unfinished = c->d_nunf;
     sp.embed = c->embed; sp.pos_embed = c->dec_pos; sp.x_out = c->dx; sp.d = c->d.d_model; sp.embed_bf16 = c->bf16 ? 1 : 0;
-    sp.partials = (const SamplePart*)c->d_sample_part;
+    sp.partials = c->d_sample_part;
     (void)forced;
-    return cw_launch_sample(sp, c->st);
+    return KD(c, cw_launch_sample, sp, c->st);
 }
 
 // decoder forward + logits + sampling for one position, captured once per batch size as a hipGraph
@@ -881,12 +889,12 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
 
     // prompt positions 0 .. n_prompt-2: forward only (their alignment rows are recorded, :254-256)
     for (int pos = 0; pos + 1 < n_prompt; ++pos) {
-        CWCHK(c, cw_launch_set_pos(c->d_pos, pos, nb, c->st));
-        CWCHK(c, cw_launch_embed(c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
+        CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, pos, nb, c->st));
+        CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
         CWCHK(c, decode_step(c, nb, false));
     }
-    CWCHK(c, cw_launch_set_pos(c->d_pos, n_prompt - 1, nb, c->st));
-    CWCHK(c, cw_launch_embed(c->d_ids, TGT, n_prompt - 1, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
+    CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, n_prompt - 1, nb, c->st));
+    CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, n_prompt - 1, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
     int t = n_prompt, step = 0;
     // Host/device overlap: the "rows still running" counter of step s lands in its own pinned slot and is only
     // *read* after step s+1 has been queued (one step of lag, so the GPU never waits for the host; at most one
@@ -949,7 +957,7 @@ int32_t cw_set_logits_capture(cw_ctx* c, float* host_buf, int32_t max_steps) {
 
 static int normalize_alignment(cw_ctx* c) {
     if (!c->align_unnormalized) return CW_OK;
-    CWCHK(c, cw_launch_align_normalize(c->d_align, c->d_align_ml, c->last_nb, c->d.n_align, c->d.max_target_positions,
+    CWCHK(c, KD(c, cw_launch_align_normalize, c->d_align, c->d_align_ml, c->last_nb, c->d.n_align, c->d.max_target_positions,
                                        c->last_L, CW_N_CTX, c->st));
     c->align_unnormalized = false;
     return CW_OK;
@@ -1012,12 +1020,12 @@ int32_t cw_beam_begin(cw_ctx* c, int32_t n_items, int32_t num_beams, const int32
     c->beam_K = num_beams; c->beam_items = n_items; c->beam_n_prompt = n_prompt;
     c->align_cur = c->d_align;
     for (int pos = 0; pos + 1 < n_prompt; ++pos) {          // prompt positions: forward only
-        CWCHK(c, cw_launch_set_pos(c->d_pos, pos, rows, c->st));
-        CWCHK(c, cw_launch_embed(c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, rows, D, c->st));
+        CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, pos, rows, c->st));
+        CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, rows, D, c->st));
         CWCHK(c, decode_step(c, rows, false));
     }
-    CWCHK(c, cw_launch_set_pos(c->d_pos, n_prompt - 1, rows, c->st));
-    CWCHK(c, cw_launch_embed(c->d_ids, TGT, n_prompt - 1, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, rows, D, c->st));
+    CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, n_prompt - 1, rows, c->st));
+    CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, n_prompt - 1, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, rows, D, c->st));
     KCHK(c);
     c->last_nb = rows; c->last_L = n_prompt - 1;
     return CW_OK;
@@ -1037,7 +1045,7 @@ int32_t cw_beam_step(cw_ctx* c, int32_t n_cand, float* cand_logprob, int32_t* ca
     sp.max_initial_timestamp_index = c->gen.max_initial_timestamp_index;
     sp.cfg = c->d_cfg; sp.pos = c->d_pos; sp.ids_stride = c->d.max_target_positions; sp.ids = c->d_ids;
     sp.embed_bf16 = c->bf16 ? 1 : 0;
-    CWCHK(c, cw_launch_beam_topk(sp, n_cand, c->d_cand_val, c->d_cand_id, c->st));
+    CWCHK(c, KD(c, cw_launch_beam_topk, sp, n_cand, c->d_cand_val, c->d_cand_id, c->st));
     KCHK(c);
     tm.stop();
     HIPCHK(c, hipMemcpy(cand_logprob, c->d_cand_val, (size_t)rows * n_cand * 4, hipMemcpyDeviceToHost));
@@ -1063,7 +1071,7 @@ int32_t cw_beam_advance(cw_ctx* c, const int32_t* parent, const int32_t* token) 
     p.parent = c->d_parent; p.token = c->d_tok; p.pos = c->d_pos;
     p.embed = c->embed; p.pos_embed = c->dec_pos; p.x_out = c->dx; p.d = c->d.d_model; p.embed_bf16 = c->bf16 ? 1 : 0;
     p.rows = rows;
-    CWCHK(c, cw_launch_beam_advance(p, c->st));
+    CWCHK(c, KD(c, cw_launch_beam_advance, p, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));                   // parent / token are caller-owned host buffers
     return CW_OK;
 }
@@ -1079,7 +1087,7 @@ int32_t cw_beam_finish(cw_ctx* c, int32_t n_items, int32_t L, const int32_t* row
         c->last_nb = rows;
         CWCHK(c, normalize_alignment(c));
         HIPCHK(c, hipMemcpyAsync(c->d_rowmap, row_of_pos, (size_t)n_items * L * 4, hipMemcpyHostToDevice, c->st));
-        CWCHK(c, cw_launch_align_gather(c->d_align, c->d_rowmap, n_items, Ha, TGT, L, CW_N_CTX, c->d_align_g, c->st));
+        CWCHK(c, KD(c, cw_launch_align_gather, c->d_align, c->d_rowmap, n_items, Ha, TGT, L, CW_N_CTX, c->d_align_g, c->st));
         HIPCHK(c, hipStreamSynchronize(c->st));
         c->align_cur = c->d_align_g;
     }
@@ -1449,7 +1457,7 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
 }
 
 int32_t cw_test_set_option(const char* name, int32_t value) {
-    if (!strcmp(name, "gemm256_min_tiles")) { cw_gemm_set_256_min_tiles(value); return CW_OK; }
+    if (!strcmp(name, "gemm256_min_tiles")) { cw_bf16::cw_gemm_set_256_min_tiles(value); cw_f16::cw_gemm_set_256_min_tiles(value); return CW_OK; }
     return CW_ERR_INVALID;
 }
 
@@ -1463,7 +1471,7 @@ int32_t cw_test_gemm(cw_ctx* c, int32_t M, int32_t N, int32_t K, const float* A,
     if (bias) HIPCHK(c, hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
     AParams ap{dA, K, 0, 0, 0, 0, nullptr, nullptr};
     EpiParams ep = epi0(); ep.out = dO; ep.bias = bias ? dB : nullptr; ep.ldo = N;
-    int r = cw_launch_gemm(c->bf16, gelu ? EPI_GELU : EPI_STORE, ap, dW, M, N, K, ep, c->st);
+    int r = KD(c, cw_launch_gemm, c->bf16, gelu ? EPI_GELU : EPI_STORE, ap, dW, M, N, K, ep, c->st);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemm: %s", hipGetErrorString(er)); }
     if (r == CW_OK) r = download_T(c, dO, 0, out, (size_t)M * N);
     hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dB);
@@ -1484,8 +1492,8 @@ int32_t cw_test_gemv(cw_ctx* c, int32_t Mb, int32_t N, int32_t K, const float* x
     EpiParams ep = epi0(); ep.outf = dO; ep.bias = bias ? dB : nullptr; ep.ldo = N;
     int r = CW_OK;
     const float* xin = dx;
-    if (ln_g && !c->bf16) { r = cw_launch_layernorm_f32(dx, dg, db, dxn, Mb, K, c->st); xin = dxn; }
-    if (r == CW_OK) r = cw_launch_gemv(c->bf16, gelu ? EPI_GELU_F32 : EPI_STORE_F32, xin, Mb, K, dW, N,
+    if (ln_g && !c->bf16) { r = KD(c, cw_launch_layernorm_f32, dx, dg, db, dxn, Mb, K, c->st); xin = dxn; }
+    if (r == CW_OK) r = KD(c, cw_launch_gemv, c->bf16, gelu ? EPI_GELU_F32 : EPI_STORE_F32, xin, Mb, K, dW, N,
                                         (ln_g && c->bf16) ? dg : nullptr, (ln_g && c->bf16) ? db : nullptr, ep, c->st, nullptr, c->d_xfrag);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemv: %s", hipGetErrorString(er)); }
     else fail(c, r, "test_gemv: launch rejected (Mb=%d N=%d K=%d)", Mb, N, K);
@@ -1506,7 +1514,7 @@ int32_t cw_test_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, const floa
         CWCHK(c, upload_T(c, dk, (size_t)bh * S_pad * 64, k + (size_t)bh * S * 64, (size_t)S * 64));
         CWCHK(c, upload_T(c, dv, (size_t)bh * S_pad * 64, v + (size_t)bh * S * 64, (size_t)S * 64));
     }
-    int r = cw_launch_attn_encoder(c->bf16, dq, dk, dv, dout, B, H, S, S_pad, c->st);
+    int r = KD(c, cw_launch_attn_encoder, c->bf16, dq, dk, dv, dout, B, H, S, S_pad, c->st);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_attention: %s", hipGetErrorString(er)); }
     if (r == CW_OK) r = download_T(c, dout, 0, out, (size_t)B * S * H * 64);
     hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout);
@@ -1565,7 +1573,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
         hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
         if (which == 100) {
             HIPCHK(c, hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
-            for (int i = 0; i < iters; ++i) cw_launch_set_pos(c->d_pos, 64, nb, c->st);
+            for (int i = 0; i < iters; ++i) KD(c, cw_launch_set_pos, c->d_pos, 64, nb, c->st);
             HIPCHK(c, hipStreamEndCapture(c->st, &g));
             HIPCHK(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             HIPCHK(c, hipGraphLaunch(ge, c->st));
@@ -1573,7 +1581,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
         }
         HIPCHK(c, hipEventRecord(c->ev0, c->st));
         if (which == 100) { for (int r = 0; r < 5; ++r) HIPCHK(c, hipGraphLaunch(ge, c->st)); }
-        else for (int r = 0; r < 5; ++r) for (int i = 0; i < iters; ++i) cw_launch_set_pos(c->d_pos, 64, nb, c->st);
+        else for (int r = 0; r < 5; ++r) for (int i = 0; i < iters; ++i) KD(c, cw_launch_set_pos, c->d_pos, 64, nb, c->st);
         HIPCHK(c, hipEventRecord(c->ev1, c->st));
         HIPCHK(c, hipEventSynchronize(c->ev1));
         float ms = 0.f;
@@ -1602,11 +1610,11 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
                 if (c->bf16) {
                     CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml, nullptr, c->d_align_ml, nullptr,
                                        c->d_pos, 0, 0, nb, H};
-                    if (c->kv8) { p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs; return cw_launch_attn_cross_split_fp8(p, c->st); }
-                    return cw_launch_attn_cross_split(true, p, c->st);
+                    if (c->kv8) { p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs; return KD(c, cw_launch_attn_cross_split_fp8, p, c->st); }
+                    return KD(c, cw_launch_attn_cross_split, true, p, c->st);
                 }
                 DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, nullptr, c->dattn, nb, H);
-                return cw_launch_attn_decode(c->bf16, p, c->st);
+                return KD(c, cw_launch_attn_decode, c->bf16, p, c->st);
             }
             case 2: {   // self-attention out projection (in-place residual, K split)
                 EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
@@ -1627,18 +1635,18 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
             }
             case 6: {   // self-attention at the positions in d_pos
                 DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
-                return cw_launch_attn_decode(c->bf16, p, c->st);
+                return KD(c, cw_launch_attn_decode, c->bf16, p, c->st);
             }
             case 7: {   // logits
                 EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = c->Vpad;
                 return gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep);
             }
             case 8:     // near-empty kernel: launch/boundary floor
-                return cw_launch_set_pos(c->d_pos, 64, nb, c->st);
+                return KD(c, cw_launch_set_pos, c->d_pos, 64, nb, c->st);
             default: return CW_ERR_INVALID;
         }
     };
-    if (which == 6 || which == 3) { CWCHK(c, cw_launch_set_pos(c->d_pos, 64, nb, c->st)); }
+    if (which == 6 || which == 3) { CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 64, nb, c->st)); }
     for (int i = 0; i < 3; ++i) CWCHK(c, launch());
     HIPCHK(c, hipEventRecord(c->ev0, c->st));
     for (int i = 0; i < iters; ++i) CWCHK(c, launch());

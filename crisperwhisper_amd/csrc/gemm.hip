@@ -25,18 +25,16 @@
 #include <stdlib.h>
 #include <mutex>
 
+namespace CW_NS {
+
 #define BM 128
 #define BN 128
 #define BK 64
 #define LDS_STRIDE 72  // bf16 per LDS row: 64 + 8 pad (144 B) keeps ds_read_b128 fragment reads spread
 
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-__device__ inline f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a),
-                                                   __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
-}
+__device__ inline f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return cw_mfma_16x16x32(a, b, c); }
 
 // Address of A row `m`, starting at K offset k0 (k0 % 64 == 0).  Returns nullptr for a zero row.
 template <typename TA>
@@ -1287,3 +1285,5 @@ int cw_launch_fold_layernorm(const float* Wf, int N, int K, const float* g, cons
     hipLaunchKernelGGL(fold_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, st, Wf, N, K, g, beta, scale, (bf16_t*)w_out, bias);
     return CW_OK;
 }
+
+}  // namespace CW_NS

@@ -12,22 +12,10 @@ struct AParams {
     const int* row_valid;  // [batch] valid input rows in the window (beyond -> zeros)
 };
 
-int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
-                   hipStream_t st);
-void cw_gemm_set_256_min_tiles(int n);   // test hook: tile count from which the 256x256 GEMM is used (default 200)
 struct CombineParams;
 // ln_g != null, ln_b == null: plain normalisation (x - mean) * rstd -- the affine part lives in W / bias (fold_layernorm)
-int cw_launch_fold_layernorm(const float* Wf, int N, int K, const float* g, const float* beta, float scale, void* w_out,
-                             float* bias, hipStream_t st);
-int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
-                   const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr,
-                   void* scratch = nullptr /* bf16 [64][5120]: enables the one-pass path for 17..64 rows */);
 
 // elementwise.hip
-int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d,
-                        hipStream_t st);
-int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d,
-                            hipStream_t st);
 
 struct SampleParams {
     const float* logits;       // [B][ldv], rows 16-byte aligned
@@ -49,12 +37,10 @@ struct SampleParams {
     float* x_out;              // [B][d] f32
     int d;
     int embed_bf16;
-    const struct SamplePart* partials;   // [B][SAMPLE_NS] slice records (32 bytes each), written by stage 1 of the sampler
+    const void* partials;      // [B][SAMPLE_NS] slice records (32 bytes each), written by stage 1 of the sampler
 };
-int cw_launch_sample(const SampleParams& p, hipStream_t st);
 // beam search (elementwise.hip): per row the n_cand best processed log-probabilities of the next token
 // (log_softmax of the raw logits, then the same processors as the greedy path) ...
-int cw_launch_beam_topk(const SampleParams& p, int n_cand, float* cand_val, int* cand_id, hipStream_t st);
 // ... and the re-ordering of the per-row state after the host picked (parent row, token) for every row
 struct BeamAdvanceParams {
     int* ids; int* ids_tmp; int ids_stride;      // [rows][stride] token history
@@ -64,16 +50,8 @@ struct BeamAdvanceParams {
     const void* embed; const float* pos_embed; float* x_out; int d; int embed_bf16;
     int rows;
 };
-int cw_launch_beam_advance(const BeamAdvanceParams& p, hipStream_t st);
-int cw_launch_align_gather(const float* align, const int* row_of_pos, int n_items, int n_align, int align_rows, int L,
-                           int n_keys, float* out, hipStream_t st);
-int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st);
-int cw_launch_embed(const int* ids, int ids_stride, int t, const void* embed, int embed_bf16, const float* pos_embed,
-                    float* x_out, int B, int d, hipStream_t st);
 
 // attention.hip
-int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* V, void* out, int B, int H, int S,
-                           int S_pad, hipStream_t st);
 struct DecAttnParams {
     const float* q;        // [B][H*64] f32, already scaled
     const void* K;         // [B][H][cap][64] T
@@ -90,7 +68,6 @@ struct DecAttnParams {
     int kv_div;            // > 1: query rows b share cache row b / kv_div (beams of one audio item; cross-attention)
     const int* anc;        // non-null: [B][cap] cache row holding key k of query row b (beam-search self-attention)
 };
-int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st);
 
 // Cross-attention decode split over the 1500 keys (flash-decoding): ATT_NS blocks per (batch, head) write
 // un-normalised partial outputs + (max, sum); the consumer GEMV combines them while loading its activations,
@@ -116,13 +93,7 @@ struct CrossSplitParams {
     const float* kv_scale; // fp8 cache only: [B][H][2] dequantisation scales of K and V (null: K/V hold T)
     int kv_div;            // > 1: rows b share the K/V of audio item b / kv_div (beam search)
 };
-int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st);
 // opt-in fp8 (OCP e4m3) cross-attention cache: quantise one layer's bf16 K/V [B][H][S][64] with a scale per (b, h, K|V)
-int cw_launch_kv_quant_fp8(const void* K, const void* V, void* K8, void* V8, float* kv_scale, int B, int H, int S,
-                           hipStream_t st);
-int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st);
-int cw_launch_align_normalize(float* align, const float* align_ml, int B, int n_align, int align_rows, int L,
-                              int n_keys, hipStream_t st);
 struct CombineParams {     // activations of a GEMV = combination of ATT_NS attention partials
     const float* part_ml;  // null: plain activations
     int H;                 // heads
@@ -136,10 +107,34 @@ struct MelTables {
     const double* window; // [400]
     const float* filters; // [201][n_mels]
 };
-int cw_launch_mel(const MelTables& t, const float* pcm, int B, int n_mels, float* logspec_tm, unsigned int* gmax,
-                  hipStream_t st);
-int cw_launch_mel_finish(const float* logspec_tm, const unsigned int* gmax, int B, int n_mels, void* feats_tm,
-                         int feats_bf16, float* feats_hf, hipStream_t st);
+
+
+// ---- launchers of the dtype-dependent translation units (gemm / attention / elementwise / mel .hip), compiled twice:
+// namespace cw_bf16 (bfloat16 build) and cw_f16 (-DCW_F16, IEEE binary16); `bool bf16` = "16-bit engine" in both, false
+// selects the f32 parity kernels (identical in the two builds).
+#define CW_DTYPE_KERNEL_DECLS \
+    int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep, hipStream_t st); \
+    void cw_gemm_set_256_min_tiles(int n); \
+    int cw_launch_fold_layernorm(const float* Wf, int N, int K, const float* g, const float* beta, float scale, void* w_out, float* bias, hipStream_t st); \
+    int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr, void* scratch = nullptr ); \
+    int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d, hipStream_t st); \
+    int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d, hipStream_t st); \
+    int cw_launch_sample(const SampleParams& p, hipStream_t st); \
+    int cw_launch_beam_topk(const SampleParams& p, int n_cand, float* cand_val, int* cand_id, hipStream_t st); \
+    int cw_launch_beam_advance(const BeamAdvanceParams& p, hipStream_t st); \
+    int cw_launch_align_gather(const float* align, const int* row_of_pos, int n_items, int n_align, int align_rows, int L, int n_keys, float* out, hipStream_t st); \
+    int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st); \
+    int cw_launch_embed(const int* ids, int ids_stride, int t, const void* embed, int embed_bf16, const float* pos_embed, float* x_out, int B, int d, hipStream_t st); \
+    int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* V, void* out, int B, int H, int S, int S_pad, hipStream_t st); \
+    int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st); \
+    int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st); \
+    int cw_launch_kv_quant_fp8(const void* K, const void* V, void* K8, void* V8, float* kv_scale, int B, int H, int S, hipStream_t st); \
+    int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st); \
+    int cw_launch_align_normalize(float* align, const float* align_ml, int B, int n_align, int align_rows, int L, int n_keys, hipStream_t st); \
+    int cw_launch_mel(const MelTables& t, const float* pcm, int B, int n_mels, float* logspec_tm, unsigned int* gmax, hipStream_t st); \
+    int cw_launch_mel_finish(const float* logspec_tm, const unsigned int* gmax, int B, int n_mels, void* feats_tm, int feats_bf16, float* feats_hf, hipStream_t st);
+namespace cw_bf16 { CW_DTYPE_KERNEL_DECLS }
+namespace cw_f16 { CW_DTYPE_KERNEL_DECLS }
 
 // ingest.hip
 int cw_launch_pcm_to_mono(const void* raw, int fmt, int channels, long long n_frames, float* out, hipStream_t st);

@@ -12,6 +12,8 @@
 #include "common.h"
 #include "kernels.h"
 
+namespace CW_NS {
+
 #define MEL_FR 16       // frames per block
 #define N_FFT 400
 #define HOP 160
@@ -172,3 +174,5 @@ int cw_launch_mel_finish(const float* logspec_tm, const unsigned int* gmax, int 
                            (float*)feats_tm, feats_hf);
     return CW_OK;
 }
+
+}  // namespace CW_NS

@@ -63,7 +63,8 @@ class EngineError(RuntimeError):
 class Engine:
     def __init__(self, spec: ModelSpec, dtype: str = "bf16", max_batch: int = 16, device: int = 0,
                  cross_kv_dtype: Optional[str] = None):
-        """``cross_kv_dtype="fp8"`` (bf16 engine only): the decode step streams an OCP e4m3 copy of the cross-attention
+        """``dtype``: "f32" (parity engine), "bf16" or "f16" (the 16-bit MFMA engine in bfloat16 / IEEE binary16).
+        ``cross_kv_dtype="fp8"`` (16-bit engines only): the decode step streams an OCP e4m3 copy of the cross-attention
         cache, half the bytes of its dominant stream -- an accuracy-gated performance mode, not the parity path."""
         self.lib = N.load()
         self.spec = spec
@@ -77,7 +78,7 @@ class Engine:
             d_model=spec.d_model, n_heads=spec.n_heads, ffn_dim=spec.ffn_dim, enc_layers=spec.enc_layers,
             dec_layers=spec.dec_layers, n_mels=spec.n_mels, vocab_size=spec.vocab_size,
             max_target_positions=spec.max_target_positions, median_filter_width=spec.median_filter_width,
-            dtype={"f32": N.CW_DTYPE_F32, "fp32": N.CW_DTYPE_F32, "bf16": N.CW_DTYPE_BF16}[dtype],
+            dtype={"f32": N.CW_DTYPE_F32, "fp32": N.CW_DTYPE_F32, "bf16": N.CW_DTYPE_BF16, "f16": N.CW_DTYPE_F16, "fp16": N.CW_DTYPE_F16}[dtype],
             max_batch=self.max_batch, n_align=len(al),
             align_layers=al.ctypes.data_as(C.POINTER(C.c_int32)), align_heads=ah.ctypes.data_as(C.POINTER(C.c_int32)))
         self.ctx = self.lib.cw_create(C.byref(desc), int(device))

@@ -148,10 +148,9 @@ def _dtype_name(dtype) -> str:
     s = str(dtype)
     if "float32" in s or s in ("f32", "fp32"):
         return "f32"
-    if "float16" in s and "bfloat16" not in s:
-        _warn_once("fp16", "torch_dtype=float16 requested (REF/transcribe.py:10): the engine computes in bfloat16 "
-                           "(same MFMA rate on gfx950, 8 instead of 11 significand bits, no fp16 overflow clamp needed)")
-    return "bf16"          # float16 / bfloat16 requests run the bf16 MFMA path
+    if ("float16" in s and "bfloat16" not in s) or s in ("f16", "fp16", "half"):
+        return "f16"       # the reference's GPU dtype (REF/transcribe.py:10): the binary16 build of the MFMA engine
+    return "bf16"
 
 
 def _device_index(device) -> int:

@@ -25,6 +25,8 @@ typedef struct cw_ctx cw_ctx;
 
 #define CW_DTYPE_F32 0   /* parity mode: f32 weights, activations and arithmetic                       */
 #define CW_DTYPE_BF16 1  /* performance mode: bf16 weights/activations, f32 accumulation + residuals   */
+#define CW_DTYPE_F16 2   /* same engine in IEEE binary16, the reference's GPU dtype (REF/transcribe.py:10,  */
+                         /* REF/app.py:111): same MFMA rate, 3 more significand bits than bfloat16           */
 
 #define CW_N_SAMPLES 480000  /* 30 s @ 16 kHz  (TF/models/whisper/feature_extraction_whisper.py:88-93) */
 #define CW_N_FRAMES 3000     /* mel frames per window                                                  */

@@ -37,6 +37,15 @@ def eng_bf16(tiny):
     e.close()
 
 
+@pytest.fixture(scope="module")
+def eng_f16(tiny):
+    g, v, W, spec = tiny
+    e = Engine(spec, dtype="f16", max_batch=4)
+    e.load_state_dict(W)
+    yield e
+    e.close()
+
+
 def _first_window_feats(g):
     x = syn.synth_audio(0, 70 * 16000, "mixed")[:480000]
     return OM.log_mel(x[None], g.n_mels)
@@ -64,10 +73,10 @@ def test_encoder_seek_window_matches_oracle(tiny, eng_f32):
     assert np.abs(enc[1] - ref[0]).max() < 1e-3
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
-def test_teacher_forced_decoder(tiny, eng_f32, eng_bf16, mode):
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
+def test_teacher_forced_decoder(tiny, eng_f32, eng_bf16, eng_f16, mode):
     g, v, W, spec = tiny
-    eng = eng_f32 if mode == "f32" else eng_bf16
+    eng = {"f32": eng_f32, "bf16": eng_bf16, "f16": eng_f16}[mode]
     z = Hh.gold_npz("e2e_golden.npz")
     ids = z["tf/ids"]                                   # [1, 3 + 12]
     T = ids.shape[1]
@@ -83,13 +92,16 @@ def test_teacher_forced_decoder(tiny, eng_f32, eng_bf16, mode):
     want = ref_logits[2:T - 1]
     if mode == "f32":
         assert np.abs(got - want).max() < 2e-3
+    elif mode == "f16":
+        assert np.abs(got - want).max() < 0.04          # binary16: 3 more significand bits than bfloat16
+        assert (got.argmax(-1) == want.argmax(-1)).mean() >= 0.9
     else:
         assert np.abs(got - want).max() < 0.25          # bf16 weights/activations, logits std ~2
         assert (got.argmax(-1) == want.argmax(-1)).mean() >= 0.9
     al = eng.alignment(1, T - 1)                        # [1, Ha, T-1, 1500]
     # probability rows: f32 mode to 1e-5 abs; bf16 mode (bf16 q/K, f32 softmax) to 2e-2 abs on rows
     # whose peaks are O(0.1-1) -- the DTW input is z-scored so this is ~1e-2 relative
-    tol = 1e-5 if mode == "f32" else 2e-2
+    tol = {"f32": 1e-5, "f16": 4e-3, "bf16": 2e-2}[mode]
     assert np.abs(al[0] - z["tf/cross"][:, :T - 1]).max() < tol
     assert np.abs(al[0].sum(-1) - 1).max() < 1e-3       # rows are probability vectors
 
@@ -445,7 +457,8 @@ def _aligned_weights(g, seed=0):
     return Lazy()
 
 
-def test_bench_shape_bf16_timestamps_and_words_vs_transformers():
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_bench_shape_bf16_timestamps_and_words_vs_transformers(dtype):
     """Parity of the TIMED path at the TIMED shape (BASELINE configs[1] = what bench.py runs): bf16 engine, large-v3
     geometry (32 + 32 layers), B = 8 x 30 s clips in one batch, 128 tokens per generate pass -- against the reference
     pipeline run through transformers 5.15.0 on the CPU in fp32 (tests/golden/gen_golden_bench.py), teacher-forced on
@@ -475,7 +488,7 @@ def test_bench_shape_bf16_timestamps_and_words_vs_transformers():
     tb = v.timestamp_begin
     n_prompt = 3
     T = n_prompt + n_tok
-    eng = Engine(spec, dtype="bf16", max_batch=B)
+    eng = Engine(spec, dtype=dtype, max_batch=B)
     try:
         eng.load_state_dict(_aligned_weights(g, gold["weight_seed"]))
         _, nf = eng.mel(clips)
@@ -515,7 +528,7 @@ def test_bench_shape_bf16_timestamps_and_words_vs_transformers():
                 n_tokens += d.size; n_close += int((d <= 0.02 + 1e-6).sum()); worst = max(worst, float(d.max()))
                 ours[i].append((np.asarray(p["sequences"][0], np.int64), t1[0].copy(), seek))
         frac = n_close / n_tokens
-        print(f"bench-shape bf16 parity: {n_close}/{n_tokens} token timestamps within 0.02 s ({100 * frac:.2f} %), worst {worst:.2f} s, "
+        print(f"bench-shape {dtype} parity: {n_close}/{n_tokens} token timestamps within 0.02 s ({100 * frac:.2f} %), worst {worst:.2f} s, "
               f"free-running top-1 agreement under teacher forcing {100 * agree:.1f} %")
         assert frac >= 0.99, (frac, worst)
         # ---- words: the reference's segment slicing (generation_whisper.py:1977-2074) + _decode_asr on the reference
@@ -567,7 +580,7 @@ def test_bench_shape_bf16_timestamps_and_words_vs_transformers():
             os.makedirs("gpurun_out", exist_ok=True)
             json.dump({"tokens_within_20ms": n_close, "tokens": n_tokens, "worst_s": worst, "words_within_20ms": n_words_close,
                        "words": n_words, "teacher_forced_top1_agreement": agree, "free_running_clips_same_text": same_text,
-                       "free_running_words_within_20ms": [same_words, tot_words]}, open("gpurun_out/parity_bench_shape.json", "w"))
+                       "free_running_words_within_20ms": [same_words, tot_words]}, open(f"gpurun_out/parity_bench_shape_{dtype}.json", "w"))
         except OSError:
             pass
     finally:

@@ -19,27 +19,34 @@ pytestmark = pytest.mark.gpu
 def engines():
     g, v, W, spec = Hh.tiny_setup()
     out = {}
-    for dt in ("f32", "bf16"):
+    for dt in ("f32", "bf16", "f16"):
         out[dt] = Engine(spec, dtype=dt, max_batch=4)
     yield out
     for e in out.values():
         e.close()
 
 
+def _round16(dt, *arrs):
+    """inputs rounded to the engine's 16-bit type, so the comparison isolates the kernel's own arithmetic"""
+    if dt == "bf16":
+        return tuple((t.view(np.uint32) & 0xFFFF0000).view(np.float32) for t in arrs)
+    if dt == "f16":
+        return tuple(t.astype(np.float16).astype(np.float32) for t in arrs)
+    return arrs
+
+
 def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1000, 384, 256), (77, 51, 64)])
 def test_gemm(engines, dt, tol, M, N, K):
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
-    if dt == "bf16":   # compare against the same bf16-rounded operands
-        import struct
-        A = (A.view(np.uint32) & 0xFFFF0000).view(np.float32); W = (W.view(np.uint32) & 0xFFFF0000).view(np.float32)
+    A, W = _round16(dt, A, W)   # compare against the same 16-bit-rounded operands
     for gelu in (False, True):
         ref = A.astype(np.float64) @ W.astype(np.float64).T + b
         if gelu:
@@ -70,7 +77,7 @@ def test_gemm_256_tile_kernel(engines, M, N, K):
         eng.lib.cw_test_set_option(b"gemm256_min_tiles", 200)
 
 
-@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
 @pytest.mark.parametrize("Mb,N,K", [(1, 128, 128), (3, 200, 256), (8, 1769, 128), (16, 64, 1280), (20, 128, 512), (40, 96, 1280), (64, 80, 256),
                                      (8, 5120, 1280), (5, 4160, 256), (12, 5120, 1280)])   # the last three: two column tiles per block (wide LayerNorm GEMV)
 def test_gemv_with_layernorm(engines, dt, tol, Mb, N, K):
@@ -79,8 +86,7 @@ def test_gemv_with_layernorm(engines, dt, tol, Mb, N, K):
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
     gam = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32); bet = (0.1 * rng.standard_normal(K)).astype(np.float32)
-    if dt == "bf16":
-        W = (W.view(np.uint32) & 0xFFFF0000).view(np.float32)
+    (W,) = _round16(dt, W)
     for ln in (None, (gam, bet)):
         for gelu in (False, True):
             xin = x if ln is None else OMOD.layer_norm(x, gam, bet)
@@ -91,7 +97,7 @@ def test_gemv_with_layernorm(engines, dt, tol, Mb, N, K):
             assert rel_err(got, ref) < tol, (dt, Mb, N, K, ln is not None, gelu, rel_err(got, ref))
 
 
-@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
 @pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 200), (1, 2, 1500)])
 def test_encoder_attention(engines, dt, tol, B, H, S):
     rng = np.random.default_rng(B + H + S)
@@ -99,8 +105,7 @@ def test_encoder_attention(engines, dt, tol, B, H, S):
     k = rng.standard_normal((B, H, S, 64)).astype(np.float32)
     v = rng.standard_normal((B, H, S, 64)).astype(np.float32)
     k[0, 0, S // 2] *= 6.0     # one dominant key: forces a running-max jump mid-stream
-    if dt == "bf16":
-        q, k, v = ((t.view(np.uint32) & 0xFFFF0000).view(np.float32) for t in (q, k, v))
+    q, k, v = _round16(dt, q, k, v)
     s = np.einsum("bhqd,bhkd->bhqk", q.astype(np.float64), k.astype(np.float64))
     p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
     ref = np.einsum("bhqk,bhkd->bhqd", p, v.astype(np.float64)).transpose(0, 2, 1, 3).reshape(B, S, H * 64)
