@@ -135,6 +135,11 @@ def cpu_reference(geometry, n_tok, threads, timeout_s, style="aligned"):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line (the JSON record): everything else any library writes to fd 1 -- RCCL prints a five-line
+    # version banner there, through C stdio, at communicator creation or at exit -- is diverted to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -428,7 +433,7 @@ def main():
                     line["cpu_baseline"]["port"] = cpu_baseline(g, v, spec, weights, a.tokens, words / max(a.steps * B * C * world, 1), a.cpu_tokens)
                 except Exception as e:
                     line["cpu_baseline"]["port"] = {"value": None, "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     for e_ in engines:
         e_.close()
     if pg is not None:
