@@ -16,6 +16,7 @@
 //                       TF/generation/utils.py:2909-2910).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace CW_NS {
 
@@ -197,6 +198,240 @@ __global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Second-generation encoder attention (the default): same S^T = K Q^T / O^T = V^T P^T register scheme, but
+//   * 64 queries per wave (4 q-tiles), 256 per block: every K / V fragment read from LDS feeds 4 MFMAs instead of 2
+//     (the 32-query kernel needs 128 B/clk of LDS reads per CU at full MFMA rate -- the LDS limit);
+//   * V is staged row-major like K (one 16-byte LDS store per 16-byte global load) into four [64 keys][16 d] sub-tiles
+//     and read with ds_read_b64_tr_b16, the hardware 4x4 transpose read: lane (d = l15, g) of a 16-lane group receives
+//     V[key0 .. key0+3][d] from the 8-byte pieces its group neighbours address -- no transposing 2-byte stores;
+//   * two LDS stages, global loads of tile t+1 issued before the MFMAs of tile t and written after them: ONE barrier
+//     per 64 keys, HBM/L2 latency hidden under the tile's compute;
+//   * exp2 with the log2(e) factor folded into one fma; the key-validity mask only on the last tile;
+//   * O leaves through a wave-private LDS transpose as whole 128-byte rows.
+// LDS: 2 x (K 8 KB swizzled | 4 x 2080 B V sub-tiles) = 33 KB, two blocks per CU (VGPR-bound).
+// ---------------------------------------------------------------------------------------------------
+#define A2_KSZ 8192
+#define A2_VSUB 2080   // 64 keys x 32 B + 32 B pad: the 8 lanes of one staged key row hit 8 distinct 16-byte slots
+#define A2_STAGE (A2_KSZ + 4 * A2_VSUB)
+#define A2_LOG2E 1.44269504088896340736f
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ inline float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ inline s16x4_t lds_tr16(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+
+// grid: ceil(S/256) * H * B blocks of 256 threads; wave w owns queries q0 + w*64 .. +63.
+__global__ __launch_bounds__(256, 2) void attn_encoder_v2_kernel(const bf16_t* __restrict__ Q,
+                                                                 const bf16_t* __restrict__ K,
+                                                                 const bf16_t* __restrict__ V,
+                                                                 bf16_t* __restrict__ out, int H, int S, int S_pad) {
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * A2_STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nqb = (S + 255) / 256;
+    int lid;
+    {   // XCD-aware logical id: the q-blocks of one (batch, head) share an XCD's L2 for their K/V re-reads
+        const int nwg = gridDim.x, nx = 8, xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+        const int q = nwg / nx, r = nwg % nx;
+        lid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bh = lid / nqb, qblk = lid - bh * nqb;
+    const int b = bh / H, h = bh - b * H;
+    const size_t head_off = ((size_t)b * H + h) * S_pad * 64;
+    const bf16_t* Qh = Q + head_off;
+    const bf16_t* Kh = K + head_off;
+    const bf16_t* Vh = V + head_off;
+    const int qbase = qblk * 256 + wave * 64;
+
+    bf16x8_t fq[4][2];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        int q = qbase + qt * 16 + l15;
+        if (q >= S) q = S - 1;  // clamp: rows beyond S are computed but never stored
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) fq[qt][kk] = *(const bf16x8_t*)(Qh + (size_t)q * 64 + kk * 32 + g * 8);
+    }
+
+    f32x4_t o[4][4];
+    float mrow[4], lrow[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        mrow[qt] = -INFINITY; lrow[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // staging map: 16-byte chunk c = tid + i*256 (i = 0, 1) -> key row c>>3, chunk c&7 of the 128-byte row; the second chunk
+    // is 32 rows further down ((row + 32) & 7 == row & 7).  Plain scalars, not arrays: the staging registers live across
+    // the whole tile body and must stay in VGPRs.
+    const int srow = tid >> 3, sch = tid & 7;
+    const int kdst0 = srow * 128 + ((sch ^ (srow & 7)) << 4), kdst1 = kdst0 + 32 * 128;
+    const int vdst0 = A2_KSZ + (sch >> 1) * A2_VSUB + srow * 32 + (sch & 1) * 16, vdst1 = vdst0 + 32 * 32;
+    const size_t goff = (size_t)srow * 64 + sch * 8;
+    uint4 rk0, rk1, rv0, rv1;
+#define A2_GLOAD(k0_)                                                          \
+    do {                                                                       \
+        const bf16_t* kp_ = Kh + (size_t)(k0_) * 64 + goff;                    \
+        const bf16_t* vp_ = Vh + (size_t)(k0_) * 64 + goff;                    \
+        rk0 = *(const uint4*)kp_; rk1 = *(const uint4*)(kp_ + 2048);           \
+        rv0 = *(const uint4*)vp_; rv1 = *(const uint4*)(vp_ + 2048);           \
+    } while (0)
+#define A2_LSTORE(buf_)                                                        \
+    do {                                                                       \
+        unsigned char* sb_ = sm + (buf_) * A2_STAGE;                           \
+        *(uint4*)(sb_ + kdst0) = rk0; *(uint4*)(sb_ + kdst1) = rk1;            \
+        *(uint4*)(sb_ + vdst0) = rv0; *(uint4*)(sb_ + vdst1) = rv1;            \
+    } while (0)
+    // per-lane fragment offsets inside a stage
+    const int koff = l15 * 128;                                   // + kt*2048, chunk (kk*4+g) ^ (l15 & 7)   ((kt*16+l15)&7 == l15&7)
+    const int kc0 = ((g) ^ (l15 & 7)) << 4, kc1 = ((4 + g) ^ (l15 & 7)) << 4;
+    const int voff = A2_KSZ + (g * 4 + (l15 >> 2)) * 32 + (l15 & 3) * 8;   // + dt*A2_VSUB + (16-key block)*512
+
+    const int ntiles = (S + 63) / 64;
+    A2_GLOAD(0);
+    A2_LSTORE(0);
+    __syncthreads();
+    // pin the Q fragments as complete HERE: otherwise their loads are scheduled past the prologue and the waits the
+    // compiler then places inside the loop (vmcnt is in-order) would also drain every tile's prefetch at once
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) asm volatile("" : "+v"(fq[qt][kk]));
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int k0 = tile * 64;
+        const unsigned char* base = sm + (tile & 1) * A2_STAGE;
+        if (tile + 1 < ntiles) A2_GLOAD(k0 + 64);
+
+        // S^T tiles: st[qt][kt][r] = score(key = k0 + kt*16 + g*4 + r, query = qbase + qt*16 + l15)
+        f32x4_t st[4][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const bf16x8_t fk0 = *(const bf16x8_t*)(base + kt * 2048 + koff + kc0);
+            const bf16x8_t fk1 = *(const bf16x8_t*)(base + kt * 2048 + koff + kc1);
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                z = mfma16a(fk0, fq[qt][0], z);
+                z = mfma16a(fk1, fq[qt][1], z);
+                st[qt][kt] = z;
+            }
+        }
+        if (k0 + 64 > S) {   // last tile: keys beyond S do not exist (block-uniform branch)
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + kt * 16 + g * 4 + r >= S) st[qt][kt][r] = -INFINITY;
+        }
+        bf16x8_t fp[4][2];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            // 16 scores -> 8 v_max3 (fmaxf on MFMA results makes the compiler canonicalise every operand first: 2.5x the ops)
+            float mx = vmax3(st[qt][0][0], st[qt][0][1], st[qt][0][2]);
+            mx = vmax3(mx, st[qt][0][3], st[qt][1][0]);
+            mx = vmax3(mx, st[qt][1][1], st[qt][1][2]);
+            mx = vmax3(mx, st[qt][1][3], st[qt][2][0]);
+            mx = vmax3(mx, st[qt][2][1], st[qt][2][2]);
+            mx = vmax3(mx, st[qt][2][3], st[qt][3][0]);
+            mx = vmax3(mx, st[qt][3][1], st[qt][3][2]);
+            mx = vmax3(mx, st[qt][3][3], st[qt][3][3]);
+            mx = xor32_max(xor16_max(mx));
+            // deferred rescale (see the 32-query kernel): move the running max only when some row grew by > RESCALE_THR
+            float mnew = mrow[qt];
+            if (__any(mx > mrow[qt] + RESCALE_THR)) {
+                mnew = fmaxf(mrow[qt], mx);
+                const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * A2_LOG2E);   // 2^-inf = 0 on the first tile
+                mrow[qt] = mnew;
+                lrow[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+            }
+            const float m2 = -mnew * A2_LOG2E;
+            float psum = 0.f;
+            bf16_t pb[16];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[qt][kt][r], A2_LOG2E, m2));
+                    psum += pv;
+                    pb[kt * 4 + r] = f32_to_bf16(pv);
+                }
+            lrow[qt] += psum;
+            // B operand of O^T = V^T P^T for k-step kp: contraction index j<4 -> key (2kp)*16 + g*4 + j,
+            // j>=4 -> key (2kp+1)*16 + g*4 + (j-4); the V fragments below use the same mapping.
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                bf16x8_t f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[j] = (short)pb[(2 * kp) * 4 + j];
+                    f[4 + j] = (short)pb[(2 * kp + 1) * 4 + j];
+                }
+                fp[qt][kp] = f;
+            }
+        }
+        // O^T[d][q] += sum_key V^T[d][key] P^T[key][q]; V^T fragments by transpose read from the row-major sub-tiles
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const s16x4_t lo = lds_tr16(base + voff + dt * A2_VSUB + (2 * kp) * 512);
+                const s16x4_t hi = lds_tr16(base + voff + dt * A2_VSUB + (2 * kp + 1) * 512);
+                bf16x8_t fv;
+                fv[0] = lo[0]; fv[1] = lo[1]; fv[2] = lo[2]; fv[3] = lo[3];
+                fv[4] = hi[0]; fv[5] = hi[1]; fv[6] = hi[2]; fv[7] = hi[3];
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) o[qt][dt] = mfma16a(fv, fp[qt][kp], o[qt][dt]);
+            }
+        }
+        if (tile + 1 < ntiles) A2_LSTORE((tile + 1) & 1);
+        __syncthreads();   // next stage written by everyone; everyone done reading this one
+    }
+
+    // finalise: 1/l per query column, O^T -> wave-private LDS rows [64 q][64 d] (16-byte chunks XOR-swizzled by q & 7),
+    // then whole 128-byte rows to out[b][q][h*64 ..]
+    unsigned char* ow = sm + wave * 8192;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        float l = lrow[qt];
+        l = xor32_sum(xor16_sum(l));
+        const float inv = 1.0f / l;
+        const int row = qt * 16 + l15;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            ushort4 pk;
+            pk.x = f32_to_bf16(o[qt][dt][0] * inv); pk.y = f32_to_bf16(o[qt][dt][1] * inv);
+            pk.z = f32_to_bf16(o[qt][dt][2] * inv); pk.w = f32_to_bf16(o[qt][dt][3] * inv);
+            const int chunk = (dt * 2 + (g >> 1)) ^ (row & 7);
+            *(ushort4*)(ow + row * 128 + chunk * 16 + (g & 1) * 8) = pk;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (wave-private region)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        const int q = qbase + row;
+        const uint4 v = *(const uint4*)(ow + row * 128 + ((ch ^ (row & 7)) << 4));
+        if (q < S) *(uint4*)(out + ((size_t)b * S + q) * (H * 64) + h * 64 + ch * 8) = v;
+    }
+}
+
 // f32 flavour: one wave per query, scores in LDS.  grid (ceil(S/4), H, B), 256 threads.
 __global__ __launch_bounds__(256) void attn_encoder_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                                const float* __restrict__ V, float* __restrict__ out,
@@ -233,8 +468,13 @@ int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* 
                            int S_pad, hipStream_t st) {
     if (bf16) {
         if (S_pad % KT != 0 || S_pad < S) return CW_ERR_INVALID;
-        hipLaunchKernelGGL(attn_encoder_bf16_kernel, dim3(((S + 127) / 128) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
-                           (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
+        static const bool v1 = getenv("CW_ATTN_V1") != nullptr;   // the 32-queries-per-wave kernel (A/B comparisons)
+        if (v1)
+            hipLaunchKernelGGL(attn_encoder_bf16_kernel, dim3(((S + 127) / 128) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
+                               (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
+        else
+            hipLaunchKernelGGL(attn_encoder_v2_kernel, dim3(((S + 255) / 256) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
+                               (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
     } else {
         hipLaunchKernelGGL(attn_encoder_f32_kernel, dim3((S + 3) / 4, H, B), dim3(256), (size_t)4 * S * sizeof(float),
                            st, (const float*)Q, (const float*)K, (const float*)V, (float*)out, H, S, S_pad);

@@ -1516,6 +1516,21 @@ int32_t cw_test_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, const floa
     }
     int r = KD(c, cw_launch_attn_encoder, c->bf16, dq, dk, dv, dout, B, H, S, S_pad, c->st);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_attention: %s", hipGetErrorString(er)); }
+    if (const char* reps_s = getenv("CW_TEST_ATTN_REPS")) {   // kernel A/B timing for the profiles (stderr only)
+        const int reps = atoi(reps_s);
+        hipEvent_t e0, e1;
+        if (r == CW_OK && reps > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            hipEventRecord(e0, c->st);
+            for (int i = 0; i < reps && r == CW_OK; ++i) r = KD(c, cw_launch_attn_encoder, c->bf16, dq, dk, dv, dout, B, H, S, S_pad, c->st);
+            hipEventRecord(e1, c->st);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double us = 1e3 * ms / reps, fl = 4.0 * B * H * (double)S * S * 64;
+            fprintf(stderr, "[cw_test_attention] B=%d H=%d S=%d: %.2f us/launch, %.1f TFLOP/s\n", B, H, S, us, fl / us * 1e-6);
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+    }
     if (r == CW_OK) r = download_T(c, dout, 0, out, (size_t)B * S * H * 64);
     hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout);
     return r;

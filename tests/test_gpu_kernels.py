@@ -98,7 +98,7 @@ def test_gemv_with_layernorm(engines, dt, tol, Mb, N, K):
 
 
 @pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
-@pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 200), (1, 2, 1500)])
+@pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 200), (1, 2, 1500), (2, 3, 257), (1, 1, 1), (3, 5, 511)])
 def test_encoder_attention(engines, dt, tol, B, H, S):
     rng = np.random.default_rng(B + H + S)
     q = (rng.standard_normal((B, H, S, 64)) * 0.3).astype(np.float32)
