@@ -199,20 +199,30 @@ __global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Second-generation encoder attention (the default): same S^T = K Q^T / O^T = V^T P^T register scheme, but
+// Second-generation encoder attention (the default): same S^T = K Q^T / O^T = V^T P^T register scheme as the kernel above, but
 //   * 64 queries per wave (4 q-tiles), 256 per block: every K / V fragment read from LDS feeds 4 MFMAs instead of 2
 //     (the 32-query kernel needs 128 B/clk of LDS reads per CU at full MFMA rate -- the LDS limit);
-//   * V is staged row-major like K (one 16-byte LDS store per 16-byte global load) into four [64 keys][16 d] sub-tiles
-//     and read with ds_read_b64_tr_b16, the hardware 4x4 transpose read: lane (d = l15, g) of a 16-lane group receives
-//     V[key0 .. key0+3][d] from the 8-byte pieces its group neighbours address -- no transposing 2-byte stores;
-//   * two LDS stages, global loads of tile t+1 issued before the MFMAs of tile t and written after them: ONE barrier
-//     per 64 keys, HBM/L2 latency hidden under the tile's compute;
-//   * exp2 with the log2(e) factor folded into one fma; the key-validity mask only on the last tile;
+//   * V is staged row-major like K into four [64 keys][16 d] sub-tiles and read with ds_read_b64_tr_b16, the hardware
+//     4x4 transpose read: lane (d = l15, g) of a 16-lane group receives V[key0 .. key0+3][d] from the 8-byte pieces its
+//     group neighbours address -- no transposing 2-byte stores (16 per thread and tile in the first kernel);
+//   * K, V and Q reach LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass; two K/V stages,
+//     the DMA of tile t+1 issued before the MFMAs of tile t: ONE barrier per 64 keys, L2 latency under the tile's compute;
+//   * Q lives in LDS (8 KB per wave), not in 32 registers: with O (64) and the scores (64) resident the kernel is
+//     register-bound, and two waves per SIMD are needed to overlap one wave's barrier / LDS waits with the other's work;
+//   * the tile body is software-pipelined over the q-tiles in scheduling regions (MFMAs of q-tile i+1 beside the
+//     max / exp2 VALU work of q-tile i), with ONE wave-uniform rescale branch per tile instead of one per q-tile;
+//   * exp2 with the log2(e) factor folded into one fma; v_max3 by inline asm (fmaxf on MFMA results makes the compiler
+//     canonicalise every operand first); the key-validity mask only in the peeled last tile;
 //   * O leaves through a wave-private LDS transpose as whole 128-byte rows.
-// LDS: 2 x (K 8 KB swizzled | 4 x 2080 B V sub-tiles) = 33 KB, two blocks per CU (VGPR-bound).
+// Measured at the bench shape (B=8, 20 heads, S=1500): 206 -> 133 us per layer (447 -> 690 TFLOP/s).  What is left
+// (profiles/r02_attn_*): with head_dim 64 the softmax costs ~300 VALU instructions per 64 MFMAs and tile, and on this chip
+// the two do not overlap inside a SIMD to any useful degree -- removing the exponentials alone gives 98 us, removing half the
+// MFMAs 118 us: time ~ MFMA cycles + VALU cycles.  The next step is fewer VALU instructions per score (running max folded
+// into the MFMA accumulator init), not more scheduling.
+// LDS: 2 x (K 8 KB swizzled | 4 x 2080 B V sub-tiles) + 32 KB Q = 65 KB, two blocks per CU.
 // ---------------------------------------------------------------------------------------------------
 #define A2_KSZ 8192
-#define A2_VSUB 2080   // 64 keys x 32 B + 32 B pad: the 8 lanes of one staged key row hit 8 distinct 16-byte slots
+#define A2_VSUB 2080   // 64 keys x 32 B (+ 32 B pad, kept from the register-staged version; harmless with the DMA)
 #define A2_STAGE (A2_KSZ + 4 * A2_VSUB)
 #define A2_LOG2E 1.44269504088896340736f
 
@@ -224,21 +234,155 @@ __device__ inline float vmax3(float a, float b, float c) {
     return r;
 }
 
+__device__ inline void a3_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 __device__ inline s16x4_t lds_tr16(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
 
-// grid: ceil(S/256) * H * B blocks of 256 threads; wave w owns queries q0 + w*64 .. +63.
-__global__ __launch_bounds__(256, 2) void attn_encoder_v2_kernel(const bf16_t* __restrict__ Q,
+// One 64-key tile of attn_encoder_q64_kernel.  MASK: the tile holds keys beyond S.
+// The body is two software-pipelined phases.  Each pipeline step is one scheduling region (closed by sched_barrier) that
+// holds 16 MFMAs of one q-tile and the VALU work of its neighbour, so the compiler interleaves them (MFMA issue every
+// ~4 VALU) without stretching live ranges across the whole tile -- unconstrained, the 1200-instruction block is scheduled
+// into 70+ spilled registers, and a scratch reload's vmcnt wait also drains the in-flight DMA of the next stage.
+template <bool MASK>
+__device__ __forceinline__ void a3_qk(const unsigned char* qw, int qt, int k0, int S, int g, int koff, int kc0, int kc1,
+                                      const bf16x8_t (&fk)[4][2], f32x4_t (&st)[4]) {
+    // Q fragments from the wave-private LDS copy (same row / swizzle geometry as a K tile): registers are the scarce
+    // resource of this kernel, LDS bandwidth is not
+    const bf16x8_t fq0 = *(const bf16x8_t*)(qw + qt * 2048 + koff + kc0);
+    const bf16x8_t fq1 = *(const bf16x8_t*)(qw + qt * 2048 + koff + kc1);
+    const int lim = S - k0 - g * 4;   // MASK: this lane's key (kt, r) exists iff kt*16 + r < lim
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (MASK) {   // last tile: keys beyond S do not exist -- start their accumulators at -inf (K rows beyond S are zero-filled
+                      // by the engine, so the products are finite and the score stays -inf; cheaper in registers than a select)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = (kt * 16 + r >= lim) ? -INFINITY : 0.f;
+        }
+        z = mfma16a(fk[kt][0], fq0, z);
+        z = mfma16a(fk[kt][1], fq1, z);
+        st[kt] = z;
+    }
+}
+
+__device__ __forceinline__ float a3_rowmax(const f32x4_t (&st)[4]) {
+    float ma = vmax3(st[0][0], st[0][1], st[0][2]);
+    float mb = vmax3(st[0][3], st[1][0], st[1][1]);
+    ma = vmax3(ma, st[1][2], st[1][3]);
+    mb = vmax3(mb, st[2][0], st[2][1]);
+    ma = vmax3(ma, st[2][2], st[2][3]);
+    mb = vmax3(mb, st[3][0], st[3][1]);
+    ma = vmax3(ma, st[3][2], st[3][3]);
+    return xor32_max(xor16_max(vmax3(ma, mb, mb)));
+}
+
+// P = 2^(s*log2e + m2) for one q-tile, as the two B-operand fragments of O^T = V^T P^T: contraction index j<4 of k-step kp
+// -> key (2kp)*16 + g*4 + j, j>=4 -> key (2kp+1)*16 + g*4 + (j-4); the V fragments use the same mapping.
+__device__ __forceinline__ float a3_probs(const f32x4_t (&st)[4], float m2, bf16x8_t (&fp)[2]) {
+    float psum = 0.f;
+    bf16_t pb[16];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][r], A2_LOG2E, m2));
+            psum += pv;
+            pb[kt * 4 + r] = f32_to_bf16(pv);
+        }
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+        bf16x8_t f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[j] = (short)pb[(2 * kp) * 4 + j];
+            f[4 + j] = (short)pb[(2 * kp + 1) * 4 + j];
+        }
+        fp[kp] = f;
+    }
+    return psum;
+}
+
+template <bool MASK, int QT>
+__device__ __forceinline__ void a3_tile(const unsigned char* base, const unsigned char* qw, int k0, int S, int g, int koff,
+                                        int kc0, int kc1, int voff, f32x4_t (&o)[QT][4], float (&mrow)[QT], float (&lrow)[QT]) {
+    // ---- phase 1: S^T = K Q^T; st[qt][kt][r] = score(key = k0 + kt*16 + g*4 + r, query = qbase + qt*16 + l15) ----
+    bf16x8_t fk[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        fk[kt][0] = *(const bf16x8_t*)(base + kt * 2048 + koff + kc0);
+        fk[kt][1] = *(const bf16x8_t*)(base + kt * 2048 + koff + kc1);
+    }
+    f32x4_t st[QT][4];
+    float mnew[QT];
+    bool moved = false;
+    a3_qk<MASK>(qw, 0, k0, S, g, koff, kc0, kc1, fk, st[0]);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (qt < QT - 1) a3_qk<MASK>(qw, qt + 1, k0, S, g, koff, kc0, kc1, fk, st[qt + 1]);   // MFMAs of q-tile qt+1 ...
+        const float mx = a3_rowmax(st[qt]);                                               // ... over the max of q-tile qt
+        // deferred rescale: the running max moves only when the row grew by more than RESCALE_THR (P <= e^THR otherwise)
+        const bool mv = mx > mrow[qt] + RESCALE_THR;
+        mnew[qt] = mv ? mx : mrow[qt];
+        moved |= mv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (__any(moved)) {   // rare after the first tiles: one wave-uniform branch for the four q-tiles
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew[qt]) * A2_LOG2E);   // 2^-inf = 0 on the first tile
+            mrow[qt] = mnew[qt];
+            lrow[qt] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+        }
+    }
+    // ---- phase 2: O^T[d][q] += sum_key V^T[d][key] P^T[key][q]; V^T fragments by transpose read of the row-major sub-tiles ----
+    bf16x8_t fv[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            const s16x4_t lo = lds_tr16(base + voff + dt * A2_VSUB + (2 * kp) * 512);
+            const s16x4_t hi = lds_tr16(base + voff + dt * A2_VSUB + (2 * kp + 1) * 512);
+            bf16x8_t f;
+            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+            f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+            fv[dt][kp] = f;
+        }
+    bf16x8_t fp[2][2];
+    lrow[0] += a3_probs(st[0], -mrow[0] * A2_LOG2E, fp[0]);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (qt < QT - 1) lrow[qt + 1] += a3_probs(st[qt + 1], -mrow[qt + 1] * A2_LOG2E, fp[(qt + 1) & 1]);   // exps of q-tile qt+1 ...
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp)                                                                   // ... under the MFMAs of qt
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[qt][dt] = mfma16a(fv[dt][kp], fp[qt & 1][kp], o[qt][dt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// grid: ceil(S / (64 QT)) * H * B blocks of 256 threads; wave w owns queries q0 + w*16*QT .. (QT q-tiles of 16).
+template <int QT>
+__global__ __launch_bounds__(256, 2) void attn_encoder_q64_kernel(const bf16_t* __restrict__ Q,
                                                                  const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V,
                                                                  bf16_t* __restrict__ out, int H, int S, int S_pad) {
-    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * A2_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * A2_STAGE + 4 * QT * 2048];   // K/V stages | Q, 2 KB per q-tile
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int nqb = (S + 255) / 256;
+    const int nqb = (S + 64 * QT - 1) / (64 * QT);
     int lid;
     {   // XCD-aware logical id: the q-blocks of one (batch, head) share an XCD's L2 for their K/V re-reads
         const int nwg = gridDim.x, nx = 8, xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
@@ -251,46 +395,32 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_v2_kernel(const bf16_t* _
     const bf16_t* Qh = Q + head_off;
     const bf16_t* Kh = K + head_off;
     const bf16_t* Vh = V + head_off;
-    const int qbase = qblk * 256 + wave * 64;
+    const int qbase = qblk * 64 * QT + wave * 16 * QT;
 
-    bf16x8_t fq[4][2];
+    f32x4_t o[QT][4];
+    float mrow[QT], lrow[QT];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-        int q = qbase + qt * 16 + l15;
-        if (q >= S) q = S - 1;  // clamp: rows beyond S are computed but never stored
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) fq[qt][kk] = *(const bf16x8_t*)(Qh + (size_t)q * 64 + kk * 32 + g * 8);
-    }
-
-    f32x4_t o[4][4];
-    float mrow[4], lrow[4];
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         mrow[qt] = -INFINITY; lrow[qt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
 
-    // staging map: 16-byte chunk c = tid + i*256 (i = 0, 1) -> key row c>>3, chunk c&7 of the 128-byte row; the second chunk
-    // is 32 rows further down ((row + 32) & 7 == row & 7).  Plain scalars, not arrays: the staging registers live across
-    // the whole tile body and must stay in VGPRs.
-    const int srow = tid >> 3, sch = tid & 7;
-    const int kdst0 = srow * 128 + ((sch ^ (srow & 7)) << 4), kdst1 = kdst0 + 32 * 128;
-    const int vdst0 = A2_KSZ + (sch >> 1) * A2_VSUB + srow * 32 + (sch & 1) * 16, vdst1 = vdst0 + 32 * 32;
-    const size_t goff = (size_t)srow * 64 + sch * 8;
-    uint4 rk0, rk1, rv0, rv1;
-#define A2_GLOAD(k0_)                                                          \
-    do {                                                                       \
-        const bf16_t* kp_ = Kh + (size_t)(k0_) * 64 + goff;                    \
-        const bf16_t* vp_ = Vh + (size_t)(k0_) * 64 + goff;                    \
-        rk0 = *(const uint4*)kp_; rk1 = *(const uint4*)(kp_ + 2048);           \
-        rv0 = *(const uint4*)vp_; rv1 = *(const uint4*)(vp_ + 2048);           \
-    } while (0)
-#define A2_LSTORE(buf_)                                                        \
-    do {                                                                       \
-        unsigned char* sb_ = sm + (buf_) * A2_STAGE;                           \
-        *(uint4*)(sb_ + kdst0) = rk0; *(uint4*)(sb_ + kdst1) = rk1;            \
-        *(uint4*)(sb_ + vdst0) = rv0; *(uint4*)(sb_ + vdst1) = rv1;            \
+    // staging by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, destination = wave base + lane*16, per-lane
+    // source address -- no staging registers, no ds_write pass): wave w moves K rows w*16 .. w*16+15 (two instructions of
+    // 8 rows, source chunk XOR-swizzled) and V sub-tile dt = w (two instructions of 32 keys x 32 B).
+    const int krow = wave * 16 + (lane >> 3);                                    // + 8 for the second instruction
+    const size_t ksrc = (size_t)krow * 64 + (((lane & 7) ^ (krow & 7)) << 3);   // (krow + 8) & 7 == krow & 7
+    const size_t vsrc = (size_t)(lane >> 1) * 64 + wave * 16 + (lane & 1) * 8;  // + 32 keys for the second instruction
+#define A3_STAGE_DMA(k0_, buf_)                                                             \
+    do {                                                                                    \
+        unsigned char* sb_ = sm + (buf_) * A2_STAGE;                                        \
+        const bf16_t* kp_ = Kh + (size_t)(k0_) * 64;                                        \
+        const bf16_t* vp_ = Vh + (size_t)(k0_) * 64;                                        \
+        a3_glds16(kp_ + ksrc, sb_ + wave * 2048);                                           \
+        a3_glds16(kp_ + ksrc + 8 * 64, sb_ + wave * 2048 + 1024);                           \
+        a3_glds16(vp_ + vsrc, sb_ + A2_KSZ + wave * A2_VSUB);                               \
+        a3_glds16(vp_ + vsrc + 32 * 64, sb_ + A2_KSZ + wave * A2_VSUB + 1024);              \
     } while (0)
     // per-lane fragment offsets inside a stage
     const int koff = l15 * 128;                                   // + kt*2048, chunk (kk*4+g) ^ (l15 & 7)   ((kt*16+l15)&7 == l15&7)
@@ -298,116 +428,40 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_v2_kernel(const bf16_t* _
     const int voff = A2_KSZ + (g * 4 + (l15 >> 2)) * 32 + (l15 & 3) * 8;   // + dt*A2_VSUB + (16-key block)*512
 
     const int ntiles = (S + 63) / 64;
-    A2_GLOAD(0);
-    A2_LSTORE(0);
+    // Q: 64 query rows x 128 B per wave, by the same DMA (8 instructions of 8 rows, source chunk XOR-swizzled); rows
+    // beyond S are clamped to the last row (computed, never stored)
+    unsigned char* qw = sm + 2 * A2_STAGE + wave * QT * 2048;
+#pragma unroll
+    for (int i = 0; i < 2 * QT; ++i) {
+        const int r = i * 8 + (lane >> 3);
+        int q = qbase + r;
+        if (q >= S) q = S - 1;
+        a3_glds16(Qh + (size_t)q * 64 + (((lane & 7) ^ (r & 7)) << 3), qw + i * 1024);
+    }
+    A3_STAGE_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // pin the Q fragments as complete HERE: otherwise their loads are scheduled past the prologue and the waits the
-    // compiler then places inside the loop (vmcnt is in-order) would also drain every tile's prefetch at once
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) asm volatile("" : "+v"(fq[qt][kk]));
-    for (int tile = 0; tile < ntiles; ++tile) {
+    // full tiles in the loop (one code path: with the masked variant inside the loop the register allocator spills the
+    // main path), the tile holding keys beyond S -- if any -- peeled behind it
+    const int nfull = S / 64;
+    for (int tile = 0; tile < nfull; ++tile) {
         const int k0 = tile * 64;
         const unsigned char* base = sm + (tile & 1) * A2_STAGE;
-        if (tile + 1 < ntiles) A2_GLOAD(k0 + 64);
-
-        // S^T tiles: st[qt][kt][r] = score(key = k0 + kt*16 + g*4 + r, query = qbase + qt*16 + l15)
-        f32x4_t st[4][4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const bf16x8_t fk0 = *(const bf16x8_t*)(base + kt * 2048 + koff + kc0);
-            const bf16x8_t fk1 = *(const bf16x8_t*)(base + kt * 2048 + koff + kc1);
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                z = mfma16a(fk0, fq[qt][0], z);
-                z = mfma16a(fk1, fq[qt][1], z);
-                st[qt][kt] = z;
-            }
-        }
-        if (k0 + 64 > S) {   // last tile: keys beyond S do not exist (block-uniform branch)
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (k0 + kt * 16 + g * 4 + r >= S) st[qt][kt][r] = -INFINITY;
-        }
-        bf16x8_t fp[4][2];
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            // 16 scores -> 8 v_max3 (fmaxf on MFMA results makes the compiler canonicalise every operand first: 2.5x the ops)
-            float mx = vmax3(st[qt][0][0], st[qt][0][1], st[qt][0][2]);
-            mx = vmax3(mx, st[qt][0][3], st[qt][1][0]);
-            mx = vmax3(mx, st[qt][1][1], st[qt][1][2]);
-            mx = vmax3(mx, st[qt][1][3], st[qt][2][0]);
-            mx = vmax3(mx, st[qt][2][1], st[qt][2][2]);
-            mx = vmax3(mx, st[qt][2][3], st[qt][3][0]);
-            mx = vmax3(mx, st[qt][3][1], st[qt][3][2]);
-            mx = vmax3(mx, st[qt][3][3], st[qt][3][3]);
-            mx = xor32_max(xor16_max(mx));
-            // deferred rescale (see the 32-query kernel): move the running max only when some row grew by > RESCALE_THR
-            float mnew = mrow[qt];
-            if (__any(mx > mrow[qt] + RESCALE_THR)) {
-                mnew = fmaxf(mrow[qt], mx);
-                const float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * A2_LOG2E);   // 2^-inf = 0 on the first tile
-                mrow[qt] = mnew;
-                lrow[qt] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
-            }
-            const float m2 = -mnew * A2_LOG2E;
-            float psum = 0.f;
-            bf16_t pb[16];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[qt][kt][r], A2_LOG2E, m2));
-                    psum += pv;
-                    pb[kt * 4 + r] = f32_to_bf16(pv);
-                }
-            lrow[qt] += psum;
-            // B operand of O^T = V^T P^T for k-step kp: contraction index j<4 -> key (2kp)*16 + g*4 + j,
-            // j>=4 -> key (2kp+1)*16 + g*4 + (j-4); the V fragments below use the same mapping.
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                bf16x8_t f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f[j] = (short)pb[(2 * kp) * 4 + j];
-                    f[4 + j] = (short)pb[(2 * kp + 1) * 4 + j];
-                }
-                fp[qt][kp] = f;
-            }
-        }
-        // O^T[d][q] += sum_key V^T[d][key] P^T[key][q]; V^T fragments by transpose read from the row-major sub-tiles
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                const s16x4_t lo = lds_tr16(base + voff + dt * A2_VSUB + (2 * kp) * 512);
-                const s16x4_t hi = lds_tr16(base + voff + dt * A2_VSUB + (2 * kp + 1) * 512);
-                bf16x8_t fv;
-                fv[0] = lo[0]; fv[1] = lo[1]; fv[2] = lo[2]; fv[3] = lo[3];
-                fv[4] = hi[0]; fv[5] = hi[1]; fv[6] = hi[2]; fv[7] = hi[3];
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt) o[qt][dt] = mfma16a(fv, fp[qt][kp], o[qt][dt]);
-            }
-        }
-        if (tile + 1 < ntiles) A2_LSTORE((tile + 1) & 1);
-        __syncthreads();   // next stage written by everyone; everyone done reading this one
+        if (tile + 1 < ntiles) A3_STAGE_DMA(k0 + 64, (tile + 1) & 1);   // stage (t+1)&1 was last read in tile t-1
+        a3_tile<false, QT>(base, qw, k0, S, g, koff, kc0, kc1, voff, o, mrow, lrow);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next stage have landed ...
+        __syncthreads();                                   // ... and everyone's; everyone done reading this stage
+    }
+    if (nfull < ntiles) {
+        a3_tile<true, QT>(sm + (nfull & 1) * A2_STAGE, qw, nfull * 64, S, g, koff, kc0, kc1, voff, o, mrow, lrow);
+        __syncthreads();   // the stages are reused for the output transpose below
     }
 
     // finalise: 1/l per query column, O^T -> wave-private LDS rows [64 q][64 d] (16-byte chunks XOR-swizzled by q & 7),
     // then whole 128-byte rows to out[b][q][h*64 ..]
-    unsigned char* ow = sm + wave * 8192;
+    unsigned char* ow = sm + wave * QT * 2048;
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float l = lrow[qt];
         l = xor32_sum(xor16_sum(l));
         const float inv = 1.0f / l;
@@ -424,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void attn_encoder_v2_kernel(const bf16_t* _
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (wave-private region)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 2 * QT; ++it) {
         const int row = it * 8 + (lane >> 3), ch = lane & 7;
         const int q = qbase + row;
         const uint4 v = *(const uint4*)(ow + row * 128 + ((ch ^ (row & 7)) << 4));
@@ -468,12 +522,12 @@ int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* 
                            int S_pad, hipStream_t st) {
     if (bf16) {
         if (S_pad % KT != 0 || S_pad < S) return CW_ERR_INVALID;
-        static const bool v1 = getenv("CW_ATTN_V1") != nullptr;   // the 32-queries-per-wave kernel (A/B comparisons)
+        static const bool v1 = getenv("CW_ATTN_V1") != nullptr;   // the round-1 32-queries-per-wave kernel (A/B comparisons)
         if (v1)
             hipLaunchKernelGGL(attn_encoder_bf16_kernel, dim3(((S + 127) / 128) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
                                (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
         else
-            hipLaunchKernelGGL(attn_encoder_v2_kernel, dim3(((S + 255) / 256) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
+            hipLaunchKernelGGL(attn_encoder_q64_kernel<4>, dim3(((S + 255) / 256) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
                                (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
     } else {
         hipLaunchKernelGGL(attn_encoder_f32_kernel, dim3((S + 3) / 4, H, B), dim3(256), (size_t)4 * S * sizeof(float),

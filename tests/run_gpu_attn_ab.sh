@@ -2,7 +2,7 @@
 # A/B timing of the encoder attention kernels at the bench shape (B=8, 20 heads, S=1500): usage run_gpu_attn_ab.sh TAG
 TAG=${1:-ab}
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "encoder_attention" -x 2>&1 | tail -3
+[ -z "$SKIPTEST" ] && python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "encoder_attention" -x 2>&1 | tail -3
 cat > /tmp/attn_ab.py <<'P'
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
@@ -16,11 +16,13 @@ for dt in ("bf16", "f16"):
     q = (rng.standard_normal((B, H, S, 64)) * 0.3).astype(np.float32)
     k = rng.standard_normal((B, H, S, 64)).astype(np.float32)
     vv = rng.standard_normal((B, H, S, 64)).astype(np.float32)
-    sys.stderr.write(f"dtype {dt} variant {'v1' if os.environ.get('CW_ATTN_V1') else 'v2'}\n")
+    sys.stderr.write(f"dtype {dt} variant {'v1' if os.environ.get('CW_ATTN_V1') else 'q64'}\n")
     e.test_attention(q, k, vv)
     e.close()
 P
-for v in v1 v2; do
-  if [ $v = v1 ]; then export CW_ATTN_V1=1; else unset CW_ATTN_V1; fi
-  CW_TEST_ATTN_REPS=100 python /tmp/attn_ab.py 2>&1 | grep -v "^\[W\|warn" | tail -8
+for v in v1 q64; do
+  unset CW_ATTN_V1
+  if [ $v = v1 ]; then export CW_ATTN_V1=1; fi
+  echo "== $v"
+  CW_TEST_ATTN_REPS=100 python /tmp/attn_ab.py 2>&1 | grep -v "^\[W\|warn" | grep "B=8"
 done | tee gpurun_out/attn_ab_$TAG.txt
