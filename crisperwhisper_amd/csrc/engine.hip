@@ -1458,6 +1458,7 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
 
 int32_t cw_test_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "gemm256_min_tiles")) { cw_bf16::cw_gemm_set_256_min_tiles(value); cw_f16::cw_gemm_set_256_min_tiles(value); return CW_OK; }
+    if (!strcmp(name, "gemm_pp")) { cw_bf16::cw_gemm_set_pp(value); cw_f16::cw_gemm_set_pp(value); return CW_OK; }
     return CW_ERR_INVALID;
 }
 
@@ -1473,6 +1474,21 @@ int32_t cw_test_gemm(cw_ctx* c, int32_t M, int32_t N, int32_t K, const float* A,
     EpiParams ep = epi0(); ep.out = dO; ep.bias = bias ? dB : nullptr; ep.ldo = N;
     int r = KD(c, cw_launch_gemm, c->bf16, gelu ? EPI_GELU : EPI_STORE, ap, dW, M, N, K, ep, c->st);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemm: %s", hipGetErrorString(er)); }
+    if (const char* reps_s = getenv("CW_TEST_GEMM_REPS")) {   // kernel A/B timing for the profiles (stderr only)
+        const int reps = atoi(reps_s);
+        hipEvent_t e0, e1;
+        if (r == CW_OK && reps > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            hipEventRecord(e0, c->st);
+            for (int i = 0; i < reps && r == CW_OK; ++i) r = KD(c, cw_launch_gemm, c->bf16, gelu ? EPI_GELU : EPI_STORE, ap, dW, M, N, K, ep, c->st);
+            hipEventRecord(e1, c->st);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double us = 1e3 * ms / reps;
+            fprintf(stderr, "[cw_test_gemm] M=%d N=%d K=%d gelu=%d: %.2f us/launch, %.1f TFLOP/s\n", M, N, K, gelu, us, 2.0 * M * N * K / us * 1e-6);
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+    }
     if (r == CW_OK) r = download_T(c, dO, 0, out, (size_t)M * N);
     hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dB);
     return r;

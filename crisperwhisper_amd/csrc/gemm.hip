@@ -435,6 +435,151 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(AParams ap, const bf
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Ping-pong flavour of the 256x256x64 LDS-DMA GEMM (plain row-major A, N % 256 == 0): same tile, LDS image, swizzle,
+// DMA map and epilogue as gemm_bf16_256_kernel, different time structure.  There all 8 waves move in lockstep through
+// "DMA issue, fragment reads, 64 MFMAs, drain, barrier": the matrix pipes idle while the fragments come out of LDS and
+// the LDS idles under the MFMAs (measured 41 % MFMA-busy in the steady state of fc2).  Here the two waves that share a
+// SIMD belong to different groups (G0 = waves 0-3 = upper 128 rows, G1 = waves 4-7 = lower 128 rows) which run half a
+// K-tile period apart: while one group issues its 64 MFMAs from registers, the other pulls the WHOLE next K-tile's
+// fragments (24 x ds_read_b128 = 96 VGPRs) and issues its share of the LDS-DMA for the tile after.  Phases, separated by
+// one s_barrier each (every wave executes the same number of barriers):
+//      phase 2t   : G0 MFMA(t)                      | G1 READ(t), ISSUE(t+1), drain
+//      phase 2t+1 : G0 READ(t+1), ISSUE(t+2)        | G1 MFMA(t)              (G0 drains at the end of its next MFMA phase)
+// Stage (t+1)&1 is rewritten from phase 2t-1 on; its previous tile t-1 was last read in phases 2t-3 (G0) and 2t-2 (G1).
+// Tile t+1 is complete when G0's pieces (issued in 2t-1) and G1's (issued in 2t) have been waited for by their issuers
+// before the barrier that closes phase 2t; G0 reads it in 2t+1, G1 in 2t+2.  No LDS-DMA is in flight at any ds_read of
+// the issuing wave (reads precede the issue inside a phase), so the compiler's conservative vmcnt(0) before LDS reads
+// never fires.
+// ---------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ A, int lda,
+                                                           const bf16_t* __restrict__ W, int M, int N, int K,
+                                                           EpiParams ep, int tiles_n, const bf16_t* __restrict__ zero_page) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm3[];   // [2][A 32 KB | W 32 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;   // wm is also the group
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int mt_, nt_;
+    grouped_tile(tile, gridDim.x / tiles_n, tiles_n, mt_, nt_);
+    const int m0 = mt_ * BM2, n0 = nt_ * BN2;
+
+    // DMA map as in the lockstep kernel: piece q of this wave = rows (wave*4 + q)*8 .. +7 of the A tile and of the W tile.
+    // Issued as buffer_load_dwordx4 ... lds: SGPR descriptor + one 32-bit per-lane offset that never changes + a scalar
+    // offset for the K position -- no 64-bit per-lane address arithmetic in the loop.  Rows beyond M are clamped to the
+    // last row instead of zero-filled: they only feed output rows beyond M, which are never stored.
+    const int lrow = lane >> 3;
+    const int csrc = ((lane & 7) ^ lrow) * 8;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    int va[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) va[q] = (min(m0 + wave * 32 + q * 8 + lrow, M - 1) * lda + csrc) * 2;
+    const int vw = ((n0 + wave * 32 + lrow) * K + csrc) * 2;
+    auto issue = [&](int k0, int buf) {
+        unsigned char* base = gsm3 + buf * 65536 + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, va[q], k0 * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(base + 32768 + q * 1024), 16, vw,
+                                                     (k0 + q * 8 * K) * 2, 0, 0);
+        }
+    };
+    // fragment offsets inside a stage (chunk XOR by row & 7 == l15 & 7)
+    const int sw = l15 & 7;
+    const int aoff = (wm * 128 + l15) * 128, woff = 32768 + (wn * 64 + l15) * 128;
+    bf16x8_t fa[2][8], fw[2][4];
+    auto read_frags = [&](int buf) {
+        const unsigned char* sb = gsm3 + buf * 65536;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = ((kk * 4 + g) ^ sw) << 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fw[kk][j] = *(const bf16x8_t*)(sb + woff + j * 2048 + c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[kk][i] = *(const bf16x8_t*)(sb + aoff + i * 2048 + c);
+        }
+    };
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    auto mfmas = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[kk][j], fa[kk][i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nk = K / BK;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 0) {
+        read_frags(0);
+        if (nk > 1) issue(BK, 1);
+        __builtin_amdgcn_s_barrier();                              // closes phase -1
+        for (int t = 0; t < nk; ++t) {
+            mfmas();                                               // phase 2t
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own pieces of tile t+1 (issued one phase ago)
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < nk) {                                      // phase 2t+1
+                read_frags((t + 1) & 1);
+                if (t + 2 < nk) issue((t + 2) * BK, t & 1);
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        __builtin_amdgcn_s_barrier();                              // closes phase -1
+        for (int t = 0; t < nk; ++t) {
+            read_frags(t & 1);                                     // phase 2t
+            if (t + 1 < nk) issue((t + 1) * BK, (t + 1) & 1);
+            // own DMA pieces landed; own fragment reads returned -- G0 starts rewriting this stage right after the barrier
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mfmas();                                               // phase 2t+1
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    const bool vec_ok = (EPI == EPI_HEADS || (ep.ldo & 3) == 0);
+    if (m0 + BM2 <= M && vec_ok) {   // interior tile (block-uniform)
+        int cols[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cols[j] = n0 + wn * 64 + j * 16 + g * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int rows[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rows[i] = m0 + wm * 128 + (h * 4 + i) * 16 + l15;
+            epi_tile_interior<bf16_t, EPI>(ep, rows, cols, *(const f32x4_t(*)[4][4])&acc[h * 4]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int m = m0 + wm * 128 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + wn * 64 + j * 16 + g * 4;
+            if (vec_ok) {
+                epi_store4<bf16_t, EPI>(ep, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi_store1<bf16_t, EPI>(ep, m, n + r, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // f32 parity GEMM: 64x64 tile, 256 threads, 4x4 outputs per thread, BK = 16.
 // ---------------------------------------------------------------------------------------------------
 template <int EPI>
@@ -1030,7 +1175,9 @@ static const bf16_t* g_zero_page = nullptr;   // 256 B of zeros: DMA source for 
 static bool g_use_glds = true;
 static bool g_use_256 = true;   // CW_NO_GEMM256=1: keep the 128x128 tiles everywhere
 static int g_256_min_tiles = 200;
+static int g_use_pp = -1;   // ping-pong schedule for the plain-A 256-tile shapes; -1: from the environment (CW_NO_GEMM_PP)
 void cw_gemm_set_256_min_tiles(int n) { g_256_min_tiles = n; }
+void cw_gemm_set_pp(int on) { g_use_pp = on; }
 
 template <int EPI>
 static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
@@ -1046,7 +1193,16 @@ static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, 
         });
         // large shapes: 256x256 tiles once they fill most of the chip (>= 200 tiles); small M keeps the 128 tiles
         const int tm2 = (M + BM2 - 1) / BM2, tn2 = (N + BN2 - 1) / BN2;
-        if (g_use_glds && g_zero_page && g_use_256 && tm2 * tn2 >= g_256_min_tiles) {
+        if (g_use_pp < 0) g_use_pp = getenv("CW_NO_GEMM_PP") == nullptr;
+        const bool use_pp = g_use_pp != 0;
+        if (g_use_glds && g_zero_page && g_use_256 && use_pp && tm2 * tn2 >= g_256_min_tiles && ap.amode == 0 && N % BN2 == 0) {
+            static std::once_flag attr_pp;
+            std::call_once(attr_pp, [] {
+                hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            });
+            hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(tm2 * tn2), dim3(512), 131072, st, (const bf16_t*)ap.A, ap.lda,
+                               (const bf16_t*)W, M, N, K, ep, tn2, g_zero_page);
+        } else if (g_use_glds && g_zero_page && g_use_256 && tm2 * tn2 >= g_256_min_tiles) {
             static std::once_flag attr_once;     // one per EPI instantiation (function-local static in a template)
             std::call_once(attr_once, [] {
                 hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);

@@ -77,6 +77,32 @@ def test_gemm_256_tile_kernel(engines, M, N, K):
         eng.lib.cw_test_set_option(b"gemm256_min_tiles", 200)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 256, 128), (513, 768, 192), (2000, 512, 5120), (3333, 1280, 1280), (1500, 3840, 1280)])
+def test_gemm_pingpong_schedule_is_bit_identical_to_lockstep(engines, M, N, K):
+    """The ping-pong 256-tile GEMM (two wave groups half a K-tile apart, LDS-DMA two tiles ahead) accumulates in exactly
+    the order of the lockstep kernel: same bits, run after run (a stage overwritten early or read late shows up here),
+    for 1, 2, 3, 20 and 80 K-tiles, with and without an M-edge tile."""
+    eng = engines["bf16"]
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    A = (A.view(np.uint32) & 0xFFFF0000).view(np.float32); W = (W.view(np.uint32) & 0xFFFF0000).view(np.float32)
+    assert eng.lib.cw_test_set_option(b"gemm256_min_tiles", 1) == 0
+    try:
+        assert eng.lib.cw_test_set_option(b"gemm_pp", 0) == 0
+        want = eng.test_gemm(A, W, b, True)
+        ref = OMOD.gelu((A.astype(np.float64) @ W.astype(np.float64).T + b).astype(np.float32))
+        assert rel_err(want, ref) < 2e-2
+        assert eng.lib.cw_test_set_option(b"gemm_pp", 1) == 0
+        for rep in range(6):
+            got = eng.test_gemm(A, W, b, True)
+            assert np.array_equal(got, want), (M, N, K, rep, int((got != want).sum()))
+    finally:
+        eng.lib.cw_test_set_option(b"gemm256_min_tiles", 200)
+        eng.lib.cw_test_set_option(b"gemm_pp", 1)
+
+
 @pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
 @pytest.mark.parametrize("Mb,N,K", [(1, 128, 128), (3, 200, 256), (8, 1769, 128), (16, 64, 1280), (20, 128, 512), (40, 96, 1280), (64, 80, 256),
                                      (8, 5120, 1280), (5, 4160, 256), (12, 5120, 1280)])   # the last three: two column tiles per block (wide LayerNorm GEMV)
