@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-rccl", action="store_true", help="N=1 only: do not create the one-rank RCCL communicator")
     ap.add_argument("--no-longform", action="store_true", help="skip the BASELINE configs[2] leg (600 s recording sharded over the ranks)")
     ap.add_argument("--longform-seconds", type=int, default=600)
+    ap.add_argument("--num-beams", type=int, default=1,
+                    help="beam search width (default 1 = greedy, the BASELINE configuration; 5 = what the literal reference call "
+                         "decodes with under transformers 5.x); the engine is provisioned with batch x beams decoder rows")
     ap.add_argument("--contexts", type=int, default=1,
                     help="independent engine contexts per GPU, each with its own batch of --batch chunks, driven by "
                          "host threads (the decode step is latency-bound, so a second batch fills idle CUs); "
@@ -181,7 +184,7 @@ def main():
     spec = syn.model_spec(g, v, n_align=15 if a.geometry == "large-v3" else 3)
     B = a.batch
     C = max(1, a.contexts)
-    engines = [Engine(spec, dtype=a.dtype, max_batch=B, device=dev, cross_kv_dtype=None if a.cross_kv == "bf16" else a.cross_kv)
+    engines = [Engine(spec, dtype=a.dtype, max_batch=B * max(1, a.num_beams), device=dev, cross_kv_dtype=None if a.cross_kv == "bf16" else a.cross_kv)
                for _ in range(C)]
     eng = engines[0]
     keep = (not a.no_cpu_baseline) and world == 1 and rank == 0
@@ -211,7 +214,7 @@ def main():
         eng, nf = engines[ci], nfs[ci]
         eng.mel_resident(B)
         out = generation.generate(eng, B, nf, language="<|en|>", task="transcribe", max_new_tokens=a.tokens,
-                                  min_new_tokens=a.tokens)
+                                  min_new_tokens=a.tokens, num_beams=a.num_beams)
         # every chunk is an independent clip here, so each rank collates + pause-splits its own chunks and the
         # ranks exchange the per-chunk *word lists* (one small all-gather); rank 0 ends up with all results
         recs = []
@@ -284,7 +287,7 @@ def main():
     # through transformers (CPU, fp32) with the same aligned weights and token count
     parity = None
     gpath = os.path.join(ROOT, "tests", "golden", "e2e_bench_golden.json")
-    if rank == 0 and a.weights == "aligned" and a.geometry == "large-v3" and a.dtype in ("bf16", "f16") and os.path.exists(gpath):
+    if rank == 0 and a.weights == "aligned" and a.geometry == "large-v3" and a.dtype in ("bf16", "f16") and a.num_beams == 1 and os.path.exists(gpath):
         gold = json.load(open(gpath))
         if gold["generate_kwargs"]["max_new_tokens"] == a.tokens and gold.get("weights") == "aligned":
             n = min(B, len(gold["clips"]))
@@ -364,10 +367,11 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "rtf": dt / total_audio, "tokens_per_s": tokens / dt,
             "config": {"workload": f"BASELINE configs[1]: batch={B} x 30 s synthetic 16 kHz audio per GPU, {a.dtype}, "
-                                   f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, {a.weights} synthetic weights, greedy, word timestamps"
+                                   f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, {a.weights} synthetic weights, "
+                                   + ("greedy" if a.num_beams == 1 else f"beam search x{a.num_beams} [not the BASELINE configuration]") + ", word timestamps"
                                    + (", fp8 (e4m3) cross-attention cache [opt-in mode]" if a.cross_kv == "fp8" else ""),
                        "chunks_per_gpu": B * C, "contexts_per_gpu": C, "tokens_per_chunk": a.tokens, "parallelism": f"chunk-dp{world}",
-                       "cross_kv_cache": a.cross_kv, "weight_load_s": round(t_load, 1)},
+                       "cross_kv_cache": a.cross_kv, "num_beams": a.num_beams, "weight_load_s": round(t_load, 1)},
             "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1) / C, 3) for k, val in stages.items()},
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
                          "frac": r["achieved"] / 8000.0,

@@ -818,102 +818,147 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
 // 8 x 64 partial outputs: 2 barriers per block instead of 7, the 64-group serial LDS reduction became three cross-lane
 // steps + 8 adds.  Needs nk <= 4 * 64 keys per block (ATT_NS >= 6 for 1500 frames).
 __device__ inline float row_ror8_add(float v) { return v + dpp_mov<0x128, 0xf>(0.f, v); }   // + lane ^ 8 (row_ror:8)
-template <typename T>
+template <typename T, int NQ>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSplitParams p) {
-    __shared__ float s_max[8];
-    __shared__ float red[8 * 64];
-    __shared__ float red_l[8];
-    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    __shared__ float s_max[8 * NQ];
+    __shared__ float red[8 * NQ * 64];
+    __shared__ float red_l[8 * NQ];
+    // blockIdx.y = group of NQ consecutive query rows that share one K/V (NQ = kv_div: the hypotheses of one audio item under
+    // beam search; NQ = 1: one row per block, K/V of item row / kv_div).  The K/V slice is read ONCE into registers and all
+    // NQ queries go through the same three block barriers together: one block per row re-streamed the 64 KB slice from L2
+    // kv_div times (26 us per layer at 8 items x 5 beams against 12.5 us at 8 rows), and a serial loop over the queries
+    // inside one block was slower still (32 us: 3 barriers + reductions per query).
+    const int h = blockIdx.x, b0 = blockIdx.y * NQ, sp = blockIdx.z;
+    const int bk = p.kv_div > 1 ? b0 / p.kv_div : b0;
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
     const int k_lo = sp * per, k_hi = min(p.n_keys, k_lo + per), nk = k_hi - k_lo;
     const int tid = threadIdx.x, lane = tid & 63, sub = tid & 7, grp = tid >> 3;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bk = p.kv_div > 1 ? b / p.kv_div : b;            // beams of one audio item share its encoder K/V
     const T* Kh = (const T*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
     const T* Vh = (const T*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
     constexpr int G = CROSS_THREADS / 8;                       // 64 key groups
-    float qv[8];
-    Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
     Raw8<T> kr[4], vr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) kr[u].ld(Kh + (size_t)min(grp + u * G, nk - 1) * 64);   // unconditional, clamped
 #pragma unroll
     for (int u = 0; u < 4; ++u) vr[u].ld(Vh + (size_t)min(grp + u * G, nk - 1) * 64);
-    float d[4];
-    float mx = -INFINITY;
+    float qv[NQ][8];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) Row8<float>::ld(p.q + (size_t)(b0 + q) * p.H * 64 + h * 64 + sub * 8, qv[q]);
+    float d[NQ][4], mx[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) mx[q] = -INFINITY;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         float kv[8];
         kr[u].cvt(kv);
-        float t = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t = fmaf(qv[e], kv[e], t);
-        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
-        d[u] = (grp + u * G < nk) ? t : -INFINITY;
-        mx = fmaxf(mx, d[u]);
+        for (int q = 0; q < NQ; ++q) {
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t = fmaf(qv[q][e], kv[e], t);
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+            d[q][u] = (grp + u * G < nk) ? t : -INFINITY;
+            mx[q] = fmaxf(mx[q], d[q][u]);
+        }
     }
-    mx = wave_max(mx);
-    if (lane == 0) s_max[wave] = mx;
-    __syncthreads();
-    mx = s_max[0];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) mx = fmaxf(mx, s_max[w]);
+    for (int q = 0; q < NQ; ++q) {
+        mx[q] = wave_max(mx[q]);
+        if (lane == 0) s_max[wave * NQ + q] = mx[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float m = s_max[q];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, s_max[w * NQ + q]);
+        mx[q] = m;
+    }
 
     const int slot = p.align_out ? p.align_slot[h] : -1;
-    float* adst = nullptr;
-    size_t rowi = 0;
-    if (slot >= 0) {
-        rowi = ((size_t)b * p.n_align + slot) * p.align_rows + p.pos[b];
-        adst = p.align_out + rowi * p.n_keys + k_lo;
+    float acc[NQ][8];
+    float lsum[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        lsum[q] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
     }
-    float acc[8] = {};
-    float lsum = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = grp + u * G;
-        const float pk = (k < nk) ? expf(d[u] - mx) : 0.f;
-        if (sub == 0 && k < nk) {
-            lsum += pk;
-            if (adst) adst[k] = pk;                            // un-normalised; align_normalize_kernel finishes the row
-        }
-        if (k < nk) {
-            float vv[8];
-            vr[u].cvt(vv);
+        float vv[8];
+        vr[u].cvt(vv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+        for (int q = 0; q < NQ; ++q) {
+            const float pk = (k < nk) ? expf(d[q][u] - mx[q]) : 0.f;
+            if (sub == 0 && k < nk) {
+                lsum[q] += pk;
+                if (slot >= 0) {                               // un-normalised; align_normalize_kernel finishes the row
+                    const size_t rowi = ((size_t)(b0 + q) * p.n_align + slot) * p.align_rows + p.pos[b0 + q];
+                    p.align_out[rowi * p.n_keys + k_lo + k] = pk;
+                }
+            }
+            if (k < nk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[q][e] = fmaf(pk, vv[e], acc[q][e]);
+            }
         }
     }
     // sum over the wave's 8 key groups (lane bits 3, 4, 5)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = xor32_sum(xor16_sum(row_ror8_add(acc[e])));
-    lsum = wave_sum(lsum);
-    if (lane < 8) {
+    for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[wave * 64 + sub * 8 + e] = acc[e];
+        for (int e = 0; e < 8; ++e) acc[q][e] = xor32_sum(xor16_sum(row_ror8_add(acc[q][e])));
+        lsum[q] = wave_sum(lsum[q]);
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(wave * NQ + q) * 64 + sub * 8 + e] = acc[q][e];
+        }
+        if (lane == 0) red_l[wave * NQ + q] = lsum[q];
     }
-    if (lane == 0) red_l[wave] = lsum;
     __syncthreads();
-    if (tid < 64) {
+    for (int i = tid; i < NQ * 64; i += CROSS_THREADS) {
+        const int q = i >> 6, c = i & 63;
         float r = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) r += red[w * 64 + tid];
-        p.part_o[((size_t)sp * p.B + b) * p.H * 64 + h * 64 + tid] = r;
+        for (int w = 0; w < 8; ++w) r += red[(w * NQ + q) * 64 + c];
+        p.part_o[((size_t)sp * p.B + b0 + q) * p.H * 64 + h * 64 + c] = r;
     }
-    if (tid == 64) {
+    if (tid >= 64 * NQ && tid < 64 * NQ + NQ) {
+        const int q = tid - 64 * NQ;
         float l = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) l += red_l[w];
-        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp) * 2;
-        ml[0] = mx; ml[1] = l;
-        if (slot >= 0) { p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l; }
+        for (int w = 0; w < 8; ++w) l += red_l[w * NQ + q];
+        float* ml = p.part_ml + (((size_t)(b0 + q) * p.H + h) * ATT_NS + sp) * 2;
+        ml[0] = mx[q]; ml[1] = l;
+        if (slot >= 0) {
+            const size_t rowi = ((size_t)(b0 + q) * p.n_align + slot) * p.align_rows + p.pos[b0 + q];
+            p.align_ml[(rowi * ATT_NS + sp) * 2] = mx[q]; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l;
+        }
     }
+}
+
+template <int NQ>
+static void launch_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
+    dim3 grid(p.H, p.B / NQ, ATT_NS);
+    if (bf16) hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, NQ>), grid, dim3(CROSS_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((attn_cross_split_kernel<float, NQ>), grid, dim3(CROSS_THREADS), 0, st, p);
 }
 
 int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > 4 * (CROSS_THREADS / 8) || CROSS_THREADS != 512) return CW_ERR_INVALID;
-    dim3 grid(p.H, p.B, ATT_NS);
-    if (bf16) hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t>), grid, dim3(CROSS_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((attn_cross_split_kernel<float>), grid, dim3(CROSS_THREADS), 0, st, p);
+    static const bool per_row = getenv("CW_CROSS_PER_ROW") != nullptr;   // A/B: one block per row even under beam search
+    const int nq = (p.kv_div > 1 && p.kv_div <= 6 && p.B % p.kv_div == 0 && !per_row) ? p.kv_div : 1;
+    switch (nq) {
+        case 2: launch_cross_split<2>(bf16, p, st); break;
+        case 3: launch_cross_split<3>(bf16, p, st); break;
+        case 4: launch_cross_split<4>(bf16, p, st); break;
+        case 5: launch_cross_split<5>(bf16, p, st); break;
+        case 6: launch_cross_split<6>(bf16, p, st); break;
+        default: launch_cross_split<1>(bf16, p, st); break;
+    }
     return CW_OK;
 }
 

@@ -97,7 +97,7 @@ struct cw_ctx {
     int beam_K = 0, beam_items = 0, beam_n_prompt = 0;
     int *d_anc = nullptr, *d_anc_tmp = nullptr, *d_ids_tmp = nullptr, *d_parent = nullptr, *d_tok = nullptr, *d_cand_id = nullptr,
         *d_rowmap = nullptr;
-    float *d_cand_val = nullptr, *d_align_g = nullptr;
+    float *d_cand_val = nullptr, *d_align_g = nullptr, *d_topk_scratch = nullptr;
     const float* align_cur = nullptr;     // alignment rows the timestamp stage reads (d_align, or the beam-gathered copy)
     float* logits_capture = nullptr;
     int logits_capture_steps = 0;
@@ -991,6 +991,7 @@ static int beam_alloc(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_parent, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_tok, Bm * 4));
     CWCHK(c, dmalloc(c, &c->d_cand_val, (size_t)Bm * 64 * 4)); CWCHK(c, dmalloc(c, &c->d_cand_id, (size_t)Bm * 64 * 4));
     CWCHK(c, dmalloc(c, &c->d_rowmap, (size_t)Bm * TGT * 4));
+    CWCHK(c, dmalloc(c, &c->d_topk_scratch, KD(c, cw_beam_topk_scratch_floats, Bm) * 4));
     return CW_OK;
 }
 
@@ -1045,7 +1046,7 @@ int32_t cw_beam_step(cw_ctx* c, int32_t n_cand, float* cand_logprob, int32_t* ca
     sp.max_initial_timestamp_index = c->gen.max_initial_timestamp_index;
     sp.cfg = c->d_cfg; sp.pos = c->d_pos; sp.ids_stride = c->d.max_target_positions; sp.ids = c->d_ids;
     sp.embed_bf16 = c->bf16 ? 1 : 0;
-    CWCHK(c, KD(c, cw_launch_beam_topk, sp, n_cand, c->d_cand_val, c->d_cand_id, c->st));
+    CWCHK(c, KD(c, cw_launch_beam_topk, sp, n_cand, c->d_cand_val, c->d_cand_id, c->d_topk_scratch, c->st));
     KCHK(c);
     tm.stop();
     HIPCHK(c, hipMemcpy(cand_logprob, c->d_cand_val, (size_t)rows * n_cand * 4, hipMemcpyDeviceToHost));
@@ -1458,6 +1459,7 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
 
 int32_t cw_test_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "gemm256_min_tiles")) { cw_bf16::cw_gemm_set_256_min_tiles(value); cw_f16::cw_gemm_set_256_min_tiles(value); return CW_OK; }
+    if (!strcmp(name, "beam_topk_1block")) { cw_bf16::cw_beam_topk_set_1block(value); cw_f16::cw_beam_topk_set_1block(value); return CW_OK; }
     if (!strcmp(name, "gemm_pp")) { cw_bf16::cw_gemm_set_pp(value); cw_f16::cw_gemm_set_pp(value); return CW_OK; }
     return CW_ERR_INVALID;
 }

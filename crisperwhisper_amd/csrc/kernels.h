@@ -121,7 +121,9 @@ struct MelTables {
     int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d, hipStream_t st); \
     int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d, hipStream_t st); \
     int cw_launch_sample(const SampleParams& p, hipStream_t st); \
-    int cw_launch_beam_topk(const SampleParams& p, int n_cand, float* cand_val, int* cand_id, hipStream_t st); \
+    int cw_launch_beam_topk(const SampleParams& p, int n_cand, float* cand_val, int* cand_id, float* scratch, hipStream_t st); \
+    size_t cw_beam_topk_scratch_floats(int rows); \
+    void cw_beam_topk_set_1block(int on); \
     int cw_launch_beam_advance(const BeamAdvanceParams& p, hipStream_t st); \
     int cw_launch_align_gather(const float* align, const int* row_of_pos, int n_items, int n_align, int align_rows, int L, int n_keys, float* out, hipStream_t st); \
     int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st); \

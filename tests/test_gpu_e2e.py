@@ -738,6 +738,28 @@ def test_pipeline_beam_search_word_for_word_vs_reference(tiny, name):
         pipe.engine.close()
 
 
+@pytest.mark.parametrize("dt", ["float32", "bfloat16"])
+def test_beam_topk_two_stage_equals_single_block_kernel(tiny, dt):
+    """The sliced two-stage candidate selection (16 slices x rows blocks + one merging wave per row) against the single-block
+    kernel it replaced, through the whole 5-beam pipeline on 3 chunks (15 rows; prompt step with the begin-suppress /
+    max-initial-timestamp rules, text and timestamp phases, forced-timestamp steps): identical words and timestamps."""
+    g, v, W, spec = tiny
+    x = syn.synth_audio(91, 50 * 16000, "mixed")
+    outs = []
+    pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30, batch_size=3,
+                       return_timestamps="word", torch_dtype=dt, device="cuda:0")
+    try:
+        for one_block in (1, 0):
+            assert pipe.engine.lib.cw_test_set_option(b"beam_topk_1block", one_block) == 0
+            outs.append(pipe(x, generate_kwargs={**Hh.GEN_KW, "num_beams": 5, "max_new_tokens": 20}))
+    finally:
+        pipe.engine.lib.cw_test_set_option(b"beam_topk_1block", 0)
+        pipe.engine.close()
+    assert outs[0]["text"] == outs[1]["text"] and len(outs[0]["chunks"]) > 3
+    assert [c["timestamp"] for c in outs[0]["chunks"]] == [c["timestamp"] for c in outs[1]["chunks"]]
+
+
 def test_beam_search_bf16_engine_many_rows_tracks_f32_engine(tiny):
     """bf16 engine, 4 chunks x 5 beams = 20 decoder rows (the 17..64-row GEMV path + ancestry attention + the key-split
     cross-attention shared per item): runs, is well formed, and its first generate call picks the f32 engine's hypotheses
