@@ -562,7 +562,11 @@ template <> struct Raw8<float> {
 };
 template <> struct Raw8<bf16_t> {
     uint4 a;
-    __device__ inline void ld(const bf16_t* p) { a = *(const uint4*)p; }
+    __device__ inline void ld(const bf16_t* p) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+        const u4 t = CW_STREAM_LD((const u4*)p);
+        a = make_uint4(t[0], t[1], t[2], t[3]);
+    }
     __device__ inline void cvt(float* o) const { h16_unpack8(a, o); }
 };
 

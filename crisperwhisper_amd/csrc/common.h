@@ -20,6 +20,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;   // one MFMA 16x16 C
 
 #define CW_WAVE 64
 
+// Streams that one block reads once per launch (decode weights, K/V caches): non-temporal loads -- `global_load ... nt` --
+// land ~18 % sooner than default-policy loads on this chip (MI355X_MICROARCH.md price list, row nt-weights) and do not
+// displace the activations that every block re-reads from L2.  -DCW_NO_NT restores the default policy (A/B builds).
+#ifdef CW_NO_NT
+#define CW_STREAM_LD(p) (*(p))
+#else
+#define CW_STREAM_LD(p) __builtin_nontemporal_load(p)
+#endif
+
 // host conversions of both formats (the engine TU uploads weights for either build)
 static inline float cw_host_bf16_to_f32(unsigned short v) { union { uint32_t u; float f; } x; x.u = ((uint32_t)v) << 16; return x.f; }
 static inline unsigned short cw_host_f32_to_bf16(float f) {   // round-nearest-even (NaN stays quiet NaN)
