@@ -203,6 +203,7 @@ int read_residual(BitReader& br, int n, int order, std::vector<int64_t>& res) {
             for (int k = 0; k < cnt; ++k) {
                 const uint64_t q = br.unary();
                 const uint64_t v = (q << param) | (param ? br.u(param) : 0);
+                if (v >> 33) return flac_fail("FLAC residual outside 32 bits (corrupt stream)");   // RFC 9639 9.2.7.3: |residual| < 2^31
                 res[idx++] = (int64_t)(v >> 1) ^ -(int64_t)(v & 1);
             }
         }
@@ -218,6 +219,7 @@ int read_subframe(BitReader& br, int n, int bps, std::vector<int64_t>& out) {
     if (br.u(1)) wasted = (int)br.unary() + 1;
     if (wasted >= bps) return flac_fail("FLAC wasted bits exceed the sample size");
     bps -= wasted;
+    const int64_t lim = (int64_t)1 << bps;                   // one bit of slack over the legal range; bounds the predictor sums below
     out.assign(n, 0);
     if (type == 0) {                                         // CONSTANT
         const int64_t v = br.s(bps);
@@ -240,6 +242,7 @@ int read_subframe(BitReader& br, int n, int bps, std::vector<int64_t>& out) {
                 default: break;
             }
             out[i] += p;
+            if (out[i] >= lim || out[i] < -lim) return flac_fail("FLAC sample outside its bit depth (corrupt stream)");
         }
     } else if (type >= 32) {                                 // LPC, order (type & 31) + 1
         const int order = (type & 31) + 1;
@@ -255,8 +258,9 @@ int read_subframe(BitReader& br, int n, int bps, std::vector<int64_t>& out) {
         if (r) return r;
         for (int i = order; i < n; ++i) {
             int64_t acc = 0;
-            for (int k = 0; k < order; ++k) acc += coef[k] * out[i - 1 - k];
+            for (int k = 0; k < order; ++k) acc += coef[k] * out[i - 1 - k];   // |coef| < 2^15, |out| < 2^33, order <= 32: < 2^53
             out[i] += acc >> shift;
+            if (out[i] >= lim || out[i] < -lim) return flac_fail("FLAC sample outside its bit depth (corrupt stream)");
         }
     } else {
         return flac_fail("reserved FLAC subframe type");

@@ -316,7 +316,7 @@ def test_flac_decoder_fails_loudly_on_corruption():
     pcm, _ = _decode(good)
     assert pcm.shape == (2048, 2)
     audio_off = good.index(bytes([0xFF, 0xF8]))
-    for mutate, msg in ((lambda b: b[:audio_off + 40] + bytes([b[audio_off + 40] ^ 0x10]) + b[audio_off + 41:], "CRC-16|residual|subframe|sync"),
+    for mutate, msg in ((lambda b: b[:audio_off + 40] + bytes([b[audio_off + 40] ^ 0x10]) + b[audio_off + 41:], "CRC-16|residual|subframe|sync|bit depth"),
                         (lambda b: b[:audio_off + 2] + bytes([b[audio_off + 2] ^ 0x01]) + b[audio_off + 3:], "CRC-8|reserved|sync"),
                         (lambda b: b[:26] + bytes([b[26] ^ 0xFF]) + b[27:], "MD5"),
                         (lambda b: b[:len(b) - 300], "truncated|ends before|CRC|sync"),

@@ -212,7 +212,7 @@ def test_pipeline_argument_errors_mirror_reference():
     from crisperwhisper_amd.pipeline import _device_index, _dtype_name
     with pytest.raises(ValueError):
         _device_index("cpu")
-    assert _device_index("cuda:3") == 3 and _device_index(None) == 0 and _dtype_name("torch.float16") == "bf16" and _dtype_name("torch.float32") == "f32"
+    assert _device_index("cuda:3") == 3 and _device_index(None) == 0 and _dtype_name("torch.float16") == "f16" and _dtype_name("torch.bfloat16") == "bf16" and _dtype_name("torch.float32") == "f32"
 
 
 def test_timestamp_accuracy_harness():
