@@ -106,6 +106,46 @@ class ModelBundle:
         return cls(spec, _SafetensorsWeights(path))
 
 
+    @classmethod
+    def from_ctranslate2(cls, path: str) -> "ModelBundle":
+        """Load a faster-whisper / CTranslate2 model directory (``model.bin`` + ``config.json`` + ``tokenizer.json`` or
+        ``vocabulary.json``; REF/README.md:186-203 distributes CrisperWhisper in this form too).  Geometry comes from the
+        tensor shapes and the recorded head count, the generation settings from CTranslate2's ``config.json``
+        (``alignment_heads``, ``suppress_ids``, ``suppress_ids_begin``, ``lang_ids``) and the token table; weights are
+        de-fused / de-quantised to the transformers names the engine loads.  Layout restated from CTranslate2's published
+        spec -- parity unpinned, see ``crisperwhisper_amd/ct2.py``."""
+        import json
+        import os
+        from . import ct2
+        from .languages import LANGUAGES
+        _, var, aliases = ct2.read_model_bin(os.path.join(path, "model.bin"))
+        geo = ct2.geometry(var)
+        cpath = os.path.join(path, "config.json")
+        cfg = json.load(open(cpath)) if os.path.exists(cpath) else {}
+        if not cfg.get("alignment_heads"):
+            raise ValueError("Model generation config has no `alignment_heads`, token-level timestamps not available. "
+                             "See https://gist.github.com/hollance/42e32852f24243b748ae6bc1f985b13a on how to add this "
+                             "property to the generation config.")
+        ids = ct2.vocabulary_ids(path)
+        if "<|notimestamps|>" not in ids:
+            raise ValueError("The generation config is outdated: `no_timestamps_token_id` is missing.")
+        lang_to_id = {f"<|{c}|>": ids[f"<|{c}|>"] for c in LANGUAGES if f"<|{c}|>" in ids}
+        spec = ModelSpec(
+            d_model=geo["d_model"], n_heads=geo["n_heads"], ffn_dim=geo["ffn_dim"], enc_layers=geo["enc_layers"],
+            dec_layers=geo["dec_layers"], n_mels=geo["n_mels"], vocab_size=geo["vocab_size"],
+            max_target_positions=geo["max_target_positions"], median_filter_width=7,
+            alignment_heads=[list(h) for h in cfg["alignment_heads"]],
+            eos_token_id=ids["<|endoftext|>"], pad_token_id=ids["<|endoftext|>"],
+            decoder_start_token_id=ids["<|startoftranscript|>"], no_timestamps_token_id=ids["<|notimestamps|>"],
+            max_initial_timestamp_index=50,
+            suppress_tokens=[int(t) for t in cfg.get("suppress_ids", []) if int(t) >= 0],
+            begin_suppress_tokens=[int(t) for t in cfg.get("suppress_ids_begin", []) if int(t) >= 0],
+            lang_to_id=lang_to_id,
+            task_to_id={k: ids[f"<|{k}|>"] for k in ("transcribe", "translate") if f"<|{k}|>" in ids},
+            max_length=geo["max_target_positions"], forced_decoder_ids=None, language=None, task=None)
+        return cls(spec, ct2.to_hf_state(var, aliases))
+
+
 class _SafetensorsWeights(dict):
     """``items()`` streams (HF name, float32 array) out of model.safetensors / its shards; nothing is held in memory."""
 
@@ -179,7 +219,11 @@ class CrisperWhisperPipeline:
         if isinstance(model, str):               # local checkpoint directory: no transformers object needed
             if tokenizer is None:
                 tokenizer = collate.Vocabulary.from_pretrained(model)
-            model = ModelBundle.from_pretrained(model)
+            import os as _os
+            # a faster-whisper / CTranslate2 directory (model.bin, no safetensors) is read through its own loader
+            ct2_dir = _os.path.exists(_os.path.join(model, "model.bin")) and not any(
+                _os.path.exists(_os.path.join(model, f)) for f in ("model.safetensors", "model.safetensors.index.json"))
+            model = ModelBundle.from_ctranslate2(model) if ct2_dir else ModelBundle.from_pretrained(model)
         self.bundle = model if isinstance(model, ModelBundle) else ModelBundle.from_hf(model)
         if tokenizer is None:
             raise ValueError("a tokenizer (WhisperTokenizer or crisperwhisper_amd.collate.Vocabulary) is required")

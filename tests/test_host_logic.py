@@ -279,6 +279,53 @@ def test_checkpoint_directory_loads_without_transformers(tmp_path):
         collate.Vocabulary.from_pretrained(str(tmp_path))
 
 
+def test_ctranslate2_directory_loads_like_the_transformers_checkpoint(tmp_path):
+    """SURVEY 8(f).4, weight-layout half: a faster-whisper style directory (model.bin in CTranslate2's layout, its config.json,
+    tokenizer.json) gives the same ModelSpec fields and -- for float32 storage -- bit-identical weights as the transformers
+    checkpoint it was converted from; float16 and int8 storage de-quantise to within their resolution.  The writer is
+    independent test code (tests/ct2_writer.py); the real converter is not available offline, so this pins the reader to the
+    published layout, not to CTranslate2 itself (DESIGN 6c says so)."""
+    pytest.importorskip("transformers")
+    import dataclasses
+    import json
+    import crisperwhisper_amd as cw
+    from tests import ct2_writer
+    from tests.golden import hf_synth as H
+    g, v = syn.tiny_geometry()
+    model = H.build_model(g, v, n_align=3)
+    tok = H.build_tokenizer(v)
+    a = cw.ModelBundle.from_hf(model)
+    for storage, tol in (("float32", 0.0), ("float16", 1e-3), ("int8", 1.2e-2)):
+        d = tmp_path / storage
+        d.mkdir()
+        tok.save_pretrained(str(d))
+        gc = model.generation_config
+        json.dump({"alignment_heads": [list(h) for h in gc.alignment_heads], "suppress_ids": list(gc.suppress_tokens or []),
+                   "suppress_ids_begin": list(gc.begin_suppress_tokens or []), "lang_ids": sorted(gc.lang_to_id.values())},
+                  open(d / "config.json", "w"))
+        ct2_writer.write_model_bin(str(d / "model.bin"), a.weights, a.spec.n_heads, a.spec.enc_layers, a.spec.dec_layers, storage)
+        b = cw.ModelBundle.from_ctranslate2(str(d))
+        sa, sb = dataclasses.asdict(a.spec), dataclasses.asdict(b.spec)
+        for k in ("d_model", "n_heads", "ffn_dim", "enc_layers", "dec_layers", "n_mels", "vocab_size", "max_target_positions",
+                  "alignment_heads", "eos_token_id", "pad_token_id", "decoder_start_token_id", "no_timestamps_token_id",
+                  "suppress_tokens", "begin_suppress_tokens", "lang_to_id", "task_to_id", "median_filter_width"):
+            assert sa[k] == sb[k], (storage, k, sa[k], sb[k])
+        assert set(b.weights) == set(a.weights), set(a.weights) ^ set(b.weights)
+        for k, wa in a.weights.items():
+            wb = b.weights[k]
+            assert wb.dtype == np.float32 and wb.shape == wa.shape, k
+            err = float(np.abs(wa - wb).max() / (np.abs(wa).max() + 1e-12))
+            assert err <= tol, (storage, k, err)
+        key = lambda x: (x.token_bytes, x.specials, x.eos, x.timestamp_begin, x.startofprev, x.sot)
+        assert key(collate.Vocabulary.from_pretrained(str(d))) == key(collate.Vocabulary.from_hf_tokenizer(tok))
+    (tmp_path / "float32" / "config.json").write_text("{}")
+    with pytest.raises(ValueError, match="alignment_heads"):
+        cw.ModelBundle.from_ctranslate2(str(tmp_path / "float32"))
+    open(tmp_path / "float32" / "model.bin", "wb").write(b"\x06\x00\x00\x00\x05\x00abc")
+    with pytest.raises(ValueError, match="truncated"):
+        cw.ModelBundle.from_ctranslate2(str(tmp_path / "float32"))
+
+
 def test_output_writers_vs_reference_vtt_and_formats():
     """`writers.timestamps_to_vtt` byte for byte against REF/app.py:74-82 (executed by the golden
     generator, tests/golden/gen_golden.py:gen_vtt), incl. minute / hour carries and the %06.3f rounding; SRT and JSON
