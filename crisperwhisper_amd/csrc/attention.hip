@@ -1,5 +1,8 @@
 // Attention kernels (head_dim = 64 for every Whisper size).
 //
+//   attn_encoder_q64    (default) 64 queries per wave, LDS-DMA staging, transpose reads for V, q-tile software pipeline --
+//                       see the comment block in front of it; attn_encoder_bf16 below is the first-generation kernel it replaced
+//                       (kept for A/B runs, CW_ATTN_V1=1).
 //   attn_encoder_bf16   flash-style fused softmax(Q K^T) V over S = 1500 frames, no mask
 //                       (TF/models/whisper/modeling_whisper.py:215-238, 284-356; q is pre-scaled by
 //                       the projection).  Never materialises the S x S map the HF eager path keeps.

@@ -8,6 +8,9 @@
 //                      output columns* of one row -> vectorised epilogues (epi_store4).
 //   gemm_bf16_256_kernel  the same with 256x256x64 tiles and 8 waves (128x64 per wave) for the large encoder shapes
 //                      (>= 200 tiles): below the per-CU LDS-read and L1->LDS limits the 128 tile sits on.
+//   gemm_bf16_pp_kernel   the 256x256x64 tile on a ping-pong schedule (plain row-major A, N % 256 == 0 -- the encoder's linear
+//                      layers and the cross-K/V projection): the two waves of a SIMD run half a K-tile apart, one issuing its
+//                      64 MFMAs from registers while the other reads the next tile's fragments and issues buffer_load-to-LDS DMA.
 //   gemm_bf16_kernel   register-staged variant of the 128 tiling (fallback, CW_NO_GLDS=1).
 //   gemm_f32_kernel    same contract in plain f32 VALU (parity mode + on-device reference).
 //   gemv2_bf16_kernel  decode-time skinny GEMM (batch rows <= 16 per launch, row groups beyond): weights streamed once
