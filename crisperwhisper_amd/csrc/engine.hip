@@ -1496,6 +1496,45 @@ int32_t cw_test_gemm(cw_ctx* c, int32_t M, int32_t N, int32_t K, const float* A,
     return r;
 }
 
+// e4m3 GEMM of the opt-in encoder mode: A and W are rounded to the engine's 16-bit type, quantised row-wise on the device
+// (quant_rows_fp8_kernel) and multiplied by gemm_fp8_pp_kernel; out = T(A W^T + bias) (gelu optional).  N % 256 == 0, K % 128 == 0.
+int32_t cw_test_gemm_fp8(cw_ctx* c, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias,
+                         int32_t gelu, float* out) {
+    if (!c->bf16) return fail(c, CW_ERR_INVALID, "the fp8 GEMM belongs to the 16-bit engines");
+    void *dA = nullptr, *dW = nullptr, *dO = nullptr, *dA8 = nullptr, *dW8 = nullptr; float *dB = nullptr, *dsa = nullptr, *dsw = nullptr;
+    const size_t e = c->esz;
+    HIPCHK(c, hipMalloc(&dA, (size_t)M * K * e)); HIPCHK(c, hipMalloc(&dW, (size_t)N * K * e));
+    HIPCHK(c, hipMalloc(&dA8, (size_t)M * K)); HIPCHK(c, hipMalloc(&dW8, (size_t)N * K));
+    HIPCHK(c, hipMalloc((void**)&dsa, (size_t)M * 4)); HIPCHK(c, hipMalloc((void**)&dsw, (size_t)N * 4));
+    HIPCHK(c, hipMalloc(&dO, (size_t)M * N * e)); HIPCHK(c, hipMalloc((void**)&dB, (size_t)N * 4));
+    CWCHK(c, upload_T(c, dA, 0, A, (size_t)M * K)); CWCHK(c, upload_T(c, dW, 0, W, (size_t)N * K));
+    if (bias) HIPCHK(c, hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    EpiParams ep = epi0(); ep.out = dO; ep.bias = bias ? dB : nullptr; ep.ldo = N;
+    int r = KD(c, cw_launch_quant_rows_fp8, dA, M, K, dA8, dsa, c->st);
+    if (r == CW_OK) r = KD(c, cw_launch_quant_rows_fp8, dW, N, K, dW8, dsw, c->st);
+    if (r == CW_OK) r = KD(c, cw_launch_gemm_fp8, gelu ? EPI_GELU : EPI_STORE, dA8, K, dW8, M, N, K, dsa, dsw, ep, c->st);
+    if (r != CW_OK) fail(c, r, "test_gemm_fp8: launch rejected (M=%d N=%d K=%d)", M, N, K);
+    if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemm_fp8: %s", hipGetErrorString(er)); }
+    if (const char* reps_s = getenv("CW_TEST_GEMM_REPS")) {   // kernel timing for the profiles (stderr only)
+        const int reps = atoi(reps_s);
+        hipEvent_t e0, e1;
+        if (r == CW_OK && reps > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            hipEventRecord(e0, c->st);
+            for (int i = 0; i < reps && r == CW_OK; ++i) r = KD(c, cw_launch_gemm_fp8, gelu ? EPI_GELU : EPI_STORE, dA8, K, dW8, M, N, K, dsa, dsw, ep, c->st);
+            hipEventRecord(e1, c->st);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double us = 1e3 * ms / reps;
+            fprintf(stderr, "[cw_test_gemm_fp8] M=%d N=%d K=%d gelu=%d: %.2f us/launch, %.1f TFLOP/s\n", M, N, K, gelu, us, 2.0 * M * N * K / us * 1e-6);
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+    }
+    if (r == CW_OK) r = download_T(c, dO, 0, out, (size_t)M * N);
+    hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dB); hipFree(dA8); hipFree(dW8); hipFree(dsa); hipFree(dsw);
+    return r;
+}
+
 int32_t cw_test_gemv(cw_ctx* c, int32_t Mb, int32_t N, int32_t K, const float* x, const float* W, const float* bias,
                      const float* ln_g, const float* ln_b, int32_t gelu, float* out) {
     float *dx = nullptr, *dB = nullptr, *dO = nullptr, *dg = nullptr, *db = nullptr, *dxn = nullptr; void* dW = nullptr;

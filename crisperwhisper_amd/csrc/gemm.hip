@@ -583,6 +583,182 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// OCP e4m3 flavour of the ping-pong GEMM (opt-in encoder mode, BASELINE configs[3]): C[M,N] = (A8 * W8^T) * sa[m] * sw[n].
+// A and W hold one byte per element with one f32 scale per row (quant_rows_fp8_kernel / layernorm_fp8_kernel); the MFMA is
+// v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (e8m0 127) -- on gfx950 the only fp8 form that runs at twice the
+// bf16 rate.  A 256 x 128-byte operand tile is byte-identical in shape to the bf16 kernel's 256 x 64-element tile, so LDS
+// image, swizzle, DMA map and schedule are the ping-pong kernel's; a lane's 32 operand bytes are the two 16-byte fragments
+// the bf16 kernel feeds to two MFMAs (chunk g and chunk 4 + g of the row: k = g*16.. and 64 + g*16.., which is also the
+// instruction's own k order -- tests/native/mfma_fp8_probe.hip), so one K-tile is 32 MFMAs of K = 128 instead of 64 of K = 32.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+// one operand fragment = 32 bytes of a row: 16-byte chunks g and 4 + g, read straight into the halves of one 8-register tuple
+__device__ inline i32x8_t frag_fp8(const unsigned char* row, int c_lo, int c_hi) {
+    const u32x4_t lo = *(const u32x4_t*)(row + c_lo), hi = *(const u32x4_t*)(row + c_hi);
+    return (i32x8_t){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_fp8_pp_kernel(const unsigned char* __restrict__ A, int lda,
+                                                          const unsigned char* __restrict__ W, int M, int N, int K,
+                                                          const float* __restrict__ sa, const float* __restrict__ sw,
+                                                          EpiParams ep, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm4[];   // [2][A 32 KB | W 32 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;   // wm is also the group
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int mt_, nt_;
+    grouped_tile(tile, gridDim.x / tiles_n, tiles_n, mt_, nt_);
+    const int m0 = mt_ * BM2, n0 = nt_ * BN2;
+
+    const int lrow = lane >> 3;
+    const int csrc = ((lane & 7) ^ lrow) * 16;                 // bytes
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    int va[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) va[q] = min(m0 + wave * 32 + q * 8 + lrow, M - 1) * lda + csrc;
+    const int vw = (n0 + wave * 32 + lrow) * K + csrc;
+    auto issue = [&](int k0, int buf) {
+        unsigned char* base = gsm4 + buf * 65536 + wave * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, va[q], k0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(base + 32768 + q * 1024), 16, vw,
+                                                     k0 + q * 8 * K, 0, 0);
+        }
+    };
+    const int sw_ = l15 & 7;
+    const int aoff = (wm * 128 + l15) * 128, woff = 32768 + (wn * 64 + l15) * 128;
+    i32x8_t fa[8], fw[4];
+    const int c_lo = (g ^ sw_) << 4, c_hi = ((4 + g) ^ sw_) << 4;
+    auto read_frags = [&](int buf) {
+        const unsigned char* sb = gsm4 + buf * 65536;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[j] = frag_fp8(sb + woff + j * 2048, c_lo, c_hi);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = frag_fp8(sb + aoff + i * 2048, c_lo, c_hi);
+    };
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    auto mfmas = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[j], fa[i], acc[i][j], 0, 0, 0, 127, 0, 127);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nk = K / 128;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 0) {   // same phases as gemm_bf16_pp_kernel; the loop is rotated so that a tile's fragments are read and consumed
+                     // inside one iteration (carried across the back edge they cost ~150 spilled registers here)
+        read_frags(0);
+        if (nk > 1) issue(128, 1);
+        __builtin_amdgcn_s_barrier();                              // closes phase -1
+        mfmas();                                                   // phase 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t + 1 < nk; ++t) {
+            read_frags((t + 1) & 1);                               // phase 2t+1
+            if (t + 2 < nk) issue((t + 2) * 128, t & 1);
+            __builtin_amdgcn_s_barrier();
+            mfmas();                                               // phase 2t+2: tile t+1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();                              // phase 2nk-1 (G1's last MFMA phase)
+    } else {
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) {
+            read_frags(t & 1);
+            if (t + 1 < nk) issue((t + 1) * 128, (t + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mfmas();
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // de-quantise: row scale x column scale, then the usual epilogues
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 cs = *(const float4*)(sw + n0 + wn * 64 + j * 16 + g * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float rs = sa[min(m0 + wm * 128 + i * 16 + l15, M - 1)];
+            acc[i][j][0] *= rs * cs.x; acc[i][j][1] *= rs * cs.y; acc[i][j][2] *= rs * cs.z; acc[i][j][3] *= rs * cs.w;
+        }
+    }
+    const bool vec_ok = (EPI == EPI_HEADS || (ep.ldo & 3) == 0);
+    if (m0 + BM2 <= M && vec_ok) {   // interior tile (block-uniform)
+        int cols[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cols[j] = n0 + wn * 64 + j * 16 + g * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int rows[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rows[i] = m0 + wm * 128 + (h * 4 + i) * 16 + l15;
+            epi_tile_interior<bf16_t, EPI>(ep, rows, cols, *(const f32x4_t(*)[4][4])&acc[h * 4]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int m = m0 + wm * 128 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + wn * 64 + j * 16 + g * 4;
+            if (vec_ok) {
+                epi_store4<bf16_t, EPI>(ep, m, n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi_store1<bf16_t, EPI>(ep, m, n + r, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// Row-wise e4m3 quantisation of a 16-bit matrix (weights at option time; activations that no fused producer quantises):
+// out8[r][k] = e4m3(x[r][k] / s_r), s_r = max_k |x[r][k]| / 448.  One wave per row, K % 8 == 0.
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int rows, int K,
+                                                             unsigned char* __restrict__ out, float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (size_t)row * K;
+    float amax = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        float v[8];
+        h16_unpack8(*(const uint4*)(xr + k), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    }
+    amax = wave_max(amax);
+    const float s = amax > 0.f ? amax / 448.0f : 1.0f, inv = 1.0f / s;
+    if (lane == 0) scale[row] = s;
+    for (int k = lane * 8; k < K; k += 512) {
+        float v[8];
+        h16_unpack8(*(const uint4*)(xr + k), v);
+        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+        int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, 0, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+        *(uint2*)(out + (size_t)row * K + k) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // f32 parity GEMM: 64x64 tile, 256 threads, 4x4 outputs per thread, BK = 16.
 // ---------------------------------------------------------------------------------------------------
 template <int EPI>
@@ -1235,6 +1411,37 @@ int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, 
         case EPI_GELU_POS_F32: launch_gemm_epi<EPI_GELU_POS_F32>(bf16, ap, W, M, N, K, ep, st); break;
         case EPI_HEADS: launch_gemm_epi<EPI_HEADS>(bf16, ap, W, M, N, K, ep, st); break;
         case EPI_STORE_F32: launch_gemm_epi<EPI_STORE_F32>(bf16, ap, W, M, N, K, ep, st); break;
+        default: return CW_ERR_INVALID;
+    }
+    return CW_OK;
+}
+
+int cw_launch_quant_rows_fp8(const void* x, int rows, int K, void* out8, float* scale, hipStream_t st) {
+    if (K % 8 != 0 || rows <= 0) return CW_ERR_INVALID;
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)x, rows, K, (unsigned char*)out8, scale);
+    return CW_OK;
+}
+
+template <int EPI>
+static void launch_gemm_fp8_epi(const void* A8, int lda, const void* W8, int M, int N, int K, const float* sa, const float* sw,
+                                const EpiParams& ep, hipStream_t st) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        hipFuncSetAttribute((const void*)gemm_fp8_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    });
+    const int tm2 = (M + BM2 - 1) / BM2, tn2 = N / BN2;
+    hipLaunchKernelGGL((gemm_fp8_pp_kernel<EPI>), dim3(tm2 * tn2), dim3(512), 131072, st, (const unsigned char*)A8, lda,
+                       (const unsigned char*)W8, M, N, K, sa, sw, ep, tn2);
+}
+
+// e4m3 x e4m3 GEMM with per-row scales of both operands; N % 256 == 0, K % 128 == 0, lda in bytes (= elements)
+int cw_launch_gemm_fp8(int epi, const void* A8, int lda, const void* W8, int M, int N, int K, const float* sa, const float* sw,
+                       const EpiParams& ep, hipStream_t st) {
+    if (K % 128 != 0 || N % BN2 != 0 || M <= 0 || (size_t)M * lda >= 0x7fffffffull || (size_t)N * K >= 0x7fffffffull) return CW_ERR_INVALID;
+    switch (epi) {
+        case EPI_STORE: launch_gemm_fp8_epi<EPI_STORE>(A8, lda, W8, M, N, K, sa, sw, ep, st); break;
+        case EPI_GELU: launch_gemm_fp8_epi<EPI_GELU>(A8, lda, W8, M, N, K, sa, sw, ep, st); break;
+        case EPI_HEADS: launch_gemm_fp8_epi<EPI_HEADS>(A8, lda, W8, M, N, K, sa, sw, ep, st); break;
         default: return CW_ERR_INVALID;
     }
     return CW_OK;

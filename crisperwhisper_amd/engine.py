@@ -297,6 +297,14 @@ class Engine:
         self._chk(self.lib.cw_test_gemm(self.ctx, A.shape[0], W.shape[0], A.shape[1], _ptr(A), _ptr(W), _ptr(b), int(gelu), _ptr(out)))
         return out
 
+    def test_gemm_fp8(self, A, W, bias=None, gelu=False):
+        """A W^T (+ bias, optional GELU) through the e4m3 GEMM of the opt-in fp8 encoder mode (row-wise scales of both operands)."""
+        A = np.ascontiguousarray(A, np.float32); W = np.ascontiguousarray(W, np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        out = np.zeros((A.shape[0], W.shape[0]), np.float32)
+        self._chk(self.lib.cw_test_gemm_fp8(self.ctx, A.shape[0], W.shape[0], A.shape[1], _ptr(A), _ptr(W), _ptr(b), int(gelu), _ptr(out)))
+        return out
+
     def test_gemv(self, x, W, bias=None, ln=None, gelu=False):
         x = np.ascontiguousarray(x, np.float32); W = np.ascontiguousarray(W, np.float32)
         b = None if bias is None else np.ascontiguousarray(bias, np.float32)

@@ -220,6 +220,9 @@ void cw_collate_free(cw_collator* c);
 int32_t cw_test_set_option(const char* name, int32_t value);
 int32_t cw_test_gemm(cw_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, const float* W,
                      const float* bias, int32_t gelu, float* out);
+/* e4m3 x e4m3 GEMM of the opt-in fp8 encoder mode (row-wise scales, v_mfma_scale_f32_16x16x128_f8f6f4): out = T(A W^T + bias) */
+int32_t cw_test_gemm_fp8(cw_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, const float* W, const float* bias,
+                         int32_t gelu, float* out);
 int32_t cw_test_gemv(cw_ctx* ctx, int32_t Mb, int32_t N, int32_t K, const float* x, const float* W,
                      const float* bias, const float* ln_g, const float* ln_b, int32_t gelu, float* out);
 int32_t cw_test_attention(cw_ctx* ctx, int32_t B, int32_t H, int32_t S, const float* q, const float* k,

@@ -77,6 +77,46 @@ def test_gemm_256_tile_kernel(engines, M, N, K):
         eng.lib.cw_test_set_option(b"gemm256_min_tiles", 200)
 
 
+def _e4m3_round(x):
+    """round-to-nearest-even onto the OCP e4m3 grid (|x| <= 448), numpy"""
+    x = np.asarray(x, np.float64)
+    a = np.abs(x)
+    e = np.floor(np.log2(np.maximum(a, 2.0 ** -9)))
+    e = np.maximum(e, -6.0)                                   # subnormals share the exponent of 2^-6
+    q = 2.0 ** (e - 3)
+    return np.sign(x) * np.minimum(np.round(a / q) * q, 448.0)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 256), (777, 256, 1280), (1500, 768, 5120)])
+def test_gemm_fp8_exact_on_representable_inputs_and_quantisation_model_otherwise(engines, M, N, K):
+    """The e4m3 ping-pong GEMM (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales, row scales applied in the epilogue):
+    (1) integer operands whose row maximum is 14 quantise without error (scale 2^-5), so the result must equal the integer GEMM
+    exactly -- any fragment / k-order / schedule mistake shows; (2) on Gaussian operands the result equals, to f32 accumulation
+    accuracy, the f64 GEMM of the operands after the documented quantisation (x -> e4m3(x / s) * s, s = rowmax / 448), i.e. the
+    kernel adds nothing beyond the quantisation it is specified to do; 1, 2, 10 and 40 K-tiles, M edge tiles, repeated runs."""
+    eng = engines["bf16"]
+    rng = np.random.default_rng(M + N + K)
+    A = rng.integers(-14, 15, size=(M, K)).astype(np.float32); A[:, 0] = 14
+    W = rng.integers(-14, 15, size=(N, K)).astype(np.float32); W[:, 1] = -14
+    want = (A.astype(np.int64) @ W.astype(np.int64).T).astype(np.float64)
+    for rep in range(3):
+        got = eng.test_gemm_fp8(A, W)
+        bf = lambda t: (np.asarray(t, np.float32).view(np.uint32) + 0x7FFF + ((np.asarray(t, np.float32).view(np.uint32) >> 16) & 1) & 0xFFFF0000).view(np.float32)
+        assert np.array_equal(got, bf(want.astype(np.float32))), (M, N, K, rep, float(np.abs(got - want).max()))   # output is stored in bf16
+    A = rng.standard_normal((M, K)).astype(np.float32); W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    (A, W) = _round16("bf16", A, W)
+    def q(x):
+        s = np.abs(x).max(axis=1, keepdims=True).astype(np.float32) / np.float32(448.0)
+        inv = (np.float32(1.0) / s).astype(np.float32)
+        return _e4m3_round((x * inv).astype(np.float32)) * s.astype(np.float64)
+    ref = q(A) @ q(W).T + b
+    got = eng.test_gemm_fp8(A, W, b)
+    assert rel_err(got, ref) < 1e-2, (M, N, K, rel_err(got, ref))                       # bf16 output rounding
+    exact = A.astype(np.float64) @ W.astype(np.float64).T + b
+    assert rel_err(got, exact) < 0.12                                                   # what e4m3 operands cost on N(0, 1) data
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 256, 128), (513, 768, 192), (2000, 512, 5120), (3333, 1280, 1280), (1500, 3840, 1280)])
 def test_gemm_pingpong_schedule_is_bit_identical_to_lockstep(engines, M, N, K):
     """The ping-pong 256-tile GEMM (two wave groups half a K-tile apart, LDS-DMA two tiles ahead) accumulates in exactly
