@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=200)
     ap.add_argument("--cross-kv", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: opt-in e4m3 cross-attention cache (accuracy-gated mode, not the headline)")
+    ap.add_argument("--encoder-gemm", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the encoder's qkv / fc1 / fc2 and the cross-K/V projections as e4m3 MFMA GEMMs (opt-in mode, BASELINE "
+                         "configs[3]; accuracy-gated, not the parity path)")
     ap.add_argument("--no-rccl", action="store_true", help="N=1 only: do not create the one-rank RCCL communicator")
     ap.add_argument("--no-longform", action="store_true", help="skip the BASELINE configs[2] leg (600 s recording sharded over the ranks)")
     ap.add_argument("--longform-seconds", type=int, default=600)
@@ -198,6 +201,10 @@ def main():
         if keep_weights:
             weights[name] = w
     t_load = time.perf_counter() - t0
+    if a.encoder_gemm == "fp8":
+        for e_ in engines:
+            e_.check_weights()
+            e_.set_encoder_gemm_fp8(True)
     vocab = collate.Vocabulary.from_synthetic(v)
     utils.bind_engine(eng)
     shard = dist.Shard(rank, world, device=f"cuda:{dev}" if pg == "nccl" else None, collective_at_world1=(pg is not None))
@@ -369,9 +376,10 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: batch={B} x 30 s synthetic 16 kHz audio per GPU, {a.dtype}, "
                                    f"{a.tokens} generated tokens/chunk, geometry {a.geometry}, {a.weights} synthetic weights, "
                                    + ("greedy" if a.num_beams == 1 else f"beam search x{a.num_beams} [not the BASELINE configuration]") + ", word timestamps"
-                                   + (", fp8 (e4m3) cross-attention cache [opt-in mode]" if a.cross_kv == "fp8" else ""),
+                                   + (", fp8 (e4m3) cross-attention cache [opt-in mode]" if a.cross_kv == "fp8" else "")
+                                   + (", fp8 (e4m3) encoder / cross-K/V GEMMs [opt-in mode]" if a.encoder_gemm == "fp8" else ""),
                        "chunks_per_gpu": B * C, "contexts_per_gpu": C, "tokens_per_chunk": a.tokens, "parallelism": f"chunk-dp{world}",
-                       "cross_kv_cache": a.cross_kv, "num_beams": a.num_beams, "weight_load_s": round(t_load, 1)},
+                       "cross_kv_cache": a.cross_kv, "encoder_gemm": a.encoder_gemm, "num_beams": a.num_beams, "weight_load_s": round(t_load, 1)},
             "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1) / C, 3) for k, val in stages.items()},
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
                          "frac": r["achieved"] / 8000.0,

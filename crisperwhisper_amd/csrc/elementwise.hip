@@ -79,6 +79,63 @@ int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const flo
     return CW_OK;
 }
 
+// LayerNorm whose output feeds an e4m3 GEMM (opt-in fp8 encoder mode): the normalised row never leaves the registers in 16 bits --
+// its maximum gives the row scale s = max|y| / 448, and y / s goes out as one byte per element (4 per lane and pass).
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ b, unsigned char* __restrict__ out,
+                                                            float* __restrict__ scale, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * d;
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int k = (lane + 64 * c) * 4;
+        v[c] = (k < d) ? *(const float4*)(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if ((lane + 64 * c) * 4 < d) {
+            float a = v[c].x - mean, bb = v[c].y - mean, cc = v[c].z - mean, e = v[c].w - mean;
+            q += (a * a + bb * bb) + (cc * cc + e * e);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int k = (lane + 64 * c) * 4;
+        if (k < d) {
+            const float4 gg = *(const float4*)(g + k), bb = *(const float4*)(b + k);
+            v[c].x = (v[c].x - mean) * rstd * gg.x + bb.x; v[c].y = (v[c].y - mean) * rstd * gg.y + bb.y;
+            v[c].z = (v[c].z - mean) * rstd * gg.z + bb.z; v[c].w = (v[c].w - mean) * rstd * gg.w + bb.w;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[c].x), fabsf(v[c].y))), fmaxf(fabsf(v[c].z), fabsf(v[c].w)));
+        }
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / 448.0f : 1.0f, inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int k = (lane + 64 * c) * 4;
+        if (k < d) {
+            int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[c].x * inv, v[c].y * inv, 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[c].z * inv, v[c].w * inv, w, true);
+            *(int*)(out + (size_t)row * d + k) = w;
+        }
+    }
+}
+int cw_launch_layernorm_fp8(const float* x, const float* g, const float* b, void* out8, float* scale, int rows, int d, hipStream_t st) {
+    if (d % 4 != 0 || d > 2048 || rows <= 0) return CW_ERR_INVALID;
+    hipLaunchKernelGGL(layernorm_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, g, b, (unsigned char*)out8, scale, rows, d);
+    return CW_OK;
+}
+
 int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d,
                             hipStream_t st) {
     return cw_launch_layernorm(false, x, g, b, out, rows, d, st);

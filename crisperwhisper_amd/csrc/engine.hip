@@ -20,6 +20,8 @@ static thread_local char g_err[512] = "";
 
 struct LayerW {
     void* wqkv = nullptr; float* bqkv = nullptr;
+    void *wqkv8 = nullptr, *w18 = nullptr, *w28 = nullptr, *wkv_c8 = nullptr;   // e4m3 copies (option encoder_gemm_fp8) ...
+    float *sqkv = nullptr, *s1 = nullptr, *s2 = nullptr, *skv_c = nullptr;        // ... and their per-output-row scales
     void* wo = nullptr; float* bo = nullptr;
     float *ln1_g = nullptr, *ln1_b = nullptr;
     void* wq_c = nullptr; float* bq_c = nullptr;
@@ -93,6 +95,8 @@ struct cw_ctx {
     cw_gen_cfg gen{};
     bool gen_set = false;
     bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
+    bool enc8 = false;                   // encoder linear layers + cross-K/V projection as e4m3 GEMMs ("encoder_gemm_fp8")
+    void *h8 = nullptr, *mid8 = nullptr; float *sa8 = nullptr, *smid8 = nullptr;   // e4m3 activations and their row scales
     // beam search (cw_beam_*): rows = items x beams; self-attention keys are found through the ancestry table
     int beam_K = 0, beam_items = 0, beam_n_prompt = 0;
     int *d_anc = nullptr, *d_anc_tmp = nullptr, *d_ids_tmp = nullptr, *d_parent = nullptr, *d_tok = nullptr, *d_cand_id = nullptr,
@@ -692,12 +696,14 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
     const int M = nb * S;
     for (int l = 0; l < c->d.enc_layers; ++l) {
         LayerW& L = c->enc[l];
-        CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, L.ln1_g, L.ln1_b, c->h, M, D, c->st));
+        if (c->enc8) CWCHK(c, KD(c, cw_launch_layernorm_fp8, c->x, L.ln1_g, L.ln1_b, c->h8, c->sa8, M, D, c->st));
+        else CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, L.ln1_g, L.ln1_b, c->h, M, D, c->st));
         {
             AParams ap{c->h, D, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.out = c->qb; ep.out1 = c->kb; ep.out2 = c->vb; ep.bias = L.bqkv;
             ep.T = S; ep.S_pad = c->S_pad; ep.H = H; ep.d_model = D;
-            CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_HEADS, ap, L.wqkv, M, 3 * D, D, ep, c->st));
+            if (c->enc8) CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_HEADS, c->h8, D, L.wqkv8, M, 3 * D, D, c->sa8, L.sqkv, ep, c->st));
+            else CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_HEADS, ap, L.wqkv, M, 3 * D, D, ep, c->st));
         }
         CWCHK(c, KD(c, cw_launch_attn_encoder, bf, c->qb, c->kb, c->vb, c->ao, nb, H, S, c->S_pad, c->st));
         {
@@ -705,19 +711,25 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
             EpiParams ep = epi0(); ep.outf = c->x; ep.resid = c->x; ep.bias = L.bo; ep.ldo = D;
             CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_RESID_F32, ap, L.wo, M, D, D, ep, c->st));
         }
-        CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, L.ln2_g, L.ln2_b, c->h, M, D, c->st));
+        if (c->enc8) CWCHK(c, KD(c, cw_launch_layernorm_fp8, c->x, L.ln2_g, L.ln2_b, c->h8, c->sa8, M, D, c->st));
+        else CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, L.ln2_g, L.ln2_b, c->h, M, D, c->st));
         {
             AParams ap{c->h, D, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.out = c->mid; ep.bias = L.b1; ep.ldo = F;
-            CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_GELU, ap, L.w1, M, F, D, ep, c->st));
+            if (c->enc8) CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_GELU, c->h8, D, L.w18, M, F, D, c->sa8, L.s1, ep, c->st));
+            else CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_GELU, ap, L.w1, M, F, D, ep, c->st));
         }
         {
             AParams ap{c->mid, F, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.outf = c->x; ep.resid = c->x; ep.bias = L.b2; ep.ldo = D;
-            CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_RESID_F32, ap, L.w2, M, D, F, ep, c->st));
+            if (c->enc8) {   // GELU output: its row maxima are only known once fc1 is complete -> one row-wise quantisation pass
+                CWCHK(c, KD(c, cw_launch_quant_rows_fp8, c->mid, M, F, c->mid8, c->smid8, c->st));
+                CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_RESID_F32, c->mid8, F, L.w28, M, D, F, c->smid8, L.s2, ep, c->st));
+            } else CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_RESID_F32, ap, L.w2, M, D, F, ep, c->st));
         }
     }
-    CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, c->enc_ln_g, c->enc_ln_b, c->enc_out, M, D, c->st));
+    CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, c->enc_ln_g, c->enc_ln_b, c->enc_out, M, D, c->st));   // cw_get_encoder_output
+    if (c->enc8) CWCHK(c, KD(c, cw_launch_layernorm_fp8, c->x, c->enc_ln_g, c->enc_ln_b, c->h8, c->sa8, M, D, c->st));
     KCHK(c);
     tm.stop();
     StageTimer tk(c, CW_STAGE_CROSS_KV);
@@ -726,7 +738,8 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
         AParams ap{c->enc_out, D, 0, 0, 0, 0, nullptr, nullptr};
         EpiParams ep = epi0(); ep.out = L.ck; ep.out1 = L.cv; ep.bias = L.bkv_c;
         ep.T = S; ep.S_pad = S; ep.H = H; ep.d_model = D;
-        CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_HEADS, ap, L.wkv_c, M, 2 * D, D, ep, c->st));
+        if (c->enc8) CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_HEADS, c->h8, D, L.wkv_c8, M, 2 * D, D, c->sa8, L.skv_c, ep, c->st));
+        else CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_HEADS, ap, L.wkv_c, M, 2 * D, D, ep, c->st));
         if (c->kv8) CWCHK(c, KD(c, cw_launch_kv_quant_fp8, L.ck, L.cv, L.ck8, L.cv8, L.kvs, nb, H, S, c->st));
     }
     KCHK(c);
@@ -1452,6 +1465,34 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
         c->kv8 = true;
         c->nb_encoded = 0;                                   // windows must be re-encoded to fill the fp8 cache
         for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // graphs hold the kernel choice
+        return CW_OK;
+    }
+    if (!strcmp(name, "encoder_gemm_fp8")) {
+        if (!value) { c->enc8 = false; c->nb_encoded = 0; return CW_OK; }
+        if (!c->bf16) return fail(c, CW_ERR_INVALID, "encoder_gemm_fp8 needs a 16-bit engine (the f32 engine is the parity mode)");
+        const int D = c->d.d_model, F = c->d.ffn_dim;
+        if (D % 256 != 0 || F % 256 != 0 || D > 2048) return fail(c, CW_ERR_INVALID, "encoder_gemm_fp8: d_model / ffn_dim must be multiples of 256 (d_model <= 2048)");
+        CWCHK(c, cw_check_weights(c));                       // the e4m3 copies are made from the resident 16-bit weights
+        if (!c->h8) {
+            const size_t MR = (size_t)c->Bm * CW_N_CTX;
+            CWCHK(c, dmalloc(c, &c->h8, MR * D, false)); CWCHK(c, dmalloc(c, &c->mid8, MR * F, false));
+            CWCHK(c, dmalloc(c, &c->sa8, MR * 4)); CWCHK(c, dmalloc(c, &c->smid8, MR * 4));
+            for (auto& L : c->enc) {
+                CWCHK(c, dmalloc(c, &L.wqkv8, (size_t)3 * D * D, false)); CWCHK(c, dmalloc(c, &L.sqkv, (size_t)3 * D * 4));
+                CWCHK(c, dmalloc(c, &L.w18, (size_t)F * D, false)); CWCHK(c, dmalloc(c, &L.s1, (size_t)F * 4));
+                CWCHK(c, dmalloc(c, &L.w28, (size_t)D * F, false)); CWCHK(c, dmalloc(c, &L.s2, (size_t)D * 4));
+            }
+            for (auto& L : c->dec) { CWCHK(c, dmalloc(c, &L.wkv_c8, (size_t)2 * D * D, false)); CWCHK(c, dmalloc(c, &L.skv_c, (size_t)2 * D * 4)); }
+        }
+        for (auto& L : c->enc) {
+            CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.wqkv, 3 * D, D, L.wqkv8, L.sqkv, c->st));
+            CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.w1, F, D, L.w18, L.s1, c->st));
+            CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.w2, D, F, L.w28, L.s2, c->st));
+        }
+        for (auto& L : c->dec) CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.wkv_c, 2 * D, D, L.wkv_c8, L.skv_c, c->st));
+        KCHK(c);
+        c->enc8 = true;
+        c->nb_encoded = 0;                                   // windows must be re-encoded
         return CW_OK;
     }
     return fail(c, CW_ERR_INVALID, "unknown option %s", name);

@@ -1442,6 +1442,7 @@ int cw_launch_gemm_fp8(int epi, const void* A8, int lda, const void* W8, int M, 
         case EPI_STORE: launch_gemm_fp8_epi<EPI_STORE>(A8, lda, W8, M, N, K, sa, sw, ep, st); break;
         case EPI_GELU: launch_gemm_fp8_epi<EPI_GELU>(A8, lda, W8, M, N, K, sa, sw, ep, st); break;
         case EPI_HEADS: launch_gemm_fp8_epi<EPI_HEADS>(A8, lda, W8, M, N, K, sa, sw, ep, st); break;
+        case EPI_RESID_F32: launch_gemm_fp8_epi<EPI_RESID_F32>(A8, lda, W8, M, N, K, sa, sw, ep, st); break;
         default: return CW_ERR_INVALID;
     }
     return CW_OK;

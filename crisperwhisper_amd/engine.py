@@ -62,10 +62,13 @@ class EngineError(RuntimeError):
 
 class Engine:
     def __init__(self, spec: ModelSpec, dtype: str = "bf16", max_batch: int = 16, device: int = 0,
-                 cross_kv_dtype: Optional[str] = None):
+                 cross_kv_dtype: Optional[str] = None, encoder_gemm_dtype: Optional[str] = None):
         """``dtype``: "f32" (parity engine), "bf16" or "f16" (the 16-bit MFMA engine in bfloat16 / IEEE binary16).
         ``cross_kv_dtype="fp8"`` (16-bit engines only): the decode step streams an OCP e4m3 copy of the cross-attention
-        cache, half the bytes of its dominant stream -- an accuracy-gated performance mode, not the parity path."""
+        cache, half the bytes of its dominant stream -- an accuracy-gated performance mode, not the parity path.
+        ``encoder_gemm_dtype="fp8"`` (16-bit engines only; BASELINE configs[3]): the encoder's qkv / fc1 / fc2 projections and
+        the cross-K/V projection run as e4m3 x e4m3 MFMA GEMMs with row-wise scales (weights quantised once after loading,
+        activations by the LayerNorm that produces them) -- likewise accuracy-gated, not the parity path."""
         self.lib = N.load()
         self.spec = spec
         self.dtype = dtype
@@ -97,6 +100,9 @@ class Engine:
             raise ValueError(f"cross_kv_dtype must be None or 'fp8', got {cross_kv_dtype!r}")
         if cross_kv_dtype == "fp8":
             self._chk(self.lib.cw_set_option(self.ctx, b"cross_kv_fp8", 1))
+        if encoder_gemm_dtype not in (None, "bf16", "f16", "f32", "fp8"):
+            raise ValueError(f"encoder_gemm_dtype must be None or 'fp8', got {encoder_gemm_dtype!r}")
+        self._enc_fp8 = encoder_gemm_dtype == "fp8"
 
     # ------------------------------------------------------------------
     def _chk(self, rc: int):
@@ -128,6 +134,12 @@ class Engine:
         for k, v in weights.items():
             self.load_tensor(k, v)
         self.check_weights()
+        if getattr(self, "_enc_fp8", False):
+            self.set_encoder_gemm_fp8(True)
+
+    def set_encoder_gemm_fp8(self, on: bool):
+        """(Re)build the e4m3 copies of the resident encoder / cross-K/V weights and switch the encoder GEMMs to them, or back."""
+        self._chk(self.lib.cw_set_option(self.ctx, b"encoder_gemm_fp8", 1 if on else 0))
 
     def check_weights(self):
         self._chk(self.lib.cw_check_weights(self.ctx))

@@ -210,6 +210,7 @@ class CrisperWhisperPipeline:
     def __init__(self, model, tokenizer=None, feature_extractor=None, chunk_length_s=0, stride_length_s=None,
                  batch_size=1, return_timestamps=None, torch_dtype=None, dtype=None, device=None,
                  shard: Optional[dist.Shard] = None, contexts: int = 1, cross_kv_dtype: Optional[str] = None,
+                 encoder_gemm_dtype: Optional[str] = None,
                  engines: Optional[List[Engine]] = None, num_beams: Optional[int] = None, **kwargs):
         """``num_beams`` (construction time): the widest beam the contexts are provisioned for -- decoder rows =
         batch_size x num_beams, at most 64.  Default 5 = ``AutomaticSpeechRecognitionPipeline._default_generation_config``
@@ -250,7 +251,8 @@ class CrisperWhisperPipeline:
             self.max_rows = min(e.max_batch for e in self.engines)
         else:
             self.engines = [Engine(self.bundle.spec, dtype=_dtype_name(dtype if dtype is not None else torch_dtype),
-                                   max_batch=self.max_rows, device=_device_index(device), cross_kv_dtype=cross_kv_dtype)
+                                   max_batch=self.max_rows, device=_device_index(device), cross_kv_dtype=cross_kv_dtype,
+                                   encoder_gemm_dtype=encoder_gemm_dtype)
                             for _ in range(max(1, int(contexts)))]
             for e in self.engines:
                 e.load_state_dict(self.bundle.weights)

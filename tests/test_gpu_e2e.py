@@ -631,6 +631,61 @@ def test_fp8_cross_kv_cache_tracks_bf16_cache():
         Engine(spec, dtype="f32", max_batch=1, cross_kv_dtype="fp8")
 
 
+def test_fp8_encoder_gemm_mode_tracks_bf16_engine():
+    """Opt-in e4m3 encoder mode (cw_set_option "encoder_gemm_fp8": qkv / fc1 / fc2 and the cross-K/V projections as
+    v_mfma_scale_f32_16x16x128_f8f6f4 GEMMs, row-wise scales, LayerNorm-fused activation quantisation) against the bf16 GEMMs
+    of the same engine, large-v3 shapes on a 4 + 2 layer stack, teacher-forced -- the accuracy gate of that mode: encoder
+    states within 10 % relative L2 (3-bit mantissas on both operands of three GEMMs per layer: ~4 % noise per GEMM output on
+    Gaussian data, measured 7 % after 4 layers), logits within 6 % of the logit range (measured 2.5 %), >= 85 % top-1 agreement (94 %),
+    alignment rows correlated > 0.95 (0.972); switching the mode off restores the bf16 results bit for
+    bit; the f32 engine refuses the option."""
+    g, v = syn.large_v3_geometry()
+    g.enc_layers, g.dec_layers = 4, 2
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19)]
+    W = syn.random_weights(g, seed=11)
+    clips = [syn.synth_audio(400 + i, 480000 - 50000 * i, ("mixed", "noise", "chirp")[i]) for i in range(3)]
+    T = 3 + 24
+    prompt = np.tile(np.array([[v.sot, v.lang_id("en"), v.transcribe]], np.int32), (3, 1))
+    e = Engine(spec, dtype="bf16", max_batch=3)
+    res = []
+    try:
+        e.load_state_dict(W)
+        forced = None
+        for mode in (False, True, False):
+            e.set_encoder_gemm_fp8(mode)
+            e.mel(clips)
+            e.encode([0, 1, 2], [0, 0, 0], [3000, 3000, 3000])
+            enc = e.encoder_output(3)
+            cap = e.capture_logits(3, T)
+            seqs, lens, amax = e.decode(prompt, max_length=T, min_new_tokens=24, forced=forced, want_argmax=True)
+            e.stop_capture()
+            if forced is None:
+                forced = np.full((3, T), -1, np.int32); forced[:, 3:] = seqs[:, 3:T]
+            res.append(dict(enc=enc.copy(), logits=cap[:T - 3].copy(), amax=amax[:, 3:T].copy(), al=e.alignment(3, T - 1)))
+    finally:
+        e.close()
+    a, b, a2 = res
+    assert np.array_equal(a["enc"], a2["enc"]) and np.array_equal(a["logits"], a2["logits"])      # mode off = the bf16 path again
+    rel = float(np.linalg.norm(a["enc"] - b["enc"]) / np.linalg.norm(a["enc"]))
+    rng_ = a["logits"].max() - a["logits"].min()
+    dl = float(np.abs(a["logits"] - b["logits"]).max() / rng_)
+    top1 = float((a["amax"] == b["amax"]).mean())
+    cc = float(np.corrcoef(a["al"].ravel(), b["al"].ravel())[0, 1])
+    print(f"fp8 encoder mode: encoder rel L2 {rel:.4f}, logits max diff / range {dl:.4f}, top-1 agreement {top1:.3f}, alignment corr {cc:.4f}")
+    assert 1e-4 < rel < 0.10, rel                                                                  # really another path, and close
+    assert dl < 0.06, dl                                                                          # measured 0.025
+    assert top1 >= 0.85, top1                                                                     # measured 0.944
+    assert cc > 0.95, cc                                                                          # measured 0.972
+    with pytest.raises(Exception):
+        e32 = Engine(spec, dtype="f32", max_batch=1)
+        try:
+            e32.load_state_dict(W)
+            e32.set_encoder_gemm_fp8(True)
+        finally:
+            e32.close()
+
+
 @pytest.mark.parametrize("name", ["mixed70_b2_n40", "noise35_b4_free", "chirp12_b1_n24"])
 def test_pipeline_segment_timestamps_vs_reference(tiny, name):
     """return_timestamps=True (segment-level chunks, what REF/app.py:51-61 constructs its pipeline with), f32 engine,
