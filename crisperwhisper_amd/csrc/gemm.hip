@@ -524,20 +524,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wm == 0) {
+    if (wm == 0) {   // loop rotated: a tile's fragments are read and consumed inside one iteration
         read_frags(0);
         if (nk > 1) issue(BK, 1);
         __builtin_amdgcn_s_barrier();                              // closes phase -1
-        for (int t = 0; t < nk; ++t) {
-            mfmas();                                               // phase 2t
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own pieces of tile t+1 (issued one phase ago)
+        mfmas();                                                   // phase 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own pieces of tile 1
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t + 1 < nk; ++t) {
+            read_frags((t + 1) & 1);                               // phase 2t+1
+            if (t + 2 < nk) issue((t + 2) * BK, t & 1);
             __builtin_amdgcn_s_barrier();
-            if (t + 1 < nk) {                                      // phase 2t+1
-                read_frags((t + 1) & 1);
-                if (t + 2 < nk) issue((t + 2) * BK, t & 1);
-            }
+            mfmas();                                               // phase 2t+2: tile t+1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own pieces of tile t+2 (issued one phase ago)
             __builtin_amdgcn_s_barrier();
         }
+        __builtin_amdgcn_s_barrier();                              // phase 2nk-1: G1's last MFMA phase
     } else {
         __builtin_amdgcn_s_barrier();                              // closes phase -1
         for (int t = 0; t < nk; ++t) {
