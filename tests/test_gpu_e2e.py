@@ -631,7 +631,8 @@ def test_fp8_cross_kv_cache_tracks_bf16_cache():
         Engine(spec, dtype="f32", max_batch=1, cross_kv_dtype="fp8")
 
 
-def test_fp8_encoder_gemm_mode_tracks_bf16_engine():
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_fp8_encoder_gemm_mode_tracks_bf16_engine(dt):
     """Opt-in e4m3 encoder mode (cw_set_option "encoder_gemm_fp8": qkv / fc1 / fc2 and the cross-K/V projections as
     v_mfma_scale_f32_16x16x128_f8f6f4 GEMMs, row-wise scales, LayerNorm-fused activation quantisation) against the bf16 GEMMs
     of the same engine, large-v3 shapes on a 4 + 2 layer stack, teacher-forced -- the accuracy gate of that mode: encoder
@@ -647,7 +648,7 @@ def test_fp8_encoder_gemm_mode_tracks_bf16_engine():
     clips = [syn.synth_audio(400 + i, 480000 - 50000 * i, ("mixed", "noise", "chirp")[i]) for i in range(3)]
     T = 3 + 24
     prompt = np.tile(np.array([[v.sot, v.lang_id("en"), v.transcribe]], np.int32), (3, 1))
-    e = Engine(spec, dtype="bf16", max_batch=3)
+    e = Engine(spec, dtype=dt, max_batch=3)
     res = []
     try:
         e.load_state_dict(W)
