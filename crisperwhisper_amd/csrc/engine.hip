@@ -96,6 +96,7 @@ struct cw_ctx {
     bool gen_set = false;
     bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
     bool enc8 = false;                   // encoder linear layers + cross-K/V projection as e4m3 GEMMs ("encoder_gemm_fp8")
+    bool enc8_stale = false;             // a tensor was (re)loaded after the e4m3 copies were made
     void *h8 = nullptr, *mid8 = nullptr; float *sa8 = nullptr, *smid8 = nullptr;   // e4m3 activations and their row scales
     // beam search (cw_beam_*): rows = items x beams; self-attention keys are found through the ancestry table
     int beam_K = 0, beam_items = 0, beam_n_prompt = 0;
@@ -441,7 +442,7 @@ static int apply_folds(cw_ctx* c);
 int32_t cw_load_tensor(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
     if (!name || !data || !shape) return fail(c, CW_ERR_INVALID, "cw_load_tensor: null argument");
     const int r = load_tensor_impl(c, name, data, shape, ndim);
-    if (r == CW_OK) { c->loaded.insert(name); c->weights_ok = false; }
+    if (r == CW_OK) { c->loaded.insert(name); c->weights_ok = false; c->enc8_stale = true; }   // e4m3 copies follow the weights
     return r;
 }
 
@@ -667,6 +668,8 @@ static DecAttnParams dec_attn(const float* q, const void* K, const void* V, int 
     return p;
 }
 
+static int enc8_quantise(cw_ctx* c);
+
 int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* seek, const int32_t* n_frames) {
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, NM = c->d.n_mels, S = CW_N_CTX;
     if (nb < 1 || nb > c->Bm) return fail(c, CW_ERR_INVALID, "nb=%d out of range", nb);
@@ -678,6 +681,7 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
         val[i] = n_frames[i];
     }
     CWCHK(c, cw_check_weights(c));
+    if (c->enc8 && c->enc8_stale) CWCHK(c, enc8_quantise(c));
     HIPCHK(c, hipMemcpyAsync(c->d_row_off, off.data(), nb * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemcpyAsync(c->d_row_valid, val.data(), nb * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));  // host vectors go out of scope
@@ -1451,6 +1455,20 @@ int32_t cw_ingest(cw_ctx* c, const void* raw, int32_t fmt, int32_t channels, int
 // ------------------------------------------------------------------------------------------------
 // kernel-level test hooks
 // ------------------------------------------------------------------------------------------------
+// e4m3 copies of the encoder qkv / fc1 / fc2 and decoder cross-K/V weights from the resident 16-bit weights (row-wise scales)
+static int enc8_quantise(cw_ctx* c) {
+    const int D = c->d.d_model, F = c->d.ffn_dim;
+    for (auto& L : c->enc) {
+        CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.wqkv, 3 * D, D, L.wqkv8, L.sqkv, c->st));
+        CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.w1, F, D, L.w18, L.s1, c->st));
+        CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.w2, D, F, L.w28, L.s2, c->st));
+    }
+    for (auto& L : c->dec) CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.wkv_c, 2 * D, D, L.wkv_c8, L.skv_c, c->st));
+    KCHK(c);
+    c->enc8_stale = false;
+    return CW_OK;
+}
+
 int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
     if (!strcmp(name, "cross_kv_fp8")) {
         if (!value) { c->kv8 = false; return CW_OK; }
@@ -1484,13 +1502,7 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
             }
             for (auto& L : c->dec) { CWCHK(c, dmalloc(c, &L.wkv_c8, (size_t)2 * D * D, false)); CWCHK(c, dmalloc(c, &L.skv_c, (size_t)2 * D * 4)); }
         }
-        for (auto& L : c->enc) {
-            CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.wqkv, 3 * D, D, L.wqkv8, L.sqkv, c->st));
-            CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.w1, F, D, L.w18, L.s1, c->st));
-            CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.w2, D, F, L.w28, L.s2, c->st));
-        }
-        for (auto& L : c->dec) CWCHK(c, KD(c, cw_launch_quant_rows_fp8, L.wkv_c, 2 * D, D, L.wkv_c8, L.skv_c, c->st));
-        KCHK(c);
+        CWCHK(c, enc8_quantise(c));
         c->enc8 = true;
         c->nb_encoded = 0;                                   // windows must be re-encoded
         return CW_OK;
