@@ -24,8 +24,11 @@ SCENARIOS = {
     "large_noise12_n24": ("noise", 12, 22, 0, {"num_beams": 1, "language": "<|en|>", "task": "transcribe", "max_new_tokens": 24}),
     # 4 chunks (30, 30, 30, 10 s) with 5 s strides, two per batch: seam merge + batch lock-step at full size
     "large_mixed70_b2_n20": ("mixed", 70, 23, 0, {"num_beams": 1, "language": "<|en|>", "task": "transcribe", "max_new_tokens": 20}),
+    # beam search at full size: 5 beams on one 30 s chunk, 3 beams on 2 chunks per batch without a language (detected)
+    "large_beam5_mixed30_n16": ("mixed", 30, 24, 0, {"num_beams": 5, "language": "<|en|>", "task": "transcribe", "max_new_tokens": 16}),
+    "large_beam3_noise45_b2_n12_autolang": ("noise", 45, 25, 0, {"num_beams": 3, "max_new_tokens": 12}),
 }
-BATCH = {"large_mixed70_b2_n20": 2}
+BATCH = {"large_mixed70_b2_n20": 2, "large_beam3_noise45_b2_n12_autolang": 2}
 
 
 def main():

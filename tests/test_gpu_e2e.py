@@ -371,7 +371,8 @@ def test_large_batch_decode_matches_small_batch_path():
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["large_mixed30_n32", "large_noise12_n24", "large_mixed70_b2_n20"])
+@pytest.mark.parametrize("name", ["large_mixed30_n32", "large_noise12_n24", "large_mixed70_b2_n20", "large_beam5_mixed30_n16",
+                                  "large_beam3_noise45_b2_n12_autolang"])
 def test_full_size_f32_pipeline_word_for_word_vs_transformers(name):
     """BASELINE geometry end to end (large-v3 shapes, 32 + 32 layers, vocab 51866, 15 alignment heads, 1.54 B synthetic
     parameters): the reference pipeline call through the f32 engine against the committed transformers 5.15.0 CPU
