@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import crisperwhisper_amd as cw
-from crisperwhisper_amd import collate, synthetic as syn
+from crisperwhisper_amd import collate, generation, synthetic as syn
 from crisperwhisper_amd.engine import Engine
 from oracle import mel as OM
 from oracle.model import WhisperOracle
@@ -815,6 +815,41 @@ def test_beam_topk_two_stage_equals_single_block_kernel(tiny, dt):
         pipe.engine.close()
     assert outs[0]["text"] == outs[1]["text"] and len(outs[0]["chunks"]) > 3
     assert [c["timestamp"] for c in outs[0]["chunks"]] == [c["timestamp"] for c in outs[1]["chunks"]]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_bench_model_beam_search_16bit_engines(dt):
+    """5-beam search with the bench model (large-v3 geometry, aligned synthetic weights) on the 16-bit engines against
+    transformers (CPU, fp32, tests/golden/gen_golden_bench_beam.py): 4 bench clips decoded together = 20 decoder rows, 40 tokens
+    per pass -- the 17..64-row GEMV path, the shared-K/V cross-attention, the sliced candidate selection and the beam-index gather
+    of the alignment rows at full depth.  Every clip must reproduce the reference text with all words within 20 ms."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "e2e_bench_beam_golden.json")
+    if not os.path.exists(path):
+        pytest.skip("bench-model beam golden not generated")
+    gold = Hh.gold_json("e2e_bench_beam_golden.json")
+    g, v = syn.large_v3_geometry()
+    spec = syn.model_spec(g, v, n_align=15)
+    vocab = collate.Vocabulary.from_synthetic(v)
+    gk = gold["generate_kwargs"]
+    B = len(gold["clips"])
+    eng = Engine(spec, dtype=dt, max_batch=B * gk["num_beams"])
+    try:
+        for n, shape in syn.weight_shapes(g).items():
+            eng.load_tensor(n, syn.weight_tensor(g, n, shape, gold["weight_seed"], gold["weights"]))
+        clips = [syn.synth_audio(c["seed"], int(c["secs"] * 16000), c["kind"]) for c in gold["clips"]]
+        _, nf = eng.mel(clips)
+        out = generation.generate(eng, B, nf, language=gk["language"], task=gk["task"], max_new_tokens=gk["max_new_tokens"],
+                                  min_new_tokens=gk["min_new_tokens"], num_beams=gk["num_beams"])
+        for k, clip in enumerate(gold["clips"]):
+            n = len(out["token_timestamps"][k])
+            text, words = collate.decode_asr(vocab, [{"tokens": out["sequences"][k][:n], "token_timestamps": out["token_timestamps"][k],
+                                                      "stride": (30.0, 0.0, 0.0)}])
+            assert text == clip["text"], (clip["seed"], text[:80], clip["text"][:80])
+            ok, why = Hh.words_equal(words, clip["chunks"], tol=0.02)
+            assert ok, (clip["seed"], why)
+    finally:
+        eng.close()
 
 
 def test_beam_search_bf16_engine_many_rows_tracks_f32_engine(tiny):
