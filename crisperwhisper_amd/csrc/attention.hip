@@ -825,11 +825,17 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
 // 8 x 64 partial outputs: 2 barriers per block instead of 7, the 64-group serial LDS reduction became three cross-lane
 // steps + 8 adds.  Needs nk <= 4 * 64 keys per block (ATT_NS >= 6 for 1500 frames).
 __device__ inline float row_ror8_add(float v) { return v + dpp_mov<0x128, 0xf>(0.f, v); }   // + lane ^ 8 (row_ror:8)
-template <typename T, int NQ>
+// FUSED (NQ = 1, fused out-projection / query stage, decfuse.hip): the query is finished here,
+//     q = rstd(x1) (qa + qb - mean(x1) qw) + qbias,
+// by wave 0 alone (LayerNorm statistics of the residual row, wave-local) and handed to the other waves through LDS: every
+// wave-level load costs 16 clocks of the CU's address unit whatever it fetches -- all eight waves fetching the same row and
+// constants measured +3 us per launch.
+template <typename T, int NQ, bool FUSED>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSplitParams p) {
     __shared__ float s_max[8 * NQ];
     __shared__ float red[8 * NQ * 64];
     __shared__ float red_l[8 * NQ];
+    __shared__ float s_q[64];
     // blockIdx.y = group of NQ consecutive query rows that share one K/V (NQ = kv_div: the hypotheses of one audio item under
     // beam search; NQ = 1: one row per block, K/V of item row / kv_div).  The K/V slice is read ONCE into registers and all
     // NQ queries go through the same three block barriers together: one block per row re-streamed the 64 KB slice from L2
@@ -844,14 +850,41 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
     const T* Kh = (const T*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
     const T* Vh = (const T*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
     constexpr int G = CROSS_THREADS / 8;                       // 64 key groups
+    // FUSED: wave 0 adds the per-block partial sums of the residual row that the producing GEMV left behind (decfuse.hip,
+    // StackSeg::pstats) -- two small loads instead of the row itself: at more than 64 VGPRs this kernel loses a block per CU
+    float2 pt0 = make_float2(0.f, 0.f), pt1 = pt0;
+    float qa1 = 0.f, qb1 = 0.f, qw1 = 0.f, qc1 = 0.f;
+    if (FUSED && wave == 0) {                                   // wave-uniform; requested ahead of the K/V stream: loads only --
+        const int Dm = p.H * 64;                                // using a value in here makes hipcc wait before the K/V loads go out
+        pt0 = *(const float2*)(p.pstats + ((size_t)min(lane, p.n_pstats - 1) * 8 + b0) * 2);
+        pt1 = *(const float2*)(p.pstats + ((size_t)min(lane + 64, p.n_pstats - 1) * 8 + b0) * 2);
+        const size_t col = (size_t)h * 64 + lane;
+        qa1 = p.qa[(size_t)b0 * Dm + col]; qb1 = p.qb[(size_t)b0 * Dm + col];
+        qw1 = p.qw[col]; qc1 = p.qbias[col];
+    }
     Raw8<T> kr[4], vr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) kr[u].ld(Kh + (size_t)min(grp + u * G, nk - 1) * 64);   // unconditional, clamped
 #pragma unroll
     for (int u = 0; u < 4; ++u) vr[u].ld(Vh + (size_t)min(grp + u * G, nk - 1) * 64);
     float qv[NQ][8];
+    if (FUSED) {
+        if (wave == 0) {
+            const float inv_d = 1.0f / (float)(p.H * 64);
+            const float ps1 = (lane < p.n_pstats ? pt0.x : 0.f) + (lane + 64 < p.n_pstats ? pt1.x : 0.f);
+            const float ps2 = (lane < p.n_pstats ? pt0.y : 0.f) + (lane + 64 < p.n_pstats ? pt1.y : 0.f);
+            const float mean = wave_sum(ps1) * inv_d;
+            const float var = fmaxf(wave_sum(ps2) * inv_d - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            s_q[lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) Row8<float>::ld(p.q + (size_t)(b0 + q) * p.H * 64 + h * 64 + sub * 8, qv[q]);
+        for (int e = 0; e < 8; ++e) qv[0][e] = s_q[sub * 8 + e];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) Row8<float>::ld(p.q + (size_t)(b0 + q) * p.H * 64 + h * 64 + sub * 8, qv[q]);
+    }
     float d[NQ][4], mx[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) mx[q] = -INFINITY;
@@ -947,15 +980,152 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Cross-attention decode, ONE block per (row, head) over all keys (six-launch layer, decfuse.hip).  grid (H, B), 512 threads:
+// an 8-lane group owns keys grp, grp+64, ... (24 rows of 128 B at 1500 frames) and every K and V row of the block is
+// requested before anything is waited for (48 x 16 B per lane in flight, 384 KB per block), so there are no key splits, no
+// partial planes and nothing to combine: the block writes the finished attention output.  The query is finished here as well,
+//     q = rstd(x1) (qa + qb - mean(x1) qw) + qbias
+// by wave 0 alone (LayerNorm statistics of the residual row, wave-local) and handed to the other waves through LDS: every
+// wave-level load costs 16 clocks of the CU's address unit whatever it fetches, and eight waves fetching the same row cost
+// 3 us per launch.  Alignment heads write exp(s - M) with the block maximum M and (M, L) in split slot 0 of align_ml (the
+// other slots (M, 0)), which is exactly what align_normalize_kernel expects from a one-split launch.
+// ---------------------------------------------------------------------------------------------------
+#define CROSSF_U 24
+template <typename T>
+__global__ __launch_bounds__(CROSS_THREADS) void attn_cross_full_kernel(CrossSplitParams p) {
+    __shared__ float s_q[64];
+    __shared__ float s_max[8];
+    __shared__ float red[8 * 64];
+    __shared__ float red_l[8];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int nk = p.n_keys;
+    const int tid = threadIdx.x, lane = tid & 63, sub = tid & 7, grp = tid >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Dm = p.H * 64, nvec = Dm >> 2;
+    const T* Kh = (const T*)p.K + ((size_t)b * p.H + h) * nk * 64 + sub * 8;
+    const T* Vh = (const T*)p.V + ((size_t)b * p.H + h) * nk * 64 + sub * 8;
+    constexpr int G = CROSS_THREADS / 8;                       // 64 key groups
+    float4 xrow[5];
+    float qa1 = 0.f, qb1 = 0.f, qw1 = 0.f, qc1 = 0.f;
+    if (wave == 0) {                                            // wave-uniform
+        const float* xr = p.xstat + (size_t)b * Dm;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) xrow[c] = *(const float4*)(xr + (size_t)min(lane + 64 * c, nvec - 1) * 4);
+        const size_t col = (size_t)h * 64 + lane;
+        qa1 = p.qa[(size_t)b * Dm + col]; qb1 = p.qb[(size_t)b * Dm + col];
+        qw1 = p.qw[col]; qc1 = p.qbias[col];
+    }
+    Raw8<T> kr[CROSSF_U], vr[CROSSF_U];
+#pragma unroll
+    for (int u = 0; u < CROSSF_U; ++u) kr[u].ld(Kh + (size_t)min(grp + u * G, nk - 1) * 64);   // unconditional, clamped
+#pragma unroll
+    for (int u = 0; u < CROSSF_U; ++u) vr[u].ld(Vh + (size_t)min(grp + u * G, nk - 1) * 64);
+    if (wave == 0) {
+        float sx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+            sx += ok * ((xrow[c].x + xrow[c].y) + (xrow[c].z + xrow[c].w));
+        }
+        const float mean = wave_sum(sx) / (float)Dm;
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+            const float a = xrow[c].x - mean, bb = xrow[c].y - mean, cc = xrow[c].z - mean, d2 = xrow[c].w - mean;
+            sq += ok * ((a * a + bb * bb) + (cc * cc + d2 * d2));
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)Dm + 1e-5f);
+        s_q[lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
+    }
+    __syncthreads();
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = s_q[sub * 8 + e];
+    float d[CROSSF_U], mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < CROSSF_U; ++u) {
+        float kv[8];
+        kr[u].cvt(kv);
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t = fmaf(qv[e], kv[e], t);
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+        d[u] = (grp + u * G < nk) ? t : -INFINITY;
+        mx = fmaxf(mx, d[u]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    mx = s_max[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) mx = fmaxf(mx, s_max[w]);
+
+    const int slot = p.align_out ? p.align_slot[h] : -1;
+    const size_t rowi = slot >= 0 ? ((size_t)b * p.n_align + slot) * p.align_rows + p.pos[b] : 0;
+    float acc[8] = {};
+    float lsum = 0.f;
+#pragma unroll
+    for (int u = 0; u < CROSSF_U; ++u) {
+        const int k = grp + u * G;
+        float vv[8];
+        vr[u].cvt(vv);
+        const float pk = (k < nk) ? expf(d[u] - mx) : 0.f;
+        if (sub == 0 && k < nk) {
+            lsum += pk;
+            if (slot >= 0) p.align_out[rowi * nk + k] = pk;     // un-normalised; align_normalize_kernel finishes the row
+        }
+        if (k < nk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = xor32_sum(xor16_sum(row_ror8_add(acc[e])));
+    lsum = wave_sum(lsum);
+    if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * 64 + sub * 8 + e] = acc[e];
+    }
+    if (lane == 0) red_l[wave] = lsum;
+    __syncthreads();
+    float l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) l += red_l[w];
+    if (tid < 64) {
+        float r = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) r += red[w * 64 + tid];
+        p.a_out[(size_t)b * Dm + h * 64 + tid] = r * (1.0f / l);
+    } else if (slot >= 0 && tid < 64 + ATT_NS) {
+        const int sI = tid - 64;
+        p.align_ml[(rowi * ATT_NS + sI) * 2] = mx;
+        p.align_ml[(rowi * ATT_NS + sI) * 2 + 1] = sI == 0 ? l : 0.f;
+    }
+}
+
 template <int NQ>
 static void launch_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
     dim3 grid(p.H, p.B / NQ, ATT_NS);
-    if (bf16) hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, NQ>), grid, dim3(CROSS_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((attn_cross_split_kernel<float, NQ>), grid, dim3(CROSS_THREADS), 0, st, p);
+    if (bf16) hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, NQ, false>), grid, dim3(CROSS_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((attn_cross_split_kernel<float, NQ, false>), grid, dim3(CROSS_THREADS), 0, st, p);
 }
 
 int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > 4 * (CROSS_THREADS / 8) || CROSS_THREADS != 512) return CW_ERR_INVALID;
+    if (p.xstat || p.pstats) {   // fused out-projection / query stage: the query is finished in the kernel; 16-bit caches
+        if (!bf16 || p.kv_div > 1 || p.H > 20 || !p.qa || !p.qb || !p.qw || !p.qbias) return CW_ERR_INVALID;
+        if (p.a_out) {
+            if (!p.xstat) return CW_ERR_INVALID;   // one block per (row, head), finished output (A/B: 17 us per launch against 12 with six key splits)
+            if (p.n_keys > CROSSF_U * (CROSS_THREADS / 8)) return CW_ERR_INVALID;
+            hipLaunchKernelGGL((attn_cross_full_kernel<bf16_t>), dim3(p.H, p.B), dim3(CROSS_THREADS), 0, st, p);
+            return CW_OK;
+        }
+        if (!p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.B > 8) return CW_ERR_INVALID;
+        hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, 1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+        return CW_OK;
+    }
     static const bool per_row = getenv("CW_CROSS_PER_ROW") != nullptr;   // A/B: one block per row even under beam search
     const int nq = (p.kv_div > 1 && p.kv_div <= 6 && p.B % p.kv_div == 0 && !per_row) ? p.kv_div : 1;
     switch (nq) {

@@ -35,6 +35,11 @@ struct LayerW {
     void *ck8 = nullptr, *cv8 = nullptr; // opt-in fp8 (e4m3) copy of it, one byte per element
     float* kvs = nullptr;                // [Bm][H][2] dequantisation scales (K, V)
     void *sk = nullptr, *sv = nullptr;   // self  K/V cache   [Bm][H][448][64]
+    // six-launch decoder layer (decfuse.hip), 16-bit engines: row-stacked weights [W'q_c ; W'q_c Wo ; Wo] and
+    // [W'1 ; W'1 Wo_c ; Wo_c] -- wq_c / wo / w1 / wo_c above point into them -- and the per-column constants
+    void *ws3 = nullptr, *ws5 = nullptr;
+    float *qa_bias = nullptr, *q_wsum = nullptr;     // [D]  W'q_c bo ;  W'q_c 1
+    float *u1_bias = nullptr, *u1_wsum = nullptr;    // [F]  W'1 bo_c ;  W'1 1
 };
 
 struct cw_ctx {
@@ -53,6 +58,12 @@ struct cw_ctx {
     // tensor is in, then the LayerNorm's gamma / beta are folded into them (gemm.hip: fold_layernorm_kernel)
     struct Fold { float* stage; int N, K; void* w_dst; size_t w_off; float* b_dst; size_t b_off; float scale; int layer, which; };
     std::vector<Fold> folds;
+    struct OutStage { float* stage; int layer, which; };   // f32 copies of the decoder out-projections (which: 0 self, 1 cross)
+    std::vector<OutStage> out_stages;
+    bool fuse6_ready = false;       // product matrices of the fused decoder stages are in place
+    bool fuse6_enabled = true;      // CW_NO_FUSE6=1: eight launches per layer (A/B)
+    bool fuse_mlp = false;          // CW_FUSE_MLP=1: also fuse cross out-projection + fc1 (six launches; measured slower, A/B)
+    int stack_nt3 = 0, stack_nt5 = 0;   // column tiles per block of the two stacked GEMVs (0 = launcher's choice; CW_STACK_NT3/5)
     bool ln_folded = false;         // decoder LN-GEMVs run plain normalisation (affine part is inside W / bias)
     bool fold_enabled = true;       // CW_NO_LN_FOLD=1: keep gamma / beta in the kernels
     std::set<std::string> loaded;   // HF tensor names received through cw_load_tensor
@@ -80,6 +91,7 @@ struct cw_ctx {
 
     // decoder state
     float *dx = nullptr, *dxn = nullptr, *dq = nullptr, *dattn = nullptr, *dmid = nullptr, *dlogits = nullptr;
+    float *dx1 = nullptr, *dx2c = nullptr, *d_qa = nullptr, *d_qb = nullptr, *d_u1 = nullptr, *d_pstats = nullptr;   // fused decoder stages (decfuse.hip)
     void *d_xfrag = nullptr, *d_xfrag2 = nullptr;             // bf16 [64][5120] fragment-major activations of the 17..64-row GEMV path
     int *d_ids = nullptr, *d_forced = nullptr, *d_argmax = nullptr, *d_last_ts = nullptr, *d_finished = nullptr,
         *d_nunf = nullptr, *d_align_slot = nullptr;
@@ -249,6 +261,10 @@ static int create_impl(cw_ctx* c) {
     c->bf16 = d.dtype == CW_DTYPE_BF16 || c->f16;
     if (getenv("CW_NO_GRAPH")) c->use_graph = false;
     if (getenv("CW_NO_LN_FOLD")) c->fold_enabled = false;
+    if (getenv("CW_NO_FUSE6")) c->fuse6_enabled = false;
+    if (getenv("CW_FUSE_MLP")) c->fuse_mlp = true;
+    if (getenv("CW_STACK_NT3")) c->stack_nt3 = atoi(getenv("CW_STACK_NT3"));
+    if (getenv("CW_STACK_NT5")) c->stack_nt5 = atoi(getenv("CW_STACK_NT5"));
     c->esz = c->bf16 ? 2 : 4;
     c->Bm = Bm;
     c->S_pad = 1536;
@@ -267,21 +283,35 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->dec_ln_g, D * 4)); CWCHK(c, dmalloc(c, &c->dec_ln_b, D * 4));
     c->enc.resize(d.enc_layers);
     c->dec.resize(d.dec_layers);
-    auto alloc_common = [&](LayerW& L) -> int {
+    auto alloc_common = [&](LayerW& L, bool stacked) -> int {
         CWCHK(c, dmalloc(c, &L.wqkv, (size_t)3 * D * D * e)); CWCHK(c, dmalloc(c, &L.bqkv, (size_t)3 * D * 4));
-        CWCHK(c, dmalloc(c, &L.wo, (size_t)D * D * e)); CWCHK(c, dmalloc(c, &L.bo, D * 4));
+        if (!stacked) CWCHK(c, dmalloc(c, &L.wo, (size_t)D * D * e));
+        CWCHK(c, dmalloc(c, &L.bo, D * 4));
         CWCHK(c, dmalloc(c, &L.ln1_g, D * 4)); CWCHK(c, dmalloc(c, &L.ln1_b, D * 4));
-        CWCHK(c, dmalloc(c, &L.w1, (size_t)F * D * e)); CWCHK(c, dmalloc(c, &L.b1, F * 4));
+        if (!stacked) CWCHK(c, dmalloc(c, &L.w1, (size_t)F * D * e));
+        CWCHK(c, dmalloc(c, &L.b1, F * 4));
         CWCHK(c, dmalloc(c, &L.w2, (size_t)D * F * e)); CWCHK(c, dmalloc(c, &L.b2, D * 4));
         CWCHK(c, dmalloc(c, &L.ln2_g, D * 4)); CWCHK(c, dmalloc(c, &L.ln2_b, D * 4));
         return CW_OK;
     };
-    for (auto& L : c->enc) CWCHK(c, alloc_common(L));
+    for (auto& L : c->enc) CWCHK(c, alloc_common(L, false));
     for (auto& L : c->dec) {
-        CWCHK(c, alloc_common(L));
-        CWCHK(c, dmalloc(c, &L.wq_c, (size_t)D * D * e)); CWCHK(c, dmalloc(c, &L.bq_c, D * 4));
+        const bool stacked = c->bf16;   // 16-bit engines: the four projections live inside the two row-stacked matrices
+        CWCHK(c, alloc_common(L, stacked));
+        if (stacked) {
+            CWCHK(c, dmalloc(c, &L.ws3, (size_t)3 * D * D * e));
+            CWCHK(c, dmalloc(c, &L.ws5, ((size_t)2 * F + D) * D * e));
+            L.wq_c = L.ws3; L.wo = (char*)L.ws3 + (size_t)2 * D * D * e;
+            L.w1 = L.ws5;   L.wo_c = (char*)L.ws5 + (size_t)2 * F * D * e;
+            CWCHK(c, dmalloc(c, &L.qa_bias, D * 4)); CWCHK(c, dmalloc(c, &L.q_wsum, D * 4));
+            CWCHK(c, dmalloc(c, &L.u1_bias, F * 4)); CWCHK(c, dmalloc(c, &L.u1_wsum, F * 4));
+        } else {
+            CWCHK(c, dmalloc(c, &L.wq_c, (size_t)D * D * e));
+            CWCHK(c, dmalloc(c, &L.wo_c, (size_t)D * D * e));
+        }
+        CWCHK(c, dmalloc(c, &L.bq_c, D * 4));
         CWCHK(c, dmalloc(c, &L.wkv_c, (size_t)2 * D * D * e)); CWCHK(c, dmalloc(c, &L.bkv_c, (size_t)2 * D * 4));
-        CWCHK(c, dmalloc(c, &L.wo_c, (size_t)D * D * e)); CWCHK(c, dmalloc(c, &L.bo_c, D * 4));
+        CWCHK(c, dmalloc(c, &L.bo_c, D * 4));
         CWCHK(c, dmalloc(c, &L.lnc_g, D * 4)); CWCHK(c, dmalloc(c, &L.lnc_b, D * 4));
         CWCHK(c, dmalloc(c, &L.ck, (size_t)Bm * H * CW_N_CTX * 64 * e));
         CWCHK(c, dmalloc(c, &L.cv, (size_t)Bm * H * CW_N_CTX * 64 * e));
@@ -359,6 +389,9 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->dx, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dxn, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->dq, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dattn, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->dmid, (size_t)Bm * F * 4));
+    CWCHK(c, dmalloc(c, &c->dx1, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dx2c, (size_t)Bm * D * 4));
+    CWCHK(c, dmalloc(c, &c->d_qa, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->d_qb, (size_t)Bm * D * 4));
+    CWCHK(c, dmalloc(c, &c->d_u1, (size_t)Bm * F * 4)); CWCHK(c, dmalloc(c, &c->d_pstats, (size_t)128 * 8 * 2 * 4));
     CWCHK(c, dmalloc(c, &c->d_xfrag, (size_t)64 * 5120 * 2));
     CWCHK(c, dmalloc(c, &c->d_xfrag2, (size_t)64 * 5120 * 2));
     c->Vpad = (V + 3) & ~3;
@@ -424,6 +457,7 @@ void cw_destroy(cw_ctx* c) {
     if (c->st) hipStreamSynchronize(c->st);
     for (auto& ge : c->step_graph) if (ge) hipGraphExecDestroy(ge);
     for (auto& f : c->folds) hipFree(f.stage);
+    for (auto& o : c->out_stages) hipFree(o.stage);
     for (void* p : c->allocs) hipFree(p);
     if (c->h_nunf) hipHostFree(c->h_nunf);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -496,8 +530,31 @@ static int apply_folds(cw_ctx* c) {
         const float* b = f.which == 0 ? L.ln1_b : (f.which == 1 ? L.lnc_b : L.ln2_b);
         CWCHK(c, KD(c, cw_launch_fold_layernorm, f.stage, f.N, f.K, g, b, f.scale, (bf16_t*)f.w_dst + f.w_off, f.b_dst + f.b_off, c->st));
     }
+    // six-launch layer: product matrices W'q_c Wo and W'1 Wo_c (f32 from the checkpoint values, one 16-bit rounding), the
+    // constants W'q_c bo / W'1 bo_c and the row sums of the folded 16-bit weights (what the MFMAs actually multiply by)
+    const int D = c->d.d_model, F = c->d.ffn_dim;
+    bool all = !c->folds.empty() && c->fuse6_enabled && F % D == 0 && D <= 1280 && D % 64 == 0 && F % 64 == 0 && c->d.n_heads <= 20;
+    if (all) {
+        for (int l = 0; l < c->d.dec_layers && all; ++l) {
+            const cw_ctx::Fold *fq = nullptr, *f1 = nullptr;
+            const float *so = nullptr, *sc = nullptr;
+            for (auto& f : c->folds) if (f.layer == l) { if (f.which == 1) fq = &f; else if (f.which == 2) f1 = &f; }
+            for (auto& o : c->out_stages) if (o.layer == l) { if (o.which == 0) so = o.stage; else sc = o.stage; }
+            if (!fq || !f1 || !so || !sc) { all = false; break; }
+            LayerW& L = c->dec[l];
+            const size_t e = c->esz;
+            CWCHK(c, KD(c, cw_launch_fold_product, fq->stage, L.lnc_g, fq->scale, so, D, D, D, (char*)L.ws3 + (size_t)D * D * e, c->st));
+            CWCHK(c, KD(c, cw_launch_fold_rowvec, fq->stage, L.lnc_g, fq->scale, L.bo, L.wq_c, D, D, L.qa_bias, L.q_wsum, c->st));
+            CWCHK(c, KD(c, cw_launch_fold_product, f1->stage, L.ln2_g, f1->scale, sc, F, D, D, (char*)L.ws5 + (size_t)F * D * e, c->st));
+            CWCHK(c, KD(c, cw_launch_fold_rowvec, f1->stage, L.ln2_g, f1->scale, L.bo_c, L.w1, F, D, L.u1_bias, L.u1_wsum, c->st));
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->st));
+    KCHK(c);
+    c->fuse6_ready = all;
     for (auto& f : c->folds) hipFree(f.stage);
+    for (auto& o : c->out_stages) hipFree(o.stage);
+    c->out_stages.clear();
     if (!c->folds.empty()) c->ln_folded = true;
     c->folds.clear();
     return CW_OK;
@@ -550,6 +607,13 @@ static int load_tensor_impl(cw_ctx* c, const char* name, const float* data, cons
         if (r == "self_attn.v_proj.weight") { CWCHK(c, expect(DD)); return stage_fold(c, li, 0, data, D, D, L.wqkv, 2 * DD, L.bqkv, 2 * (size_t)D, 1.f); }
         if (r == "encoder_attn.q_proj.weight") { CWCHK(c, expect(DD)); return stage_fold(c, li, 1, data, D, D, L.wq_c, 0, L.bq_c, 0, qs); }
         if (r == "fc1.weight") { CWCHK(c, expect((size_t)F * D)); return stage_fold(c, li, 2, data, F, D, L.w1, 0, L.b1, 0, 1.f); }
+        if (c->fuse6_enabled && (r == "self_attn.out_proj.weight" || r == "encoder_attn.out_proj.weight")) {   // f32 copy for the products
+            CWCHK(c, expect(DD));
+            cw_ctx::OutStage o{nullptr, li, r[0] == 's' ? 0 : 1};
+            HIPCHK(c, hipMalloc((void**)&o.stage, DD * 4));
+            HIPCHK(c, hipMemcpy(o.stage, data, DD * 4, hipMemcpyHostToDevice));
+            c->out_stages.push_back(o);
+        }
     }
     if (r == "self_attn.q_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wqkv, 0, data, n, qs); }
     if (r == "self_attn.k_proj.weight") { CWCHK(c, expect(DD)); return upload_T(c, L.wqkv, DD, data, n); }
@@ -775,18 +839,84 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     const int TGT = c->d.max_target_positions;
     // 17..64 rows (bf16): producers hand activations to the next GEMV already in MFMA fragment order (no prep launch)
     const bool frag = c->bf16 && nb > 16;
+    // fused out-projection / cross-query stage (decfuse.hip): greedy rows of one MFMA half tile, 16-bit caches.  The residual
+    // stream then alternates between two buffers: a layer reads x from `xin` and leaves x1, x2, x3 in `xalt`.
+    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 8 && c->beam_K == 0 && !c->kv8;
+    float *xin = c->dx, *xalt = c->dx1;
     for (int l = 0; l < c->d.dec_layers; ++l) {
         LayerW& L = c->dec[l];
         {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
             EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
             ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
-            CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, c->dx, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep));
+            CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, xin, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep));
         }
         {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
             if (frag) p.out_frag = (unsigned short*)c->d_xfrag2;
             if (c->beam_K > 0) p.anc = c->d_anc;
             CWCHK(c, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
+        }
+        if (fuse) {
+            const int TD = D / 16, TF = F / 16;
+            const int nt3 = c->stack_nt3 > 0 ? c->stack_nt3 : 1;   // column tiles per X1 block (3 * TD blocks at 1: 240 at large-v3)
+            {   // X1 over [W'q_c ; W'q_c Wo ; Wo]:  qa = W'q_c x + W'q_c bo,  qb = (W'q_c Wo) a,  x1 = x + Wo a + bo
+                StackParams sp;
+                memset(&sp, 0, sizeof(sp));
+                sp.W = L.ws3; sp.K = D; sp.Mb = nb; sp.nseg = 3;
+                sp.seg[0].x = xin;      sp.seg[0].bias = L.qa_bias; sp.seg[0].out = c->d_qa; sp.seg[0].tile0 = 0;      sp.seg[0].n_tiles = TD; sp.seg[0].epi = 0;
+                sp.seg[1].x = c->dattn; sp.seg[1].bias = nullptr;   sp.seg[1].out = c->d_qb; sp.seg[1].tile0 = TD;     sp.seg[1].n_tiles = TD; sp.seg[1].epi = 0;
+                sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo;      sp.seg[2].out = xalt;    sp.seg[2].tile0 = 2 * TD; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
+                sp.seg[2].resid = xin; sp.seg[2].pstats = c->d_pstats;   // LayerNorm partial sums of x1 for the cross-attention
+                if (c->fuse_mlp) { sp.zero = c->d_u1; sp.zero_n4 = nb * F / 4; }   // X2 below accumulates its two halves into u1
+                CWCHK(c, KD(c, cw_launch_gemv_stack, sp, nt3, c->st));
+            }
+            // cross-attention; the kernel finishes q_c = rstd(x1) (qa + qb - mean(x1) W'q_c 1) + b'q_c
+            CrossSplitParams p{nullptr, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml,
+                               c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_ml, c->d_align_slot + (size_t)l * H,
+                               c->d_pos, c->d.n_align, TGT, nb, H};
+            p.kv_div = 1;
+            p.qa = c->d_qa; p.qb = c->d_qb; p.qw = L.q_wsum; p.qbias = L.bq_c;
+            p.pstats = c->d_pstats; p.n_pstats = (TD + nt3 - 1) / nt3;
+            if (!c->fuse_mlp) {
+                CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
+                {   // out-projection combines the key-split partials; x2 = x1 + Wo_c a_c + bo_c in place
+                    EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.bo_c; ep.ldo = D;
+                    CombineParams cb{c->d_part_ml, H, nb * D};
+                    CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
+                }
+                {
+                    EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
+                    CWCHK(c, gemv_ln(c, EPI_GELU_F32, xalt, nb, D, L.w1, F, L.ln2_g, nullptr, ep));
+                }
+                {
+                    EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.b2; ep.ldo = D;
+                    CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
+                }
+                float* t = xin; xin = xalt; xalt = t;
+                continue;
+            }
+            // A/B (CW_FUSE_MLP=1), measured slower: cross out-projection + fc1 fused the same way.  Needs the
+            // finished attention output in one plane (one block per (row, head): 17 us against 12) and makes every fc2 block
+            // redo the statistics and the GELU of its K slice.
+            p.a_out = c->dattn; p.xstat = xalt;
+            CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
+            {   // X2 over [W'1 ; W'1 Wo_c ; Wo_c]:  u1 = W'1 x1 + W'1 bo_c + (W'1 Wo_c) a_c (two halves, atomics into the zeros X1
+                // left: two commutative additions, so the order does not matter),  x2 = x1 + Wo_c a_c + bo_c (+ a copy that
+                // fc2 takes the LayerNorm statistics of while its atomics are already modifying the stream)
+                StackParams sp;
+                memset(&sp, 0, sizeof(sp));
+                sp.W = L.ws5; sp.K = D; sp.Mb = nb; sp.nseg = 3;
+                sp.seg[0].x = xalt;     sp.seg[0].bias = L.u1_bias; sp.seg[0].out = c->d_u1; sp.seg[0].tile0 = 0;      sp.seg[0].n_tiles = TF; sp.seg[0].epi = 2;
+                sp.seg[1].x = c->dattn; sp.seg[1].bias = nullptr;   sp.seg[1].out = c->d_u1; sp.seg[1].tile0 = TF;     sp.seg[1].n_tiles = TF; sp.seg[1].epi = 2;
+                sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo_c;    sp.seg[2].out = xin;     sp.seg[2].tile0 = 2 * TF; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
+                sp.seg[2].resid = xalt; sp.seg[2].out2 = c->dx2c;
+                CWCHK(c, KD(c, cw_launch_gemv_stack, sp, c->stack_nt5, c->st));
+            }
+            {   // fc2: mid = gelu(rstd(x2) (u1 - mean(x2) W'1 1) + b'1) on load; x3 = x2 + W2 mid + b2 in place
+                Fc2xParams fp{c->dx2c, c->d_u1, L.u1_wsum, L.b1, L.w2, L.b2, xin, nb, D, F};
+                CWCHK(c, KD(c, cw_launch_gemv_fc2x, fp, c->st));
+            }
+            continue;
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
@@ -831,7 +961,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     }
     if (want_logits) {   // final LN + tied proj_out (:790, :1080), logits in f32 (utils.py:2894)
         EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = c->Vpad;
-        CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep));
+        CWCHK(c, gemv_ln(c, EPI_STORE_F32, xin, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep));
     }
     return CW_OK;
 }

@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const float* __restrict_
 // Development aid (make EXTRA=-DCW_PHASE_TIMING, tools/phase_probe.py): thread 0 of the first 512 blocks stamps the
 // 100 MHz wall clock at the phase boundaries of the decode GEMV; cw_debug_phases copies the stamps out.  This is how the
 // ds_bpermute-based LayerNorm reductions were found on the critical path (1.5 us of a 7.9 us kernel).
-#ifdef CW_PHASE_TIMING
+#if defined(CW_PHASE_TIMING) && !defined(CW_F16)
 __device__ unsigned long long g_phase[512 * 8];
 #define PH(i)                                                                                          \
     do {                                                                                               \

@@ -92,12 +92,56 @@ struct CrossSplitParams {
     int n_align, align_rows, B, H;
     const float* kv_scale; // fp8 cache only: [B][H][2] dequantisation scales of K and V (null: K/V hold T)
     int kv_div;            // > 1: rows b share the K/V of audio item b / kv_div (beam search)
+    // fused out-projection / query stage (decfuse.hip): q is finished here from the two partial projections and the statistics of
+    // the residual row,  q = rstd(xs) * (qa + qb - mean(xs) * qw) + qbias;  all null: `q` holds the finished query
+    const float* xstat;    // [B][H*64] residual rows the LayerNorm statistics are taken of (null: plain q), or
+    const float* pstats;   // [n_pstats][8][2] per-block (sum, sum of squares) of those rows, left by the producing GEMV
+    int n_pstats;
+    const float* qa;       // [B][H*64] W'q x + W'q bo
+    const float* qb;       // [B][H*64] (W'q Wo) a
+    const float* qw;       // [H*64]    W'q 1
+    const float* qbias;    // [H*64]    b'q
+    float* a_out;          // [B][H*64] non-null: one block per (row, head) over all keys writes the finished output (no splits)
 };
 // opt-in fp8 (OCP e4m3) cross-attention cache: quantise one layer's bf16 K/V [B][H][S][64] with a scale per (b, h, K|V)
 struct CombineParams {     // activations of a GEMV = combination of ATT_NS attention partials
     const float* part_ml;  // null: plain activations
     int H;                 // heads
     int plane;             // elements per partial plane (B * K)
+};
+
+// decfuse.hip: one launch over a row-stacked weight matrix W [sum n_tiles * 16][K]; up to 3 segments
+struct StackSeg {
+    const float* x;        // [Mb][K] f32 input rows of this segment (rounded to 16 bit, no LayerNorm)
+    const float* bias;     // [n_tiles*16] or null
+    const float* resid;    // epi 1: [Mb][n_tiles*16]
+    float* out;            // [Mb][n_tiles*16]
+    float* out2;           // epi 1: optional second copy of the result
+    float* pstats;         // epi 1: optional [blocks of the segment][8][2] per-block (sum, sum of squares) of every output row
+    int tile0, n_tiles;    // rows [tile0*16, (tile0+n_tiles)*16) of W
+    int nt;                // 16-column tiles per block of this segment (<= the launch's NT; 0 = NT)
+    int block0;            // filled in by the launcher
+    int epi;               // 0: out = acc + bias;  1: out = resid + grid(acc + bias)   (2^-12 residual grid)
+                           // 2: out += acc + bias (f32 atomics; two segments summing into a zeroed buffer: order-independent)
+};
+struct StackParams {
+    const void* W;
+    int K, Mb, nseg;
+    StackSeg seg[3];
+    float* zero;           // optional: the launch also clears zero_n4 float4 (a buffer a LATER launch accumulates into)
+    int zero_n4;
+};
+// decfuse.hip: fc2 that finishes fc1 on load, mid = gelu(rstd (u - mean w1sum) + b1), (mean, rstd) = LayerNorm statistics of
+// the residual rows `xstat` (an untouched copy: the launch's own atomics are already modifying the stream x)
+struct Fc2xParams {
+    const float* xstat;    // [Mb][D]
+    const float* u;        // [Mb][F] W'1 x2 summands: W'1 x1 + W'1 bo_c + (W'1 Wo_c) a_c
+    const float* w1sum;    // [F] W'1 1
+    const float* b1;       // [F] b'1
+    const void* W2;        // [D][F]
+    const float* b2;       // [D]
+    float* x;              // [Mb][D] residual stream, accumulated in place
+    int Mb, D, F;
 };
 
 // mel.hip
@@ -121,6 +165,10 @@ struct MelTables {
     int cw_launch_gemm_fp8(int epi, const void* A8, int lda, const void* W8, int M, int N, int K, const float* sa, const float* sw, const EpiParams& ep, hipStream_t st); \
     int cw_launch_fold_layernorm(const float* Wf, int N, int K, const float* g, const float* beta, float scale, void* w_out, float* bias, hipStream_t st); \
     int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr, void* scratch = nullptr ); \
+    int cw_launch_fold_product(const float* A, const float* s, float scale, const float* B, int N, int J, int K, void* C16, hipStream_t st); \
+    int cw_launch_fold_rowvec(const float* A, const float* s, float scale, const float* v, const void* W16, int N, int J, float* c_out, float* w_out, hipStream_t st); \
+    int cw_launch_gemv_stack(const StackParams& p, int nt, hipStream_t st); \
+    int cw_launch_gemv_fc2x(const Fc2xParams& p, hipStream_t st); \
     int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d, hipStream_t st); \
     int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d, hipStream_t st); \
     int cw_launch_sample(const SampleParams& p, hipStream_t st); \
