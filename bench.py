@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-rccl", action="store_true", help="N=1 only: do not create the one-rank RCCL communicator")
     ap.add_argument("--no-longform", action="store_true", help="skip the BASELINE configs[2] leg (600 s recording sharded over the ranks)")
     ap.add_argument("--longform-seconds", type=int, default=600)
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE configs[3] leg (batch 64, bf16 and the opt-in fp8 mode, 2 steps each; N = 1 only)")
     ap.add_argument("--num-beams", type=int, default=1,
                     help="beam search width (default 1 = greedy, the BASELINE configuration; 5 = what the literal reference call "
                          "decodes with under transformers 5.x); the engine is provisioned with batch x beams decoder rows")
@@ -139,8 +140,86 @@ def cpu_reference(geometry, n_tok, threads, timeout_s, style="aligned"):
                       f"token timestamps {st['token_timestamps']:.1f} s); model build {r['build_s']:.1f} s not counted"}
 
 
+def config3_leg(a, dev, g, v, spec, gold_path):
+    """BASELINE configs[3] (throughput ceiling): batch = 64 x 30 s on one GPU, the same step as the headline -- once in the parity
+    dtype (bf16) and once in the opt-in fp8 mode (e4m3 MFMA GEMMs in the encoder + e4m3 cross-attention cache; accuracy-gated, not
+    the parity path).  1 warm-up + 2 timed steps each; the first 8 clips are the golden clips, checked against the reference."""
+    from crisperwhisper_amd import collate, generation, synthetic as syn
+    from crisperwhisper_amd.engine import Engine
+    B3 = 64
+    vocab = collate.Vocabulary.from_synthetic(v)
+    gold = json.load(open(gold_path)) if os.path.exists(gold_path) else None
+    clips = [syn.synth_audio(i, 480000, "noise") for i in range(B3)]
+    out = {"workload": f"BASELINE configs[3]: batch={B3} x 30 s, {a.tokens} tokens/chunk, 1 warm-up + 2 timed steps per mode", "modes": {}}
+    for mode in ("bf16", "fp8"):
+        eng = Engine(spec, dtype=a.dtype, max_batch=B3, device=dev, cross_kv_dtype="fp8" if mode == "fp8" else None)
+        try:
+            for name, shape in syn.weight_shapes(g).items():
+                eng.load_tensor(name, syn.weight_tensor(g, name, shape, 0, a.weights))
+            if mode == "fp8":
+                eng.check_weights()
+                eng.set_encoder_gemm_fp8(True)
+            nf = eng.upload_pcm(clips)
+
+            def one():
+                eng.mel_resident(B3)
+                return generation.generate(eng, B3, nf, language="<|en|>", task="transcribe", max_new_tokens=a.tokens,
+                                           min_new_tokens=a.tokens)
+            one()
+            eng.stage_times(reset=True)
+            eng.sync()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                res = one()
+            eng.sync()
+            dt = (time.perf_counter() - t0) / 2
+            st = eng.stage_times()
+            words = same = w_ok = w_tot = 0
+            for k in range(B3):
+                n = len(res["token_timestamps"][k])
+                text, ws = collate.decode_asr(vocab, [{"tokens": res["sequences"][k][:n], "token_timestamps": res["token_timestamps"][k],
+                                                       "stride": (30.0, 0.0, 0.0)}])
+                words += len(ws)
+                if gold is not None and k < len(gold["clips"]) and gold["generate_kwargs"]["max_new_tokens"] == a.tokens and a.weights == "aligned":
+                    gc_ = gold["clips"][k]
+                    if text == gc_["text"] and len(ws) == len(gc_["chunks"]):
+                        same += 1
+                        for wa, wb in zip(ws, gc_["chunks"]):
+                            w_tot += 1
+                            w_ok += int(wa["text"] == wb["text"] and all(abs(x - y) <= 0.02 + 1e-9 for x, y in zip(wa["timestamp"], wb["timestamp"])))
+            enc_ms, enc_calls = st["encoder"]
+            enc_tf = 2.274e12 * B3 / (enc_ms / enc_calls) / 1e9 if enc_calls else None
+            peak = 5000.0 if mode == "fp8" else 2500.0
+            out["modes"][mode] = {"ms_per_step": dt * 1e3, "rtf": dt / (30.0 * B3), "aligned_words_per_s": words / dt,
+                                  "stage_ms_per_step": {k_: round(val[0] / 2, 3) for k_, val in st.items()},
+                                  "encoder_TFps": enc_tf, "encoder_frac_of_peak": (enc_tf / peak if enc_tf else None), "encoder_peak_TFps": peak,
+                                  "golden_clips_identical_text": [same, min(8, B3)], "golden_words_within_20ms": [w_ok, w_tot],
+                                  "encoder_gemm": "fp8" if mode == "fp8" else a.dtype, "cross_kv_cache": "fp8" if mode == "fp8" else a.dtype}
+        finally:
+            eng.close()
+    return out
+
+
+def spawn_command(a, argv, port):
+    """`python bench.py --gpus N` without a launcher: the command that re-runs this script as N ranks, one per GPU of this node
+    (torch.distributed.run, rendezvous on 127.0.0.1 -- the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: spawn the ranks ourselves and relay rank 0's JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        rc = subprocess.call(spawn_command(a, sys.argv[1:], port), env=env)
+        sys.exit(rc)
     # stdout carries exactly ONE line (the JSON record): everything else any library writes to fd 1 -- RCCL prints a five-line
     # version banner there, through C stdio, at communicator creation or at exit -- is diverted to stderr
     sys.stdout.flush()
@@ -149,6 +228,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     import torch  # imported before the native library so that one HIP runtime serves both
     import torch.distributed as td
     backend = os.environ.get("CW_DIST_BACKEND", "nccl")       # "gloo": lets 2 ranks share one GPU in a smoke test
@@ -315,7 +396,8 @@ def main():
             parity = {"timestamp_f1_collar_0.2s": float(np.mean(f1s)) if f1s else None, "mean_word_iou": float(np.mean(ious)) if ious else None,
                       "against": "tests/golden/e2e_bench_golden.json (transformers 5.15.0 pipeline, CPU fp32, same clips / weights / token count)",
                       "mode": "free-running greedy, the timed path itself", "clips_with_identical_text": [same_text, n],
-                      "words_identical_and_within_20ms": [w_ok, w_tot]}
+                      "words_identical_and_within_20ms": [w_ok, w_tot],
+                      "ok": bool(n > 0 and same_text == n and w_tot > 0 and w_ok >= 0.99 * w_tot)}
 
     # ---- BASELINE configs[2]: one long recording -> 30 s chunks with 5 s strides, chunk-sharded over the ranks
     # (contiguous blocks, dist.shard_bounds), one all-gather of the per-chunk records, seam merge + pause split on every
@@ -389,7 +471,8 @@ def main():
                          "avg_launch_ms": r["avg_ms"], "algorithmic_bytes_per_launch": r["algo_bytes"]},
             "parity": parity,
             "collective": {"backend": ("rccl (torch.distributed nccl)" if pg == "nccl" else pg), "all_gathers_in_timed_region": n_gathers,
-                           "note": pg_note},
+                           "ranks_seen": (td.get_world_size() if pg is not None else 1), "devices_visible": ndev,
+                           "chunks_per_rank": [B * C] * world, "note": pg_note},
             "longform": longform,
             "roofline_other": [{"kernel": roof[k]["kernel"], "achieved_GBps": roof[k]["achieved"],
                                 "avg_launch_ms": roof[k]["avg_ms"], "algorithmic_bytes_per_launch": roof[k]["algo_bytes"]}
@@ -431,6 +514,14 @@ def main():
                                           "dtw_us_per_antidiagonal": t * 1e3 / (a.tokens + 1500 - 1)}
             line["stage_roofline"] = sr
             line["passes_per_step"] = stages["encoder"][1] / max(a.steps, 1)
+        if a.geometry == "large-v3" and world == 1 and not a.no_config3 and a.dtype in ("bf16", "f16") and a.num_beams == 1:
+            for e_ in engines:
+                e_.close()
+            engines = []
+            try:
+                line["config3"] = config3_leg(a, dev, g, v, spec, gpath)
+            except Exception as e:                   # never take the headline down with it
+                line["config3"] = {"error": repr(e)}
         if keep:
             for e_ in engines:                       # free the GPU side first: the CPU legs need the host memory bandwidth
                 e_.close()

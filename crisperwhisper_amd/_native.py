@@ -58,6 +58,9 @@ _SIGS = {
     "cw_encode": (_I, [_P, _I, _P, _P, _P]),
     "cw_get_encoder_output": (_I, [_P, _P, _I]),
     "cw_decode": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "cw_set_thresholds": (_I, [_P, C.c_float, C.c_float]),
+    "cw_no_speech_probs": (_I, [_P, _I, _I, _P]),
+    "cw_get_avg_logprobs": (_I, [_P, _P, _I]),
     "cw_get_logits": (_I, [_P, _P, _I]),
     "cw_set_logits_capture": (_I, [_P, _P, _I]),
     "cw_get_alignment": (_I, [_P, _P, _I, _I]),

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(SampleParams p, Sam
     const uchar4* mk4 = (const uchar4*)p.mask;
     ArgPair bt = {-INFINITY, 0x7fffffff}, bs = {-INFINITY, 0x7fffffff};
     float sv[4][4]; int nmine = 0;                                         // this thread's allowed timestamp scores
+    float tv[4][4];                                                        // ... and allowed text scores (p.lp_sum only)
     for (int i4 = lo4 + tid, it = 0; i4 < hi4; i4 += 256, ++it) {
         const float4 x = lg4[i4]; const uchar4 mk = mk4[i4];
         const float xs[4] = {x.x, x.y, x.z, x.w};
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(SampleParams p, Sam
                 ArgPair c = {val, v};
                 if (v < tb) bt = arg_better(bt, c); else bs = arg_better(bs, c);
             }
-            if (it < 4) sv[it][j] = (v >= tb && v < p.V) ? val : -INFINITY;
+            if (it < 4) { sv[it][j] = (v >= tb && v < p.V) ? val : -INFINITY; tv[it][j] = (v < tb) ? val : -INFINITY; }
         }
         nmine = it + 1;
     }
@@ -272,9 +273,19 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(SampleParams p, Sam
     }
     __syncthreads();
     acc = block_sum(acc, s_f);
+    float acc_t = 0.f;                                          // sum over allowed text tokens of exp(s - slice max), on request
+    if (p.lp_sum) {
+        if (bt.v > -INFINITY) {
+            for (int it = 0; it < nmine && it < 4; ++it)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (tv[it][j] > -INFINITY) acc_t += expf(tv[it][j] - bt.v);
+        }
+        __syncthreads();
+        acc_t = block_sum(acc_t, s_f);
+    }
     if (tid == 0 && b == 0 && sl == 0) *p.n_unfinished = 0;     // stage 2 (a later launch) counts the running rows into it
     if (tid == 0) {
-        SamplePart o; o.bt_v = bt.v; o.bt_i = bt.i; o.bs_v = bs.v; o.bs_i = bs.i; o.ts_sum = acc; o.pad[0] = o.pad[1] = o.pad[2] = 0.f;
+        SamplePart o; o.bt_v = bt.v; o.bt_i = bt.i; o.bs_v = bs.v; o.bs_i = bs.i; o.ts_sum = acc; o.pad[0] = acc_t; o.pad[1] = o.pad[2] = 0.f;
         part[(size_t)b * SAMPLE_NS + sl] = o;
     }
 }
@@ -324,6 +335,18 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleParams p) {
         if (!(M > -INFINITY) || choice < 0 || choice >= p.V) choice = 0;
         if (p.argmax_trace) p.argmax_trace[(size_t)b * p.ids_stride + t] = choice;
         int tok = (forced >= 0) ? forced : choice;
+        if (p.lp_sum && !was_finished && n_gen >= 0) {
+            // log_softmax of the PROCESSED scores at the chosen token (generation_whisper.py:1967-1971): suppressed tokens
+            // are -inf there, and so is every text token once the timestamp rule has fired
+            float st = 0.f;
+            for (int i = 0; i < SAMPLE_NS; ++i)
+                if (pr[i].bt_v > -INFINITY) st += pr[i].pad[0] * expf(pr[i].bt_v - M);
+            const float tot = acc + (force_ts ? 0.f : st);
+            if (tot > 0.f && tok >= 0 && tok < p.V) {
+                p.lp_sum[b] += lg[tok] - (M + logf(tot));
+                p.lp_cnt[b] += 1;
+            }
+        }
         if (was_finished) tok = p.pad;                                  // utils.py:2928-2929
         ids[t] = tok;
         if (tok >= tb && n_gen >= 0) p.last_ts_tok[b] = tok;

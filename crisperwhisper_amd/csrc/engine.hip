@@ -96,6 +96,9 @@ struct cw_ctx {
     int *d_ids = nullptr, *d_forced = nullptr, *d_argmax = nullptr, *d_last_ts = nullptr, *d_finished = nullptr,
         *d_nunf = nullptr, *d_align_slot = nullptr;
     unsigned char* d_mask = nullptr;
+    float* d_lp_sum = nullptr; int* d_lp_cnt = nullptr;      // per-row sum / count of chosen-token log-probabilities (score_tokens)
+    bool score_tokens = false;
+    float logprob_thr = NAN, no_speech_thr = NAN;             // cw_set_thresholds (NaN: unset)
     void* d_sample_part = nullptr;            // [Bm][16] 32-byte slice records of the two-stage sampler
     float* d_align = nullptr;
     float *d_part_o = nullptr, *d_part_ml = nullptr, *d_align_ml = nullptr;   // split cross-attention partials
@@ -112,6 +115,7 @@ struct cw_ctx {
     void *h8 = nullptr, *mid8 = nullptr; float *sa8 = nullptr, *smid8 = nullptr;   // e4m3 activations and their row scales
     // beam search (cw_beam_*): rows = items x beams; self-attention keys are found through the ancestry table
     int beam_K = 0, beam_items = 0, beam_n_prompt = 0;
+    int beam_pos = 0, beam_max_len = 0;   // position of the last decoder input / length limit (cw_beam_step refuses to run past it)
     int *d_anc = nullptr, *d_anc_tmp = nullptr, *d_ids_tmp = nullptr, *d_parent = nullptr, *d_tok = nullptr, *d_cand_id = nullptr,
         *d_rowmap = nullptr;
     float *d_cand_val = nullptr, *d_align_g = nullptr, *d_topk_scratch = nullptr;
@@ -403,6 +407,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_pos, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_cfg, 4 * 4));
     CWCHK(c, dmalloc(c, &c->d_mask, (size_t)V + 16));
     CWCHK(c, dmalloc(c, &c->d_sample_part, (size_t)Bm * 16 * 32));
+    CWCHK(c, dmalloc(c, &c->d_lp_sum, (size_t)Bm * 4)); CWCHK(c, dmalloc(c, &c->d_lp_cnt, (size_t)Bm * 4));
     CWCHK(c, dmalloc(c, &c->d_align_slot, (size_t)d.dec_layers * H * 4));
     {
         std::vector<int> slot((size_t)d.dec_layers * H, -1);
@@ -979,6 +984,7 @@ static int launch_sample(cw_ctx* c, int nb, bool forced) {
     sp.n_unfinished = c->d_nunf;
     sp.embed = c->embed; sp.pos_embed = c->dec_pos; sp.x_out = c->dx; sp.d = c->d.d_model; sp.embed_bf16 = c->bf16 ? 1 : 0;
     sp.partials = c->d_sample_part;
+    if (c->score_tokens) { sp.lp_sum = c->d_lp_sum; sp.lp_cnt = c->d_lp_cnt; }
     (void)forced;
     return KD(c, cw_launch_sample, sp, c->st);
 }
@@ -1027,6 +1033,8 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
     HIPCHK(c, hipMemcpyAsync(c->d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->st));
     if (forced) HIPCHK(c, hipMemcpyAsync(c->d_forced, forced, (size_t)nb * TGT * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_finished, 0, nb * 4, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_lp_sum, 0, nb * 4, c->st));
+    HIPCHK(c, hipMemsetAsync(c->d_lp_cnt, 0, nb * 4, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_last_ts, 0xff, nb * 4, c->st));
     HIPCHK(c, hipMemsetAsync(c->d_argmax, 0xff, (size_t)nb * TGT * 4, c->st));
     const int cfg[4] = {n_prompt, min_new_tokens, max_length, forced ? 1 : 0};
@@ -1087,6 +1095,65 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
     c->last_L = t - 1;   // attention rows retained: one per decoder input position
     c->align_unnormalized = c->bf16 && c->d.n_align > 0;
     c->last_nb = nb;
+    return CW_OK;
+}
+
+// ---- deterministic half of generate_with_fallback (generation_whisper.py:970-1116, 1243-1287)
+static void drop_step_graphs(cw_ctx* c) {
+    for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // kernel arguments are baked into the graphs
+}
+
+int32_t cw_set_thresholds(cw_ctx* c, float logprob_threshold, float no_speech_threshold) {
+    if (!isnan(no_speech_threshold) && isnan(logprob_threshold))
+        return fail(c, CW_ERR_INVALID, "no_speech_threshold needs logprob_threshold (generation_whisper.py:1275-1285 compares both)");
+    c->logprob_thr = logprob_threshold; c->no_speech_thr = no_speech_threshold;
+    const bool want = !isnan(logprob_threshold);
+    if (want != c->score_tokens) { c->score_tokens = want; drop_step_graphs(c); }
+    return CW_OK;
+}
+
+// average log_softmax(processed scores)[token] over the generated tokens of every row of the last cw_decode, the eos
+// included (generation_whisper.py:1958-1974); rows that generated nothing report 0
+int32_t cw_get_avg_logprobs(cw_ctx* c, float* out, int32_t nb) {
+    if (!c->score_tokens) return fail(c, CW_ERR_STATE, "token scores are only tracked while a logprob threshold is set (cw_set_thresholds)");
+    if (nb < 1 || nb > c->last_nb) return fail(c, CW_ERR_INVALID, "nb=%d but the last decode had %d rows", nb, c->last_nb);
+    std::vector<float> s(nb); std::vector<int> n(nb);
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipMemcpy(s.data(), c->d_lp_sum, nb * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(n.data(), c->d_lp_cnt, nb * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; ++b) out[b] = n[b] > 0 ? s[b] / (float)n[b] : 0.f;
+    return CW_OK;
+}
+
+// WhisperNoSpeechDetection (logits_process.py:2050-2112): softmax of the raw decoder logits at the <|startoftranscript|>
+// position of every encoded window, at token no_timestamps_token_id - 1 (generation_whisper.py:1801-1806).  One decoder
+// forward at position 0; call it before cw_decode (which decodes position 0 again).
+int32_t cw_no_speech_probs(cw_ctx* c, int32_t nb, int32_t sot_token, float* out) {
+    const int D = c->d.d_model, V = c->d.vocab_size, TGT = c->d.max_target_positions;
+    if (!c->gen_set) return fail(c, CW_ERR_STATE, "cw_set_generation not called");
+    if (nb < 1 || nb > c->nb_encoded) return fail(c, CW_ERR_STATE, "nb=%d but %d windows encoded", nb, c->nb_encoded);
+    const int tok = c->gen.no_timestamps_token_id - 1;
+    if (sot_token < 0 || sot_token >= V || tok < 0) return fail(c, CW_ERR_INVALID, "no_speech_probs: token out of range");
+    c->beam_K = 0;
+    c->align_cur = c->d_align;
+    std::vector<int> ids((size_t)nb * TGT, c->gen.pad_token_id);
+    for (int b = 0; b < nb; ++b) ids[(size_t)b * TGT] = sot_token;
+    HIPCHK(c, hipMemcpyAsync(c->d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 0, nb, c->st));
+    CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, 0, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
+    CWCHK(c, decode_step(c, nb, true));
+    KCHK(c);
+    std::vector<float> lg((size_t)nb * V);
+    CWCHK(c, cw_get_logits(c, lg.data(), nb));
+    for (int b = 0; b < nb; ++b) {
+        const float* r = lg.data() + (size_t)b * V;
+        float m = r[0];
+        for (int v = 1; v < V; ++v) m = r[v] > m ? r[v] : m;
+        double z = 0.0;
+        for (int v = 0; v < V; ++v) z += exp((double)(r[v] - m));
+        out[b] = (float)(exp((double)(r[tok] - m)) / z);
+    }
     return CW_OK;
 }
 
@@ -1166,6 +1233,7 @@ int32_t cw_beam_begin(cw_ctx* c, int32_t n_items, int32_t num_beams, const int32
     HIPCHK(c, hipMemcpyAsync(c->d_cfg, cfg, sizeof(cfg), hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     c->beam_K = num_beams; c->beam_items = n_items; c->beam_n_prompt = n_prompt;
+    c->beam_pos = n_prompt - 1; c->beam_max_len = max_length;
     c->align_cur = c->d_align;
     for (int pos = 0; pos + 1 < n_prompt; ++pos) {          // prompt positions: forward only
         CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, pos, rows, c->st));
@@ -1182,6 +1250,9 @@ int32_t cw_beam_begin(cw_ctx* c, int32_t n_items, int32_t num_beams, const int32
 int32_t cw_beam_step(cw_ctx* c, int32_t n_cand, float* cand_logprob, int32_t* cand_token) {
     if (c->beam_K <= 0) return fail(c, CW_ERR_STATE, "cw_beam_begin not called");
     if (n_cand < 1 || n_cand > 64) return fail(c, CW_ERR_INVALID, "n_cand=%d out of range", n_cand);
+    // the token chosen from this step sits at index beam_pos + 1: one step too many would write cache and alignment rows
+    // beyond the limit the context was sized for
+    if (c->beam_pos + 1 >= c->beam_max_len) return fail(c, CW_ERR_STATE, "beam_step: sequence already has max_length=%d tokens", c->beam_max_len);
     const int rows = c->beam_items * c->beam_K;
     StageTimer tm(c, CW_STAGE_DECODE);
     CWCHK(c, decode_step(c, rows, true));
@@ -1221,6 +1292,7 @@ int32_t cw_beam_advance(cw_ctx* c, const int32_t* parent, const int32_t* token) 
     p.rows = rows;
     CWCHK(c, KD(c, cw_launch_beam_advance, p, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));                   // parent / token are caller-owned host buffers
+    c->beam_pos += 1;
     return CW_OK;
 }
 
@@ -1284,8 +1356,18 @@ int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, 
     {   // workspace of the wave-local DTW, grown on demand (diagonal-major copy of the cost matrices)
         const size_t need = cw_dtw_skew_floats(nb, N, S);
         if (need > c->skew_cap) {
-            CWCHK(c, dmalloc(c, &c->d_skew, need * 4, false));
-            c->skew_cap = need;
+            // grown at most a few times: sized for the worst case of this batch size (N = max_target_positions) and the
+            // previous buffer is released, so a token count that creeps upwards cannot pile up dead workspaces
+            const size_t want = cw_dtw_skew_floats(nb, c->d.max_target_positions, S) > need ? cw_dtw_skew_floats(nb, c->d.max_target_positions, S) : need;
+            if (c->d_skew) {
+                HIPCHK(c, hipStreamSynchronize(c->st));
+                for (auto it = c->allocs.begin(); it != c->allocs.end(); ++it)
+                    if (*it == (void*)c->d_skew) { c->allocs.erase(it); break; }
+                hipFree(c->d_skew);
+                c->d_skew = nullptr; c->skew_cap = 0;
+            }
+            CWCHK(c, dmalloc(c, &c->d_skew, want * 4, false));
+            c->skew_cap = want;
         }
     }
     CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, getenv("CW_DTW_BLOCK") ? c->d_path_text : nullptr, getenv("CW_DTW_BLOCK") ? c->d_path_time : nullptr, c->d_path_len, c->st, c->d_skew));
@@ -1364,7 +1446,13 @@ int32_t cw_transcribe(cw_ctx* c, int32_t B, const int32_t* num_frames, const cw_
         if (!(pre_encoded && passes == 0)) CWCHK(c, cw_encode(c, nb, active.data(), a_seek.data(), a_n.data()));
         std::vector<int> prm((size_t)nb * n_prompt), seq((size_t)nb * TGT), ln(nb);
         for (int r = 0; r < nb; ++r) for (int k = 0; k < n_prompt; ++k) prm[(size_t)r * n_prompt + k] = prompts[active[r]][k];
+        // deterministic half of generate_with_fallback: a window with a low average log-probability AND a high no-speech
+        // probability is skipped (seek moves on by the whole window, no segment; :879-881, :1275-1285)
+        const bool thr = !isnan(c->logprob_thr) && !isnan(c->no_speech_thr);
+        std::vector<float> nsp(nb, 0.f), alp(nb, 0.f);
+        if (thr) CWCHK(c, cw_no_speech_probs(c, nb, cfg->sot_token, nsp.data()));
         CWCHK(c, cw_decode(c, nb, prm.data(), n_prompt, max_length, cfg->min_new_tokens, nullptr, seq.data(), ln.data(), nullptr));
+        if (thr) CWCHK(c, cw_get_avg_logprobs(c, alp.data(), nb));
         int total = 0;
         for (int r = 0; r < nb; ++r) total = ln[r] > total ? ln[r] : total;
         const int L = total - 1;
@@ -1373,6 +1461,7 @@ int32_t cw_transcribe(cw_ctx* c, int32_t B, const int32_t* num_frames, const cw_
         ++passes;
         for (int r = 0; r < nb; ++r) {
             const int i = active[r];
+            if (thr && alp[r] < c->logprob_thr && nsp[r] > c->no_speech_thr) { seek[i] += a_n[r]; continue; }
             const int* s = seq.data() + (size_t)r * TGT + n_prompt;
             int n = total - n_prompt;
             if (n > 0 && s[n - 1] == pad) {                                            // strip right padding (:1060-1067)
@@ -1600,6 +1689,7 @@ static int enc8_quantise(cw_ctx* c) {
 }
 
 int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
+    if (!name) return fail(c, CW_ERR_INVALID, "cw_set_option: null option name");
     if (!strcmp(name, "cross_kv_fp8")) {
         if (!value) { c->kv8 = false; return CW_OK; }
         if (!c->bf16) return fail(c, CW_ERR_INVALID, "cross_kv_fp8 needs the bf16 engine (the f32 engine is the parity mode)");

@@ -38,6 +38,10 @@ struct SampleParams {
     int d;
     int embed_bf16;
     const void* partials;      // [B][SAMPLE_NS] slice records (32 bytes each), written by stage 1 of the sampler
+    // optional (null: off): running sum / count of log_softmax(processed scores)[chosen token] per row, for the average
+    // log-probability of generation_whisper.py:1958-1974 (logprob_threshold)
+    float* lp_sum;             // [B]
+    int* lp_cnt;               // [B]
 };
 // beam search (elementwise.hip): per row the n_cand best processed log-probabilities of the next token
 // (log_softmax of the raw logits, then the same processors as the greedy path) ...

@@ -193,6 +193,22 @@ class Engine:
                                      _ptr(f), _ptr(seqs), _ptr(lens), _ptr(amax)))
         return seqs, lens, amax
 
+    def set_thresholds(self, logprob_threshold: Optional[float] = None, no_speech_threshold: Optional[float] = None):
+        """Deterministic half of generate_with_fallback (``cw_set_thresholds``); None = unset."""
+        nan = float("nan")
+        self._chk(self.lib.cw_set_thresholds(self.ctx, nan if logprob_threshold is None else float(logprob_threshold),
+                                             nan if no_speech_threshold is None else float(no_speech_threshold)))
+
+    def no_speech_probs(self, nb: int, sot: int) -> np.ndarray:
+        out = np.zeros(nb, np.float32)
+        self._chk(self.lib.cw_no_speech_probs(self.ctx, nb, int(sot), _ptr(out)))
+        return out
+
+    def avg_logprobs(self, nb: int) -> np.ndarray:
+        out = np.zeros(nb, np.float32)
+        self._chk(self.lib.cw_get_avg_logprobs(self.ctx, _ptr(out), nb))
+        return out
+
     def last_logits(self, nb: int) -> np.ndarray:
         out = np.empty((nb, self.spec.vocab_size), dtype=np.float32)
         self._chk(self.lib.cw_get_logits(self.ctx, _ptr(out), nb))

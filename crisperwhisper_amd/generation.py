@@ -258,12 +258,13 @@ def beam_search(engine: Engine, prompt: np.ndarray, max_length: int, min_new_tok
     unrolled = np.concatenate([np.repeat(bi_out[:, :1], n_prompt - 1, axis=1), bi_out], axis=1) if n_prompt > 1 else bi_out
     unrolled = np.where(unrolled == -1, 0, unrolled).astype(np.int32)
     engine.beam_finish(unrolled)
-    return seq_out, bi_out, unrolled.shape[1]
+    return seq_out, bi_out, unrolled.shape[1], beam_scores[:, 0].astype(np.float32)
 
 
 def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str], task: Optional[str] = None,
              max_new_tokens: Optional[int] = None, min_new_tokens: Optional[int] = None,
-             num_beams: Optional[int] = 1, stats: Optional[dict] = None, native: Optional[bool] = None):
+             num_beams: Optional[int] = 1, stats: Optional[dict] = None, native: Optional[bool] = None,
+             logprob_threshold: Optional[float] = None, no_speech_threshold: Optional[float] = None):
     """Transcribe the ``n_items`` 30 s feature windows resident in the engine (items 0..n-1).
 
     Returns {"sequences": [B, Lmax] int64 (pad-right), "token_timestamps": list of float32 arrays,
@@ -271,8 +272,20 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
 
     ``native`` (default: whenever the engine exports it) runs the seek loop inside the library
     (``cw_transcribe``, one C call per batch); ``native=False`` runs the same control flow here, stage by stage
-    over ``cw_encode`` / ``cw_decode`` / ``cw_token_timestamps`` -- the two are tested to agree exactly."""
+    over ``cw_encode`` / ``cw_decode`` / ``cw_token_timestamps`` -- the two are tested to agree exactly.
+
+    ``logprob_threshold`` / ``no_speech_threshold``: the deterministic (temperature 0) half of HF's
+    ``generate_with_fallback`` (generation_whisper.py:970-1116, ``_need_fallback`` :1243-1287): a window whose average token
+    log-probability is below the first AND whose no-speech probability is above the second is skipped -- seek moves on by the
+    whole window, no segment (:879-881).  Re-decoding at higher temperatures is not implemented (pipeline.py refuses it)."""
     spec = engine.spec
+    if no_speech_threshold is not None and logprob_threshold is None:
+        raise ValueError("no_speech_threshold needs logprob_threshold as well (generation_whisper.py:1275-1285 compares both)")
+    if hasattr(engine, "set_thresholds"):
+        engine.set_thresholds(logprob_threshold, no_speech_threshold)
+    elif logprob_threshold is not None:
+        raise ValueError("this engine does not implement logprob_threshold / no_speech_threshold")
+    skip_on = logprob_threshold is not None and no_speech_threshold is not None
     num_beams = 1 if num_beams is None else int(num_beams)
     if num_beams < 1:
         raise ValueError(f"`num_beams` has to be an integer strictly greater than 0, but is {num_beams}")
@@ -330,8 +343,9 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
         if not (pre_encoded and n_calls == 0):            # first pass: windows already encoded for detection
             engine.encode(active, seek[active], seek_num[active])
         max_length = (n_prompt + max_new_tokens) if max_new_tokens is not None else min(spec.max_length, spec.max_target_positions)
+        nsp = engine.no_speech_probs(len(active), spec.decoder_start_token_id) if skip_on else None
         if num_beams > 1:
-            bs, _, L = beam_search(engine, init[active], max_length, min_new_tokens or 0, num_beams)
+            bs, _, L, alp = beam_search(engine, init[active], max_length, min_new_tokens or 0, num_beams)   # sequences_scores (:1262-1263)
             total = bs.shape[1]
             seqs = np.full((len(active), spec.max_target_positions), spec.pad_token_id, dtype=np.int64)
             seqs[:, :total] = bs
@@ -339,9 +353,13 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
             seqs, lens, _ = engine.decode(init[active], max_length, min_new_tokens or 0)
             total = int(lens.max())
             L = total - 1
+            alp = engine.avg_logprobs(len(active)) if skip_on else None
         token_ts = engine.token_timestamps(len(active), L, n_prompt, (num_frames - seek)[active])
         n_calls += 1
         for row, i in enumerate(active):
+            if skip_on and float(alp[row]) < logprob_threshold and float(nsp[row]) > no_speech_threshold:
+                seek[i] += seek_num[i]                            # should_skip (:879-881)
+                continue
             s = seqs[row, n_prompt:total].astype(np.int64)
             if s[-1] == spec.pad_token_id:                        # strip right padding, keep one eos
                 npad = int((s == spec.pad_token_id).sum())

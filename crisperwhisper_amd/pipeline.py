@@ -206,6 +206,49 @@ def _device_index(device) -> int:
     return int(s.split(":")[1]) if ":" in s else 0
 
 
+# generate_kwargs the native path implements (TF generation_whisper.py:generate); everything else raises instead of being
+# dropped: a drop-in must either honour an argument or refuse it
+_GENERATE_KWARGS = ("language", "task", "max_new_tokens", "min_new_tokens", "num_beams", "length_penalty", "early_stopping",
+                    "do_sample", "temperature", "num_return_sequences", "prompt_ids", "assistant_model",
+                    "logprob_threshold", "no_speech_threshold", "compression_ratio_threshold", "return_timestamps")
+
+
+def _check_generate_kwargs(gk: Dict[str, Any]) -> None:
+    unknown = sorted(k for k in gk if k not in _GENERATE_KWARGS)
+    if unknown:
+        raise ValueError(f"generate_kwargs {unknown} are not implemented on the native path (implemented: "
+                         f"{', '.join(_GENERATE_KWARGS)}); they would be silently ignored otherwise")
+    thresholds = [k for k in ("compression_ratio_threshold", "logprob_threshold", "no_speech_threshold") if gk.get(k) is not None]
+    if gk.get("do_sample"):
+        raise ValueError("generate_kwargs['do_sample'] is not supported on the native path (deterministic greedy / beam search "
+                         "only: stochastic decoding cannot be made bit-comparable with torch's generator)")
+    temp = gk.get("temperature")
+    if isinstance(temp, (tuple, list)):
+        # temperature fallback (generation_whisper.py:970-1116) only fires when a threshold is set
+        if thresholds or len(temp) == 0:
+            raise ValueError("temperature fallback with sampling is not implemented on the native path "
+                             "(stochastic decoding cannot be made bit-comparable with torch's generator)")
+        temp = temp[0]
+    if temp is not None and not (isinstance(temp, (int, float)) and not isinstance(temp, bool) and float(temp) in (0.0, 1.0)):
+        raise ValueError(f"generate_kwargs['temperature']={gk['temperature']!r} is not supported on the native path "
+                         "(deterministic greedy / beam search only)")
+    if gk.get("num_return_sequences") not in (None, 1):
+        raise ValueError("generate_kwargs['num_return_sequences'] > 1 is not supported on the native path")
+    for k in ("prompt_ids", "assistant_model"):
+        if gk.get(k) is not None:
+            raise ValueError(f"generate_kwargs[{k!r}] is not supported on the native path")
+    if gk.get("return_timestamps") not in (None, True, "word"):
+        raise ValueError("generate_kwargs['return_timestamps'] must be left to the pipeline argument of the same name")
+    if gk.get("no_speech_threshold") is not None and gk.get("logprob_threshold") is None:
+        raise ValueError("no_speech_threshold needs logprob_threshold as well (generation_whisper.py:1275-1285 compares both)")
+    if gk.get("logprob_threshold") is not None and gk.get("temperature") is None:
+        raise ValueError("logprob_threshold needs an explicit temperature (pass temperature=0.0): transformers itself fails with "
+                         "a TypeError in _retrieve_avg_logprobs otherwise (generation_whisper.py:1959)")
+    # with one temperature a failed compression-ratio / log-probability check has nowhere to fall back to and HF keeps the
+    # result (generation_whisper.py:1100-1104): the only observable effect of the thresholds at temperature 0 is the no-speech
+    # skip, which generation.generate implements; compression_ratio_threshold is therefore accepted and has no effect
+
+
 class CrisperWhisperPipeline:
     def __init__(self, model, tokenizer=None, feature_extractor=None, chunk_length_s=0, stride_length_s=None,
                  batch_size=1, return_timestamps=None, torch_dtype=None, dtype=None, device=None,
@@ -307,17 +350,7 @@ class CrisperWhisperPipeline:
         if return_language:
             raise ValueError("return_language is not supported on the native path")
         gk = dict(generate_kwargs or {})
-        for unsupported in ("do_sample", "temperature", "num_return_sequences", "prompt_ids", "assistant_model"):
-            val = gk.get(unsupported)
-            if unsupported == "temperature" and isinstance(val, (tuple, list)):
-                # temperature fallback (generation_whisper.py:970-1116) only fires when a threshold is set
-                if any(gk.get(k_) is not None for k_ in ("compression_ratio_threshold", "logprob_threshold", "no_speech_threshold")):
-                    raise ValueError("temperature fallback with sampling is not implemented on the native path "
-                                     "(stochastic decoding cannot be made bit-comparable with torch's generator)")
-                val = val[0]
-            if val not in (None, False, 0, 0.0, 1, 1.0):
-                raise ValueError(f"generate_kwargs[{unsupported!r}]={gk[unsupported]!r} is not supported on the native path "
-                                 "(deterministic greedy / beam search only)")
+        _check_generate_kwargs(gk)
         if "num_beams" not in gk:
             _warn_once("beams", f"no num_beams given: decoding with {self.default_num_beams} beams like the installed transformers "
                                 "ASR pipeline default; pass generate_kwargs={'num_beams': 1} for the greedy decoding of the 2024 reference")
@@ -356,7 +389,8 @@ class CrisperWhisperPipeline:
             out = generation.generate(
                 eng, len(idxs), nf, language=gk.get("language"), task=gk.get("task"),
                 max_new_tokens=gk.get("max_new_tokens"), min_new_tokens=gk.get("min_new_tokens"),
-                num_beams=num_beams, stats=st)
+                num_beams=num_beams, stats=st, logprob_threshold=gk.get("logprob_threshold"),
+                no_speech_threshold=gk.get("no_speech_threshold"))
             rs = []
             for k, i in enumerate(idxs):
                 n_tok = len(out["token_timestamps"][k])

@@ -138,6 +138,17 @@ int32_t cw_get_encoder_output(cw_ctx* ctx, float* out /* [nb][1500][d_model] */,
 int32_t cw_decode(cw_ctx* ctx, int32_t nb, const int32_t* prompt, int32_t n_prompt, int32_t max_length,
                   int32_t min_new_tokens, const int32_t* forced, int32_t* sequences, int32_t* lengths,
                   int32_t* argmax_out);
+/* Deterministic half of generate_with_fallback (generation_whisper.py:970-1116, _need_fallback :1243-1287) at temperature 0:
+ * with both thresholds set, a window whose average token log-probability (log_softmax of the processed scores at the
+ * generated tokens, eos included, :1958-1974) is below logprob_threshold AND whose no-speech probability
+ * (WhisperNoSpeechDetection, logits_process.py:2050-2112: softmax of the raw logits at the <|startoftranscript|> position, token
+ * no_timestamps_token_id - 1) is above no_speech_threshold is skipped: seek advances by the window, no segment (:879-881).
+ * NaN = unset.  cw_transcribe applies them; stage-wise callers use cw_no_speech_probs before cw_decode and
+ * cw_get_avg_logprobs after it (token scores are tracked while a logprob threshold is set).  The stochastic half --
+ * re-decoding at higher temperatures -- is not implemented.                                                              */
+int32_t cw_set_thresholds(cw_ctx* ctx, float logprob_threshold, float no_speech_threshold);
+int32_t cw_no_speech_probs(cw_ctx* ctx, int32_t nb, int32_t sot_token, float* out /* [nb] */);
+int32_t cw_get_avg_logprobs(cw_ctx* ctx, float* out /* [nb] */, int32_t nb);
 int32_t cw_get_logits(cw_ctx* ctx, float* out /* [nb][vocab] */, int32_t nb);       /* last sampled step */
 int32_t cw_set_logits_capture(cw_ctx* ctx, float* host_buf, int32_t max_steps);    /* [steps][nb][vocab] */
 int32_t cw_get_alignment(cw_ctx* ctx, float* out /* [nb][n_align][L][1500] */, int32_t nb, int32_t L);

@@ -4,7 +4,7 @@ TAG=${1:-enc}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/enc_trace
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/enc_trace -o t --output-format csv -- python $R/bench.py --batch 8 --tokens 2 --steps 1 --warmup 1 --no-cpu-baseline --no-longform --no-rccl > $R/gpurun_out/enc_trace/log.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace -d $R/gpurun_out/enc_trace -o t --output-format csv -- python $R/bench.py --batch 8 --tokens 2 --steps 1 --warmup 1 --no-cpu-baseline --no-longform --no-config3 --no-rccl > $R/gpurun_out/enc_trace/log.txt 2>&1
 cd $R
 python - <<'P' | tee gpurun_out/enc_trace_$TAG.txt
 import csv, glob, collections

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of HIP runtime settings that could move the per-launch floor of the decode chain (one bench run per setting).
 export PYTHONUNBUFFERED=1
-ARGS="--batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-longform --no-rccl --kernel-iters 50"
+ARGS="--batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-longform --no-config3 --no-rccl --kernel-iters 50"
 run() { name=$1; shift; env "$@" timeout 300 python bench.py $ARGS > gpurun_out/env_$name.json 2> gpurun_out/env_$name.err; 
   python - <<P
 import json

@@ -10,6 +10,7 @@ import sys
 import tempfile
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -69,3 +70,36 @@ def test_two_rank_shard_and_gather_matches_single_process():
     assert [c["text"] for c in res[0]["chunks"]] == [c["text"] for c in gold["chunks"]]
     for a, b in zip(res[0]["chunks"], gold["chunks"]):
         assert np.allclose(a["timestamp"], b["timestamp"], atol=0.02 + 1e-9)
+
+
+def test_bench_gpus_flag_builds_a_launcher_command():
+    """`python bench.py --gpus N` outside a launcher re-runs itself as N ranks (bench.spawn_command): one process per GPU,
+    rendezvous on 127.0.0.1, every other argument passed through."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    cmd = bench.spawn_command(argparse.Namespace(gpus=4), argv, 29555)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-len(argv) - 1] == os.path.join(ROOT, "bench.py") and cmd[-len(argv):] == argv
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_spawns_two_ranks_and_reports_them():
+    """bench.py --gpus 2 with no launcher around it: two ranks (here sharing the one GPU of the box, collectives over gloo:
+    two RCCL ranks cannot share a device) -- the line must say n_gpus == 2 and the communicator must have seen 2 ranks."""
+    env = dict(os.environ, CW_DIST_BACKEND="gloo", PYTHONUNBUFFERED="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--geometry", "tiny", "--batch", "2",
+                        "--tokens", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--kernel-iters", "3"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["collective"]["ranks_seen"] == 2
+    assert rec["collective"]["chunks_per_rank"] == [2, 2] and rec["config"]["parallelism"] == "chunk-dp2"
+    assert rec["value"] > 0
