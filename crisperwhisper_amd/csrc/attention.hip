@@ -827,15 +827,15 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
 __device__ inline float row_ror8_add(float v) { return v + dpp_mov<0x128, 0xf>(0.f, v); }   // + lane ^ 8 (row_ror:8)
 // FUSED (NQ = 1, fused out-projection / query stage, decfuse.hip): the query is finished here,
 //     q = rstd(x1) (qa + qb - mean(x1) qw) + qbias,
-// by wave 0 alone (LayerNorm statistics of the residual row, wave-local) and handed to the other waves through LDS: every
-// wave-level load costs 16 clocks of the CU's address unit whatever it fetches -- all eight waves fetching the same row and
-// constants measured +3 us per launch.
+// see the FUSED block below (every wave-level 16 B-per-lane load costs 16 clocks of the CU's address unit whatever it fetches:
+// all eight waves fetching the residual row and 8 columns of each constant measured +3 us per launch; wave 0 alone + a block
+// barrier +1.3 us).
 template <typename T, int NQ, bool FUSED>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSplitParams p) {
     __shared__ float s_max[8 * NQ];
     __shared__ float red[8 * NQ * 64];
     __shared__ float red_l[8 * NQ];
-    __shared__ float s_q[64];
+    __shared__ float s_q[FUSED ? 8 * 64 : 1];
     // blockIdx.y = group of NQ consecutive query rows that share one K/V (NQ = kv_div: the hypotheses of one audio item under
     // beam search; NQ = 1: one row per block, K/V of item row / kv_div).  The K/V slice is read ONCE into registers and all
     // NQ queries go through the same three block barriers together: one block per row re-streamed the 64 KB slice from L2
@@ -850,12 +850,15 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
     const T* Kh = (const T*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
     const T* Vh = (const T*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
     constexpr int G = CROSS_THREADS / 8;                       // 64 key groups
-    // FUSED: wave 0 adds the per-block partial sums of the residual row that the producing GEMV left behind (decfuse.hip,
-    // StackSeg::pstats) -- two small loads instead of the row itself: at more than 64 VGPRs this kernel loses a block per CU
+    // FUSED: every wave finishes the query itself -- lane c takes column c of the head: two 8-byte loads of the per-block
+    // LayerNorm partial sums the producing GEMV left behind (decfuse.hip, StackSeg::pstats) and four 4-byte loads (256 B per
+    // wave instruction: a quarter of the address-unit time of a 16 B-per-lane load), a wave-local reduction, and a trip
+    // through a wave-private LDS row to hand each lane its 8 columns.  No block barrier, no wave waits for another one;
+    // the kernel stays at 64 VGPRs (one more costs a resident block per CU).
     float2 pt0 = make_float2(0.f, 0.f), pt1 = pt0;
     float qa1 = 0.f, qb1 = 0.f, qw1 = 0.f, qc1 = 0.f;
-    if (FUSED && wave == 0) {                                   // wave-uniform; requested ahead of the K/V stream: loads only --
-        const int Dm = p.H * 64;                                // using a value in here makes hipcc wait before the K/V loads go out
+    if (FUSED) {                                                // loads only: using a value in here makes hipcc wait before the K/V loads go out
+        const int Dm = p.H * 64;
         pt0 = *(const float2*)(p.pstats + ((size_t)min(lane, p.n_pstats - 1) * 8 + b0) * 2);
         pt1 = *(const float2*)(p.pstats + ((size_t)min(lane + 64, p.n_pstats - 1) * 8 + b0) * 2);
         const size_t col = (size_t)h * 64 + lane;
@@ -867,20 +870,22 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
     for (int u = 0; u < 4; ++u) kr[u].ld(Kh + (size_t)min(grp + u * G, nk - 1) * 64);   // unconditional, clamped
 #pragma unroll
     for (int u = 0; u < 4; ++u) vr[u].ld(Vh + (size_t)min(grp + u * G, nk - 1) * 64);
+    if (FUSED) __builtin_amdgcn_sched_barrier(0);              // every load is out before the first wait (hipcc otherwise holds two V loads back)
     float qv[NQ][8];
     if (FUSED) {
-        if (wave == 0) {
-            const float inv_d = 1.0f / (float)(p.H * 64);
-            const float ps1 = (lane < p.n_pstats ? pt0.x : 0.f) + (lane + 64 < p.n_pstats ? pt1.x : 0.f);
-            const float ps2 = (lane < p.n_pstats ? pt0.y : 0.f) + (lane + 64 < p.n_pstats ? pt1.y : 0.f);
-            const float mean = wave_sum(ps1) * inv_d;
-            const float var = fmaxf(wave_sum(ps2) * inv_d - mean * mean, 0.f);
-            const float rstd = 1.0f / sqrtf(var + 1e-5f);
-            s_q[lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
-        }
-        __syncthreads();
+        const float inv_d = 1.0f / (float)(p.H * 64);
+        const float ps1 = (lane < p.n_pstats ? pt0.x : 0.f) + (lane + 64 < p.n_pstats ? pt1.x : 0.f);
+        const float ps2 = (lane < p.n_pstats ? pt0.y : 0.f) + (lane + 64 < p.n_pstats ? pt1.y : 0.f);
+        const float mean = wave_sum(ps1) * inv_d;
+        const float var = fmaxf(wave_sum(ps2) * inv_d - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        float* sq = s_q + wave * 64;                             // wave-private: ordered by the wave's own lgkmcnt
+        sq[lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qv[0][e] = s_q[sub * 8 + e];
+        for (int e = 0; e < 8; ++e) qv[0][e] = sq[sub * 8 + e];
     } else {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) Row8<float>::ld(p.q + (size_t)(b0 + q) * p.H * 64 + h * 64 + sub * 8, qv[q]);

@@ -488,4 +488,210 @@ int cw_launch_gemv_fc2x(const Fc2xParams& p, hipStream_t st) {
     return CW_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// mlp_pair_kernel: LN + fc1 + GELU, group barrier, fc2 + residual in one launch (grid F / 32, 256 threads; every block must be
+// resident at once: F / 32 <= CUs).  Block p computes fc1 columns [32 p, 32 p + 32) -- they lie in K slice kq = p / (D / 32) of
+// fc2 -- writes them as 16-bit values with agent-scope (write-through) stores and arrives at its group's barrier; once the
+// D / 32 blocks of the group are in, the slice mid[:, kq D .. (kq + 1) D) is complete and block p continues as fc2 block
+// (column pair p % (D / 32), K slice kq) exactly like gemv2's K-split launch.  fc2's 80 KB of weights per block are requested at
+// kernel entry, behind fc1's: they stream while fc1 computes and the group gathers, which is what a second launch cannot do.
+// The barrier is a sense-reversing arrival counter per group (reusable without re-initialisation: graph replays carry no
+// per-launch arguments); spins are bounded and report through p.err instead of hanging.
+// MEASURED AND REJECTED (round 3, MI355X, B = 8, profiles/r03_c_*): 23.3 us per launch against 6.5 + 6.2 us for the two launches
+// it replaces -- correct (parity tests green), but an arrival barrier among 40 blocks spread over 8 XCDs, the write-through
+// hand-over of the 20 KB slice and its agent-scope re-read cost more than a kernel boundary (~2 us) does.  Kept behind
+// CW_MLP_PAIR=1 as the A/B for "replace a boundary by an in-kernel barrier"; the decode step does not use it.
+// ---------------------------------------------------------------------------------------------------
+#define MLP_SPIN_LIMIT 400000
+template <int NSLOT, int PER_LANE>
+__global__ __launch_bounds__(256) void mlp_pair_kernel(MlpPairParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_m[];
+    __shared__ int s_ok;
+    constexpr int NT = 2, RPW = 2;
+    const int D = p.D, F = p.F, Mb = p.Mb;
+    const int xs_stride = D + 8;
+    bf16_t* xs = (bf16_t*)smem_m;                               // [16][D+8]: LayerNorm(x) for fc1, then the mid slice for fc2
+    float* red = (float*)(smem_m + (size_t)16 * xs_stride * 2);  // [4 waves][NT][4][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int per_group = D / 32;
+    const int kq = blockIdx.x / per_group, gi = blockIdx.x - kq * per_group;
+    const int steps = D >> 7, nvec = D >> 2;
+    const bf16_t* __restrict__ W1 = (const bf16_t*)p.W1;
+    const bf16_t* __restrict__ W2 = (const bf16_t*)p.W2;
+    const int n1 = blockIdx.x * 32;                              // fc1 columns of this block
+    const int n2 = gi * 32;                                      // fc2 columns
+    const int kbase = kq * D;                                    // fc2 K slice
+
+    float b1v[NT], b2v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { b1v[t] = p.b1[n1 + t * 16 + l15]; b2v[t] = p.b2[n2 + t * 16 + l15]; }
+    float4 xv[RPW][PER_LANE];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int row = min(wave + 4 * i, Mb - 1);
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) xv[i][c] = *(const float4*)(p.x + (size_t)row * D + (size_t)min(lane + 64 * c, nvec - 1) * 4);
+    }
+    u32x4_t w1q[NT][NSLOT][4], w2q[NT][NSLOT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bf16_t* wrow = W1 + (size_t)(n1 + t * 16 + l15) * D + g * 8;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const u32x4_t* wp = (const u32x4_t*)(wrow + min(wave + 4 * s, steps - 1) * 128);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w1q[t][s][j] = wp[j * 4];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bf16_t* wrow = W2 + (size_t)(n2 + t * 16 + l15) * F + kbase + g * 8;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const u32x4_t* wp = (const u32x4_t*)(wrow + min(wave + 4 * s, steps - 1) * 128);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w2q[t][s][j] = wp[j * 4];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                          // every load is out before the first wait
+    // ---- fc1: wave-local LayerNorm (gamma / beta folded into W1 / b1), rows -> 16 bit -> LDS
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        float sx = 0.f;
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) {
+            const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+            sx += ok * ((xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w));
+        }
+        const float mean = wave_sum(sx) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) {
+            const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+            const float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
+            sq += ok * ((a * a + b * b) + (cc * cc + d * d));
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
+        const int row = wave + 4 * i;
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) {
+            const int v4 = min(lane + 64 * c, nvec - 1);
+            ushort4 o;
+            o.x = f32_to_bf16((xv[i][c].x - mean) * rstd); o.y = f32_to_bf16((xv[i][c].y - mean) * rstd);
+            o.z = f32_to_bf16((xv[i][c].z - mean) * rstd); o.w = f32_to_bf16((xv[i][c].w - mean) * rstd);
+            *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
+        }
+    }
+    __syncthreads();
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int step = wave + 4 * s;
+        if (step < steps) {
+            const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma16x(a, __builtin_bit_cast(bf16x8_t, w1q[t][s][j]), acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    bf16_t* mid = (bf16_t*)p.mid;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int r = tid >> 6;
+        const float v = red[((0 * NT + t) * 4 + r) * 64 + lane] + red[((1 * NT + t) * 4 + r) * 64 + lane] +
+                        red[((2 * NT + t) * 4 + r) * 64 + lane] + red[((3 * NT + t) * 4 + r) * 64 + lane];
+        const unsigned int h = f32_to_bf16(gelu_erf(v + b1v[t]));
+        const unsigned int other = (unsigned int)__shfl_xor((int)h, 1, 64);        // neighbouring column
+        const int m = g * 4 + r, n = n1 + t * 16 + l15;
+        if (m < Mb && !(l15 & 1))                               // two columns per 4-byte write-through store
+            __hip_atomic_store((unsigned int*)(mid + (size_t)m * F + n), h | (other << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- group barrier: the stores above have completed (and so have the fc2 weight loads) before the block arrives
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int* cnt = p.bar + 2 * kq;
+        unsigned int* gen = p.bar + 2 * kq + 1;
+        const unsigned int g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        if (ticket == (unsigned int)per_group - 1) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gen, g0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int it = 0;
+            while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++it > MLP_SPIN_LIMIT) { ok = 0; break; }
+            }
+        }
+        if (!ok) *p.err = 1;
+        s_ok = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // ---- fc2: the group's mid slice [Mb][D] -> LDS (agent-scope loads: written by blocks on other XCDs)
+    {
+        const unsigned long long* src = (const unsigned long long*)mid;
+        const int n8 = D >> 2;                                   // 8-byte words per row of the slice
+        for (int idx = tid; idx < 8 * n8; idx += 256) {
+            const int row = idx / n8, w = idx - row * n8;
+            const int rc = row < Mb ? row : Mb - 1;
+            const unsigned long long v = __hip_atomic_load((unsigned long long*)src + ((size_t)rc * F + kbase) / 4 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *(unsigned long long*)(xs + (size_t)row * xs_stride + w * 4) = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int step = wave + 4 * s;
+        if (step < steps) {
+            const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma16x(a, __builtin_bit_cast(bf16x8_t, w2q[t][s][j]), acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int r = tid >> 6;
+        const float v = red[((0 * NT + t) * 4 + r) * 64 + lane] + red[((1 * NT + t) * 4 + r) * 64 + lane] +
+                        red[((2 * NT + t) * 4 + r) * 64 + lane] + red[((3 * NT + t) * 4 + r) * 64 + lane];
+        const int m = g * 4 + r, n = n2 + t * 16 + l15;
+        if (m < Mb) atomicAdd(p.x + (size_t)m * D + n, resid_grid(v + (kq == 0 ? b2v[t] : 0.f)));
+    }
+}
+
+int cw_launch_mlp_pair(const MlpPairParams& p, hipStream_t st) {
+    if (p.Mb < 1 || p.Mb > 8 || p.D % 128 || p.D > 1280 || p.F % p.D || p.F / 32 > 256 || !p.bar || !p.err || !p.mid) return CW_ERR_INVALID;
+    const size_t lds = (size_t)16 * (p.D + 8) * 2 + (size_t)4 * 2 * 4 * 64 * 4;
+    const dim3 grid(p.F / 32);
+    if (p.D <= 256) hipLaunchKernelGGL((mlp_pair_kernel<1, 1>), grid, dim3(256), lds, st, p);
+    else if (p.D <= 768) hipLaunchKernelGGL((mlp_pair_kernel<2, 3>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((mlp_pair_kernel<3, 5>), grid, dim3(256), lds, st, p);
+    return CW_OK;
+}
+
 }  // namespace CW_NS

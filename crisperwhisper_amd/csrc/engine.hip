@@ -63,6 +63,8 @@ struct cw_ctx {
     bool fuse6_ready = false;       // product matrices of the fused decoder stages are in place
     bool fuse6_enabled = true;      // CW_NO_FUSE6=1: eight launches per layer (A/B)
     bool fuse_mlp = false;          // CW_FUSE_MLP=1: also fuse cross out-projection + fc1 (six launches; measured slower, A/B)
+    bool mlp_pair = false;          // CW_MLP_PAIR=1: fc1 + fc2 in one launch with an in-kernel group barrier (A/B: 23 us against 12.8 for two launches)
+    unsigned int* d_bar = nullptr; int* d_err = nullptr;   // group barriers of mlp_pair_kernel; "a block gave up waiting" flag
     int stack_nt3 = 0, stack_nt5 = 0;   // column tiles per block of the two stacked GEMVs (0 = launcher's choice; CW_STACK_NT3/5)
     bool ln_folded = false;         // decoder LN-GEMVs run plain normalisation (affine part is inside W / bias)
     bool fold_enabled = true;       // CW_NO_LN_FOLD=1: keep gamma / beta in the kernels
@@ -267,6 +269,7 @@ static int create_impl(cw_ctx* c) {
     if (getenv("CW_NO_LN_FOLD")) c->fold_enabled = false;
     if (getenv("CW_NO_FUSE6")) c->fuse6_enabled = false;
     if (getenv("CW_FUSE_MLP")) c->fuse_mlp = true;
+    if (getenv("CW_MLP_PAIR")) c->mlp_pair = true;
     if (getenv("CW_STACK_NT3")) c->stack_nt3 = atoi(getenv("CW_STACK_NT3"));
     if (getenv("CW_STACK_NT5")) c->stack_nt5 = atoi(getenv("CW_STACK_NT5"));
     c->esz = c->bf16 ? 2 : 4;
@@ -396,6 +399,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->dx1, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dx2c, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->d_qa, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->d_qb, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->d_u1, (size_t)Bm * F * 4)); CWCHK(c, dmalloc(c, &c->d_pstats, (size_t)128 * 8 * 2 * 4));
+    CWCHK(c, dmalloc(c, &c->d_bar, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_err, 4));
     CWCHK(c, dmalloc(c, &c->d_xfrag, (size_t)64 * 5120 * 2));
     CWCHK(c, dmalloc(c, &c->d_xfrag2, (size_t)64 * 5120 * 2));
     c->Vpad = (V + 3) & ~3;
@@ -889,13 +893,19 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                     CombineParams cb{c->d_part_ml, H, nb * D};
                     CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
                 }
-                {
-                    EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
-                    CWCHK(c, gemv_ln(c, EPI_GELU_F32, xalt, nb, D, L.w1, F, L.ln2_g, nullptr, ep));
-                }
-                {
-                    EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.b2; ep.ldo = D;
-                    CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
+                if (c->mlp_pair && F % D == 0 && D % 32 == 0 && F / 32 <= 256 && F / D <= 32) {
+                    // LN + fc1 + GELU, group barrier, fc2 + residual in one launch (decfuse.hip: mlp_pair_kernel)
+                    MlpPairParams mp{xalt, L.w1, L.b1, L.w2, L.b2, c->d_xfrag2, c->d_bar, c->d_err, nb, D, F};
+                    CWCHK(c, KD(c, cw_launch_mlp_pair, mp, c->st));
+                } else {
+                    {
+                        EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
+                        CWCHK(c, gemv_ln(c, EPI_GELU_F32, xalt, nb, D, L.w1, F, L.ln2_g, nullptr, ep));
+                    }
+                    {
+                        EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.b2; ep.ldo = D;
+                        CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
+                    }
                 }
                 float* t = xin; xin = xalt; xalt = t;
                 continue;
@@ -1077,6 +1087,11 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
+    {   // a block of a launch with an in-kernel barrier gave up waiting (never expected: all of its blocks are co-resident)
+        int e = 0;
+        HIPCHK(c, hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
+        if (e) { hipMemset(c->d_err, 0, 4); hipMemset(c->d_bar, 0, 64 * 4); return fail(c, CW_ERR_HIP, "decode: an in-kernel group barrier timed out"); }
+    }
     if (first_copied >= 0)                 // true end = first step after which no row was running
         for (int s2 = first_copied; s2 < step; ++s2)
             if (c->h_nunf[s2] == 0) { t = n_prompt + s2 + 1; break; }
@@ -1734,6 +1749,7 @@ int32_t cw_test_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "gemm256_min_tiles")) { cw_bf16::cw_gemm_set_256_min_tiles(value); cw_f16::cw_gemm_set_256_min_tiles(value); return CW_OK; }
     if (!strcmp(name, "beam_topk_1block")) { cw_bf16::cw_beam_topk_set_1block(value); cw_f16::cw_beam_topk_set_1block(value); return CW_OK; }
     if (!strcmp(name, "gemm_pp")) { cw_bf16::cw_gemm_set_pp(value); cw_f16::cw_gemm_set_pp(value); return CW_OK; }
+    if (!strcmp(name, "gemm_8ph")) { cw_bf16::cw_gemm_set_8ph(value); cw_f16::cw_gemm_set_8ph(value); return CW_OK; }
     return CW_ERR_INVALID;
 }
 

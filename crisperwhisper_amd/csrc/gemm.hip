@@ -585,6 +585,192 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Quarter-tile ("8-phase") flavour of the same 256x256x64 LDS-DMA GEMM (round 3).  The ping-pong kernel above ends every
+// phase with `s_waitcnt vmcnt(0)`: the DMA pieces a group issued in a phase must have landed before that phase's barrier, so
+// a K-tile costs two memory round trips however few cycles its 64 MFMAs take (MFMA pipe busy 0.33-0.35).  Here
+//   * the operand tiles are handled as four HALF tiles (A rows 0-127 / 128-255, W rows 0-127 / 128-255 of the K-tile, 16 KB
+//     each) and a wave's 128 x 64 output is two 64-row x two 32-column pieces, one from each half, so that its four
+//     quadrants touch the half tiles at different times:
+//         phase 1: read A_h0 (8 ds_read_b128) + W_h0 (4)   -> 16 MFMAs, quadrant (0,0)
+//         phase 2: read W_h1 (4)                            -> 16 MFMAs, quadrant (0,1)
+//         phase 3: read A_h1 (8)                            -> 16 MFMAs, quadrant (1,1)
+//         phase 4: (W_h0 fragments kept from phase 1)       -> 16 MFMAs, quadrant (1,0)
+//   * every phase also issues the DMA of ONE half tile (2 x buffer_load ... lds per lane): W_h0, W_h1, A_h1 of the next
+//     K-tile in phases 1-3 and A_h0 of the tile after next in phase 4 -- each into a half-tile slot whose last ds_read was
+//     issued at least three phases earlier;
+//   * the only wait on DMA is a COUNTED one, `s_waitcnt vmcnt(6)`: three half tiles stay in flight, a half tile is read
+//     four phases (five for A_h0) after it was requested and never in the phase whose wait retired it;
+//   * the two wave rows (wr = wave >> 2, which share the SIMDs pairwise) run one barrier apart: one does its 16 MFMAs while
+//     the other reads fragments and issues DMA.
+// Same LDS image, swizzle, epilogue and per-element summation order as the other 256-tile kernels (bit-identical results).
+// ---------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const bf16_t* __restrict__ A, int lda,
+                                                            const bf16_t* __restrict__ W, int M, int N, int K,
+                                                            EpiParams ep, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm4[];   // [2][A 32 KB | W 32 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int mt_, nt_;
+    grouped_tile(tile, gridDim.x / tiles_n, tiles_n, mt_, nt_);
+    const int m0 = mt_ * BM2, n0 = nt_ * BN2;
+
+    // DMA map of a half tile (128 rows x 128 B): wave w, load q: rows w*16 + q*8 .. +7, lane -> (row lane >> 3, 16 B chunk
+    // (lane & 7) ^ row): 1 KB per wave instruction, chunk-swizzled on the SOURCE side so the LDS image is lane-linear
+    const int lrow = lane >> 3;
+    const int csrc = ((lane & 7) ^ lrow) * 8;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    int va[2][2];                                                // rows beyond M clamped: they feed output rows that are never stored
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) va[h][q] = (min(m0 + h * 128 + wave * 16 + q * 8 + lrow, M - 1) * lda + csrc) * 2;
+    const int vw = ((n0 + wave * 16 + lrow) * K + csrc) * 2;
+    auto issue_a = [&](int k0, int buf, int h) {
+        unsigned char* base = gsm4 + buf * 65536 + (h * 128 + wave * 16) * 128;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, va[h][q], k0 * 2, 0, 0);
+    };
+    auto issue_w = [&](int k0, int buf, int h) {
+        unsigned char* base = gsm4 + buf * 65536 + 32768 + (h * 128 + wave * 16) * 128;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, vw,
+                                                     (k0 + (h * 128 + q * 8) * K) * 2, 0, 0);
+    };
+    // fragment offsets (chunk XOR by row & 7 == l15 & 7): A half h: rows h*128 + wr*64 + i*16 + l15; W half h: rows h*128 + wn*32 + j*16 + l15
+    const int sw = l15 & 7;
+    const int aoff = (wr * 64 + l15) * 128, woff = 32768 + (wn * 32 + l15) * 128;
+    bf16x8_t fa[2][4], fw[2][2][2];                             // fw[column half]: the W_h0 fragments serve phases 1 and 4
+    auto read_a = [&](int buf, int h) {
+        const unsigned char* sb = gsm4 + buf * 65536 + aoff + h * 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = ((kk * 4 + g) ^ sw) << 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[kk][i] = *(const bf16x8_t*)(sb + i * 2048 + c);
+        }
+    };
+    auto read_w = [&](int buf, int h) {
+        const unsigned char* sb = gsm4 + buf * 65536 + woff + h * 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = ((kk * 4 + g) ^ sw) << 4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fw[h][kk][j] = *(const bf16x8_t*)(sb + j * 2048 + c);
+        }
+    };
+    f32x4_t acc[2][4][4];                                        // [row half][i][column half * 2 + j]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // second half of a phase: the reads above have returned, 16 MFMAs on quadrant (hm, hn), closing barrier
+#define CW_8PH_COMPUTE(hm, hn)                                                                              \
+    do {                                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+                    acc[hm][i][(hn) * 2 + j] = mfma16(fw[hn][kk][j], fa[kk][i], acc[hm][i][(hn) * 2 + j]); \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+    } while (0)
+    // counted wait on the LDS-DMA: three half tiles (6 loads) may stay in flight; once fewer are being issued (the last two
+    // K-tiles) everything is drained instead
+#define CW_8PH_WAIT(steady)                                                                                 \
+    do {                                                                                                    \
+        if (steady) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                        \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+    } while (0)
+
+    const int nk = K / BK;
+    // prologue: K-tile 0 complete, A_h0 of K-tile 1
+    issue_a(0, 0, 0); issue_w(0, 0, 0); issue_w(0, 0, 1); issue_a(0, 0, 1);
+    if (nk > 1) issue_a(BK, 1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                   // the lower wave row runs one barrier behind
+    for (int t = 0; t < nk; ++t) {
+        const int b = t & 1, nb = b ^ 1;
+        const bool nxt = t + 1 < nk, nxt2 = t + 2 < nk;
+        const bool steady = t + 2 < nk;                          // all four phases of this tile issue a half tile
+        const int k1 = (t + 1) * BK, k2 = (t + 2) * BK;
+        // phase 1
+        read_w(b, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(b, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt) issue_w(k1, nb, 0);
+        CW_8PH_WAIT(steady);
+        CW_8PH_COMPUTE(0, 0);
+        // phase 2
+        read_w(b, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt) issue_w(k1, nb, 1);
+        CW_8PH_WAIT(steady);
+        CW_8PH_COMPUTE(0, 1);
+        // phase 3
+        read_a(b, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt) issue_a(k1, nb, 1);
+        CW_8PH_WAIT(steady);
+        CW_8PH_COMPUTE(1, 1);
+        // phase 4
+        if (nxt2) issue_a(k2, b, 0);
+        CW_8PH_WAIT(steady);
+        CW_8PH_COMPUTE(1, 0);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();                   // every wave executes the same number of barriers
+#undef CW_8PH_COMPUTE
+#undef CW_8PH_WAIT
+
+    const bool vec_ok = (EPI == EPI_HEADS || (ep.ldo & 3) == 0);
+    int cols[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cols[j] = n0 + (j >> 1) * 128 + wn * 32 + (j & 1) * 16 + g * 4;
+    if (m0 + BM2 <= M && vec_ok) {   // interior tile (block-uniform)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int rows[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rows[i] = m0 + h * 128 + wr * 64 + i * 16 + l15;
+            epi_tile_interior<bf16_t, EPI>(ep, rows, cols, acc[h]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + h * 128 + wr * 64 + i * 16 + l15;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = cols[j];
+                if (vec_ok) {
+                    epi_store4<bf16_t, EPI>(ep, m, n, acc[h][i][j][0], acc[h][i][j][1], acc[h][i][j][2], acc[h][i][j][3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) epi_store1<bf16_t, EPI>(ep, m, n + r, acc[h][i][j][r]);
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // OCP e4m3 flavour of the ping-pong GEMM (opt-in encoder mode, BASELINE configs[3]): C[M,N] = (A8 * W8^T) * sa[m] * sw[n].
 // A and W hold one byte per element with one f32 scale per row (quant_rows_fp8_kernel / layernorm_fp8_kernel); the MFMA is
 // v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (e8m0 127) -- on gfx950 the only fp8 form that runs at twice the
@@ -1358,7 +1544,9 @@ static bool g_use_256 = true;   // CW_NO_GEMM256=1: keep the 128x128 tiles every
 static int g_256_min_tiles = 200;
 static int g_use_pp = -1;   // ping-pong schedule for the plain-A 256-tile shapes; -1: from the environment (CW_NO_GEMM_PP)
 void cw_gemm_set_256_min_tiles(int n) { g_256_min_tiles = n; }
+static int g_use_8ph = -1;  // quarter-tile (8-phase) schedule instead of ping-pong; -1: from the environment (CW_NO_GEMM_8PH)
 void cw_gemm_set_pp(int on) { g_use_pp = on; }
+void cw_gemm_set_8ph(int on) { g_use_8ph = on; }
 
 template <int EPI>
 static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
@@ -1376,7 +1564,15 @@ static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, 
         const int tm2 = (M + BM2 - 1) / BM2, tn2 = (N + BN2 - 1) / BN2;
         if (g_use_pp < 0) g_use_pp = getenv("CW_NO_GEMM_PP") == nullptr;
         const bool use_pp = g_use_pp != 0;
-        if (g_use_glds && g_zero_page && g_use_256 && use_pp && tm2 * tn2 >= g_256_min_tiles && ap.amode == 0 && N % BN2 == 0) {
+        if (g_use_8ph < 0) g_use_8ph = getenv("CW_NO_GEMM_8PH") == nullptr;
+        if (g_use_glds && g_zero_page && g_use_256 && use_pp && g_use_8ph && tm2 * tn2 >= g_256_min_tiles && ap.amode == 0 && N % BN2 == 0) {
+            static std::once_flag attr_8;
+            std::call_once(attr_8, [] {
+                hipFuncSetAttribute((const void*)gemm_bf16_8ph_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            });
+            hipLaunchKernelGGL((gemm_bf16_8ph_kernel<EPI>), dim3(tm2 * tn2), dim3(512), 131072, st, (const bf16_t*)ap.A, ap.lda,
+                               (const bf16_t*)W, M, N, K, ep, tn2);
+        } else if (g_use_glds && g_zero_page && g_use_256 && use_pp && tm2 * tn2 >= g_256_min_tiles && ap.amode == 0 && N % BN2 == 0) {
             static std::once_flag attr_pp;
             std::call_once(attr_pp, [] {
                 hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);

@@ -148,6 +148,21 @@ struct Fc2xParams {
     int Mb, D, F;
 };
 
+// decfuse.hip: fc1 -> GELU -> fc2 in ONE launch.  The F / 32 blocks form F / D independent groups of D / 32 blocks (a group =
+// the fc1 columns of one d_model-wide K slice of fc2 = the blocks that then share that slice); inside a group the blocks meet
+// at a reusable arrival barrier between the two GEMVs, and fc2's weights are requested before the barrier.
+struct MlpPairParams {
+    float* x;              // [Mb][D] residual stream: LayerNorm input of fc1, accumulated into by fc2 (f32 atomics, 2^-12 grid)
+    const void* W1;        // [F][D] 16-bit, LayerNorm gamma folded in
+    const float* b1;       // [F]
+    const void* W2;        // [D][F]
+    const float* b2;       // [D]
+    void* mid;             // [8][F] 16-bit scratch (GELU output), handed over inside the launch
+    unsigned int* bar;     // [2 * F / D]: arrival counter and generation of every group (zero-initialised, reusable)
+    int* err;              // set to 1 when a block gave up waiting at the barrier (never expected; results are then invalid)
+    int Mb, D, F;
+};
+
 // mel.hip
 struct MelTables {
     const double* cos_t;  // [400]
@@ -164,6 +179,7 @@ struct MelTables {
     int cw_launch_gemm(bool bf16, int epi, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep, hipStream_t st); \
     void cw_gemm_set_256_min_tiles(int n); \
     void cw_gemm_set_pp(int on); \
+    void cw_gemm_set_8ph(int on); \
     int cw_launch_layernorm_fp8(const float* x, const float* g, const float* b, void* out8, float* scale, int rows, int d, hipStream_t st); \
     int cw_launch_quant_rows_fp8(const void* x, int rows, int K, void* out8, float* scale, hipStream_t st); \
     int cw_launch_gemm_fp8(int epi, const void* A8, int lda, const void* W8, int M, int N, int K, const float* sa, const float* sw, const EpiParams& ep, hipStream_t st); \
@@ -173,6 +189,7 @@ struct MelTables {
     int cw_launch_fold_rowvec(const float* A, const float* s, float scale, const float* v, const void* W16, int N, int J, float* c_out, float* w_out, hipStream_t st); \
     int cw_launch_gemv_stack(const StackParams& p, int nt, hipStream_t st); \
     int cw_launch_gemv_fc2x(const Fc2xParams& p, hipStream_t st); \
+    int cw_launch_mlp_pair(const MlpPairParams& p, hipStream_t st); \
     int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d, hipStream_t st); \
     int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d, hipStream_t st); \
     int cw_launch_sample(const SampleParams& p, hipStream_t st); \

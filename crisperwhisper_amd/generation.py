@@ -286,6 +286,8 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
     elif logprob_threshold is not None:
         raise ValueError("this engine does not implement logprob_threshold / no_speech_threshold")
     skip_on = logprob_threshold is not None and no_speech_threshold is not None
+    if skip_on and num_beams is not None and int(num_beams) > 1:
+        raise ValueError("logprob_threshold / no_speech_threshold are implemented for greedy decoding only (num_beams=1)")
     num_beams = 1 if num_beams is None else int(num_beams)
     if num_beams < 1:
         raise ValueError(f"`num_beams` has to be an integer strictly greater than 0, but is {num_beams}")
@@ -345,7 +347,7 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
         max_length = (n_prompt + max_new_tokens) if max_new_tokens is not None else min(spec.max_length, spec.max_target_positions)
         nsp = engine.no_speech_probs(len(active), spec.decoder_start_token_id) if skip_on else None
         if num_beams > 1:
-            bs, _, L, alp = beam_search(engine, init[active], max_length, min_new_tokens or 0, num_beams)   # sequences_scores (:1262-1263)
+            bs, _, L, alp = beam_search(engine, init[active], max_length, min_new_tokens or 0, num_beams)
             total = bs.shape[1]
             seqs = np.full((len(active), spec.max_target_positions), spec.pad_token_id, dtype=np.int64)
             seqs[:, :total] = bs

@@ -241,6 +241,9 @@ def _check_generate_kwargs(gk: Dict[str, Any]) -> None:
         raise ValueError("generate_kwargs['return_timestamps'] must be left to the pipeline argument of the same name")
     if gk.get("no_speech_threshold") is not None and gk.get("logprob_threshold") is None:
         raise ValueError("no_speech_threshold needs logprob_threshold as well (generation_whisper.py:1275-1285 compares both)")
+    if thresholds and gk.get("num_beams") not in (None, 1) and any(k in thresholds for k in ("logprob_threshold", "no_speech_threshold")):
+        raise ValueError("logprob_threshold / no_speech_threshold are implemented for greedy decoding only (num_beams=1): "
+                         "transformers scores beam hypotheses differently again and that path is not reproduced")
     if gk.get("logprob_threshold") is not None and gk.get("temperature") is None:
         raise ValueError("logprob_threshold needs an explicit temperature (pass temperature=0.0): transformers itself fails with "
                          "a TypeError in _retrieve_avg_logprobs otherwise (generation_whisper.py:1959)")

@@ -7,8 +7,10 @@ Follows:
     torchaudio is a third-party dependency of the reference (REF/requirements.txt, unpinned) and is NOT installed in
     this image, so this file restates its published algorithm (``_get_sinc_resample_kernel`` /
     ``_apply_sinc_resample_kernel``, torchaudio 2.x functional.py) -- **parity unpinned**: no torchaudio output is
-    available offline to pin it; the tests anchor it on analytic properties instead (identity, length formula,
-    in-band sinusoids keep amplitude and phase, out-of-band ones are rejected).
+    available offline to pin it; the tests anchor it on analytic properties (identity, length formula, in-band sinusoids
+    keep amplitude and phase, out-of-band ones are rejected) and, round 3, on the published closed-form kernel evaluated
+    sample by sample in f64 by a route that shares no code with this file
+    (tests/test_audio_ingest.py::test_resampler_equals_the_closed_form_kernel_by_direct_convolution).
   * the sample decoding of ``ffmpeg -ac 1 -f f32le`` (TF/pipelines/audio_utils.py:9-45): integer PCM scaled to
     [-1, 1), channels averaged.
   * REF/app.py:85-93: ``(y - mean) / std / 8``.

@@ -11,9 +11,10 @@ from crisperwhisper_amd.engine import Engine
 g, v, W, spec = Hh.tiny_setup()
 e = Engine(spec, dtype="bf16", max_batch=4)
 rng = np.random.default_rng(0)
-for pp in (0, 1):
+for pp, ph8 in ((0, 0), (1, 0), (1, 1)):
     e.lib.cw_test_set_option(b"gemm_pp", pp)
-    sys.stderr.write(f"== ping-pong {pp}\n")
+    e.lib.cw_test_set_option(b"gemm_8ph", ph8)
+    sys.stderr.write(f"== ping-pong {pp} 8-phase {ph8}\n")
     for (M, N, K, gelu) in [(12000, 3840, 1280, False), (12000, 1280, 1280, False), (12000, 5120, 1280, True), (12000, 1280, 5120, False)]:
         A = rng.standard_normal((M, K)).astype(np.float32)
         Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)

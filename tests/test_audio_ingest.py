@@ -348,3 +348,45 @@ def test_gpu_flac_path_equals_wav_path(eng, tmp_path):
     data = FW.write_stream(c24, 24, 16000, [dict(n=4096, plans=[dict(kind="fixed", order=3, method=1, porder=2)])] * 2)
     got = audio.decode_wav_bytes(data, 16000, eng)
     assert np.array_equal(got, (c24[0].astype(np.float64) / (1 << 23)).astype(np.float32))
+
+
+@pytest.mark.parametrize("sr_in,sr_out", [(44100, 16000), (48000, 16000), (22050, 16000), (8000, 16000), (11025, 16000), (16000, 44100)])
+def test_resampler_equals_the_closed_form_kernel_by_direct_convolution(sr_in, sr_out):
+    """Independent route to the same numbers (no torchaudio exists offline, so the oracle stays "parity unpinned" against its
+    OUTPUT; this pins it against its published DEFINITION): torchaudio's sinc_interp_hann resampler is, for every output sample m at
+    input time tau = m * orig / new,
+        y[m] = sum_n x[n] * (f0 / orig) * sinc(pi f0 (n - tau) / orig) * cos^2(pi f0 (n - tau) / (2 L orig)),   |f0 (n - tau) / orig| <= L,
+    f0 = min(orig, new) * rolloff, L = lowpass_filter_width = 6 (functional.py: _get_sinc_resample_kernel /
+    _apply_sinc_resample_kernel).  Evaluated here sample by sample in f64 from that formula -- no polyphase table, no strided
+    convolution, no shared code with oracle/audio.py -- on random audio, and compared with the oracle's table-driven result."""
+    import math
+    from oracle import audio as OA
+    rng = np.random.default_rng(sr_in + sr_out)
+    n = 3000
+    x = rng.standard_normal(n).astype(np.float32)
+    g = math.gcd(sr_in, sr_out)
+    orig, new = sr_in // g, sr_out // g
+    f0 = min(orig, new) * 0.99
+    L = 6.0
+    n_out = -(-(n * new) // orig)
+    width = math.ceil(L * orig / f0)                     # support in input samples (torchaudio zero-pads this many on both sides)
+    y = np.zeros(n_out, np.float64)
+    nn = np.arange(-width - 1, n + width + orig + 1, dtype=np.float64)
+    xx = np.zeros(len(nn), np.float64)
+    xx[width + 1: width + 1 + n] = x.astype(np.float64)
+    for m in range(n_out):
+        tau = m * orig / new
+        # torchaudio evaluates the kernel on the integer grid idx in [-width, width + orig) around frame i = m // new:
+        # taps cover input samples i*orig - width .. i*orig + width + orig - 1; the clamp makes the window zero outside |t| <= L
+        i = m // new
+        lo, hi = i * orig - width, i * orig + width + orig
+        sel = (nn >= lo) & (nn < hi)
+        t = (nn[sel] - tau) * f0 / orig
+        tc = np.clip(t, -L, L)
+        w = np.cos(tc * math.pi / L / 2.0) ** 2
+        s = np.where(tc == 0.0, 1.0, np.sin(tc * math.pi) / np.where(tc == 0.0, 1.0, tc * math.pi))
+        y[m] = float(np.sum(xx[sel] * s * w)) * f0 / orig
+    got = OA.resample(x, sr_in, sr_out).astype(np.float64)
+    assert len(got) == n_out
+    # the oracle rounds its taps to f32 once (torchaudio's dtype=None branch): 6e-8 relative per tap
+    assert np.abs(got - y).max() <= 2e-6 * max(1.0, np.abs(y).max()), np.abs(got - y).max()
