@@ -1003,6 +1003,18 @@ def test_logprob_and_no_speech_thresholds_vs_transformers(tiny, case):
             want = c["passes"][0][0]
             assert abs(float(nsp[0]) - want["no_speech_prob"]) <= 1e-4 * max(1.0, want["no_speech_prob"]) + 1e-7, (nsp, want)
             assert abs(float(alp[0]) - want["avg_logprob"]) <= 2e-3, (alp, want)
+            # the seek loop inside the library (cw_transcribe) and the stage-by-stage host loop skip the same windows
+            from crisperwhisper_amd import generation
+            wins = [x[k * 400000: k * 400000 + 480000] for k in range(2)]
+            kw = dict(language="<|en|>", task="transcribe", max_new_tokens=c["generate_kwargs"]["max_new_tokens"],
+                      logprob_threshold=c["generate_kwargs"]["logprob_threshold"], no_speech_threshold=c["generate_kwargs"]["no_speech_threshold"])
+            outs = []
+            for native in (True, False):
+                _, nf = eng.mel(wins)
+                outs.append(generation.generate(eng, 2, nf, native=native, **kw))
+            assert outs[0]["sequences"].tolist() == outs[1]["sequences"].tolist()
+            for a_, b_ in zip(outs[0]["token_timestamps"], outs[1]["token_timestamps"]):
+                assert np.array_equal(a_, b_)
     finally:
         pipe.engine.close()
 
