@@ -426,7 +426,7 @@ def main():
     roof = {}
     for which, kname in ((0, "gemv2_bf16_kernel<EPI_GELU_F32> (decoder fc1 + fused LayerNorm)"),
                          (1, ("attn_cross_split_fp8_kernel (cross-attention over the e4m3 cache, 1500 frames, 6-way key split)" if a.cross_kv == "fp8" else
-                              "attn_cross_split_kernel<bf16> (cross-attention, 1500 frames, 6-way key split)"))):
+                              "attn_cross_split_kernel<bf16> (cross-attention, 1500 frames, 6-way key split; finishes the fused query)"))):
         ms, by = eng.time_kernel(which, B, a.kernel_iters)
         roof[which] = {"kernel": kname, "avg_ms": ms, "algo_bytes": by, "achieved": by / (ms * 1e-3) / 1e9}
 
@@ -504,8 +504,12 @@ def main():
                 steps_per_call = a.tokens + 2            # prompt positions 0,1 + one forward per generated token
                 by = 1.812e9 + B * 245.76e6               # weights (bf16) + cross-K/V per step; self-K/V omitted
                 per_step_ms = ms / calls / steps_per_call
-                sr["decode_step"] = {"bound": "hbm", "algorithmic_bytes": by, "ms_per_step": per_step_ms,
-                                     "achieved_GBps": by / per_step_ms / 1e6, "frac_of_8TBps": by / per_step_ms / 1e6 / 8000.0}
+                # streamed = what the kernels actually read: the fused out-projection / cross-query stage (csrc/decfuse.hip) adds a
+                # d x d product matrix per layer to the weight stream; the fraction is quoted on the ALGORITHMIC bytes
+                streamed = by + (g.dec_layers * g.d_model * g.d_model * 2.0 if (a.dtype in ("bf16", "f16") and B <= 16 and a.num_beams == 1 and not os.environ.get("CW_NO_FUSE6")) else 0.0)
+                sr["decode_step"] = {"bound": "hbm", "algorithmic_bytes": by, "streamed_bytes": streamed, "ms_per_step": per_step_ms,
+                                     "achieved_GBps": by / per_step_ms / 1e6, "frac_of_8TBps": by / per_step_ms / 1e6 / 8000.0,
+                                     "launches_per_layer": 7 if streamed > by else 8}
             t = per_call("timestamps")
             if t:
                 by = 4.0 * 15 * a.tokens * 1500 * B

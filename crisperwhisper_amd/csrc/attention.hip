@@ -859,8 +859,8 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
     float qa1 = 0.f, qb1 = 0.f, qw1 = 0.f, qc1 = 0.f;
     if (FUSED) {                                                // loads only: using a value in here makes hipcc wait before the K/V loads go out
         const int Dm = p.H * 64;
-        pt0 = *(const float2*)(p.pstats + ((size_t)min(lane, p.n_pstats - 1) * 8 + b0) * 2);
-        pt1 = *(const float2*)(p.pstats + ((size_t)min(lane + 64, p.n_pstats - 1) * 8 + b0) * 2);
+        pt0 = *(const float2*)(p.pstats + ((size_t)min(lane, p.n_pstats - 1) * 16 + b0) * 2);
+        pt1 = *(const float2*)(p.pstats + ((size_t)min(lane + 64, p.n_pstats - 1) * 16 + b0) * 2);
         const size_t col = (size_t)h * 64 + lane;
         qa1 = p.qa[(size_t)b0 * Dm + col]; qb1 = p.qb[(size_t)b0 * Dm + col];
         qw1 = p.qw[col]; qc1 = p.qbias[col];
@@ -1127,7 +1127,7 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
             hipLaunchKernelGGL((attn_cross_full_kernel<bf16_t>), dim3(p.H, p.B), dim3(CROSS_THREADS), 0, st, p);
             return CW_OK;
         }
-        if (!p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.B > 8) return CW_ERR_INVALID;
+        if (!p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.B > 16) return CW_ERR_INVALID;
         hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, 1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
         return CW_OK;
     }

@@ -164,9 +164,11 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
             for (int s = 0; s < NSLOT; ++s) {
                 int step = wave + 4 * s;
                 step = step < steps ? step : steps - 1;
-                const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
+                const u32x4_t* wp = p.wpk ? (const u32x4_t*)(W + ((((size_t)(tile0 + tl) * (K >> 5)) + step * 4) * 64 + lane) * 8)
+                                          : (const u32x4_t*)(wrow + step * 128);
+                const int sj = p.wpk ? 64 : 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * 4];
+                for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * sj];
             }
         } else {
 #pragma unroll
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
             ps2 += sft == 0 ? dpp_mov<0x111, 0xf>(0.f, ps2) : sft == 1 ? dpp_mov<0x112, 0xf>(0.f, ps2) : sft == 2 ? dpp_mov<0x114, 0xf>(0.f, ps2) : dpp_mov<0x118, 0xf>(0.f, ps2);
         }
         const int m = g * 4 + (tid >> 6);
-        if (l15 == 15 && m < 8) *(float2*)(pstats + ((size_t)(bid - block0) * 8 + m) * 2) = make_float2(ps1, ps2);
+        if (l15 == 15) *(float2*)(pstats + ((size_t)(bid - block0) * 16 + m) * 2) = make_float2(ps1, ps2);
     }
 }
 
@@ -274,7 +276,7 @@ static int launch_stack_nt(StackParams& p, hipStream_t st) {
 // is one block per CU at most where possible
 int cw_launch_gemv_stack(const StackParams& p_in, int nt, hipStream_t st) {
     StackParams p = p_in;
-    if (p.Mb < 1 || p.Mb > 8 || p.K % 128 || p.K > 1280 || p.nseg < 1 || p.nseg > 3) return CW_ERR_INVALID;
+    if (p.Mb < 1 || p.Mb > 16 || p.K % 128 || p.K > 1280 || p.nseg < 1 || p.nseg > 3) return CW_ERR_INVALID;
     if (nt <= 0) {
         nt = 1;
         for (;;) {
@@ -286,6 +288,11 @@ int cw_launch_gemv_stack(const StackParams& p_in, int nt, hipStream_t st) {
             if (blocks <= 256 || nt == 3) break;
             ++nt;
         }
+    }
+    if (p.Mb > 8) {                                              // 9..16 rows: four rows per wave
+        if (nt == 1) return launch_stack_nt<4, 1>(p, st);
+        if (nt == 2) return launch_stack_nt<4, 2>(p, st);
+        return launch_stack_nt<4, 3>(p, st);
     }
     if (nt == 1) return launch_stack_nt<2, 1>(p, st);
     if (nt == 2) return launch_stack_nt<2, 2>(p, st);
@@ -369,9 +376,11 @@ __global__ __launch_bounds__(256) void gemv_fc2x_kernel(Fc2xParams p) {
         for (int s = 0; s < NSLOT; ++s) {
             int step = wave + 4 * s;
             step = step < steps ? step : steps - 1;
-            const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
+            const u32x4_t* wp = p.wpk ? (const u32x4_t*)(W + ((((size_t)(ncl[t] >> 4) * (K >> 5)) + (kbase >> 5) + step * 4) * 64 + g * 16 + (ncl[t] & 15)) * 8)
+                                      : (const u32x4_t*)(wrow + step * 128);
+            const int sj = p.wpk ? 64 : 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * 4];
+            for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * sj];
         }
     }
     __builtin_amdgcn_sched_barrier(0);   // all loads issued before the first wait (see gemv_stack_kernel)
@@ -540,9 +549,12 @@ __global__ __launch_bounds__(256) void mlp_pair_kernel(MlpPairParams p) {
         const bf16_t* wrow = W1 + (size_t)(n1 + t * 16 + l15) * D + g * 8;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            const u32x4_t* wp = (const u32x4_t*)(wrow + min(wave + 4 * s, steps - 1) * 128);
+            const int step = min(wave + 4 * s, steps - 1);
+            const u32x4_t* wp = p.wpk ? (const u32x4_t*)(W1 + ((((size_t)((n1 >> 4) + t) * (D >> 5)) + step * 4) * 64 + lane) * 8)
+                                      : (const u32x4_t*)(wrow + step * 128);
+            const int sj = p.wpk ? 64 : 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w1q[t][s][j] = wp[j * 4];
+            for (int j = 0; j < 4; ++j) w1q[t][s][j] = wp[j * sj];
         }
     }
 #pragma unroll
@@ -550,9 +562,12 @@ __global__ __launch_bounds__(256) void mlp_pair_kernel(MlpPairParams p) {
         const bf16_t* wrow = W2 + (size_t)(n2 + t * 16 + l15) * F + kbase + g * 8;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
-            const u32x4_t* wp = (const u32x4_t*)(wrow + min(wave + 4 * s, steps - 1) * 128);
+            const int step = min(wave + 4 * s, steps - 1);
+            const u32x4_t* wp = p.wpk ? (const u32x4_t*)(W2 + ((((size_t)((n2 >> 4) + t) * (F >> 5)) + (kbase >> 5) + step * 4) * 64 + lane) * 8)
+                                      : (const u32x4_t*)(wrow + step * 128);
+            const int sj = p.wpk ? 64 : 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w2q[t][s][j] = wp[j * 4];
+            for (int j = 0; j < 4; ++j) w2q[t][s][j] = wp[j * sj];
         }
     }
     __builtin_amdgcn_sched_barrier(0);                          // every load is out before the first wait

@@ -70,6 +70,9 @@ struct cw_ctx {
     bool fold_enabled = true;       // CW_NO_LN_FOLD=1: keep gamma / beta in the kernels
     std::set<std::string> loaded;   // HF tensor names received through cw_load_tensor
     bool weights_ok = false;        // every tensor of the geometry has been loaded (checked once, see cw_check_weights)
+    bool wpacked = false;           // the decoder's GEMV matrices are in fragment-major order (gemm.hip: wfrag_pack_kernel)
+    bool wpack_enabled = true;      // CW_NO_WPACK=1: keep them row-major (A/B)
+    void* embed_pk = nullptr;       // fragment-major copy of the tied embedding for the logits GEMV (the row-major one serves the token lookup)
 
     // weights
     void *conv1_w = nullptr, *conv2_w = nullptr, *embed = nullptr;
@@ -269,6 +272,7 @@ static int create_impl(cw_ctx* c) {
     if (getenv("CW_NO_LN_FOLD")) c->fold_enabled = false;
     if (getenv("CW_NO_FUSE6")) c->fuse6_enabled = false;
     if (getenv("CW_FUSE_MLP")) c->fuse_mlp = true;
+    if (getenv("CW_NO_WPACK")) c->wpack_enabled = false;
     if (getenv("CW_MLP_PAIR")) c->mlp_pair = true;
     if (getenv("CW_STACK_NT3")) c->stack_nt3 = atoi(getenv("CW_STACK_NT3"));
     if (getenv("CW_STACK_NT5")) c->stack_nt5 = atoi(getenv("CW_STACK_NT5"));
@@ -398,7 +402,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->dmid, (size_t)Bm * F * 4));
     CWCHK(c, dmalloc(c, &c->dx1, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dx2c, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->d_qa, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->d_qb, (size_t)Bm * D * 4));
-    CWCHK(c, dmalloc(c, &c->d_u1, (size_t)Bm * F * 4)); CWCHK(c, dmalloc(c, &c->d_pstats, (size_t)128 * 8 * 2 * 4));
+    CWCHK(c, dmalloc(c, &c->d_u1, (size_t)Bm * F * 4)); CWCHK(c, dmalloc(c, &c->d_pstats, (size_t)128 * 16 * 2 * 4));
     CWCHK(c, dmalloc(c, &c->d_bar, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_err, 4));
     CWCHK(c, dmalloc(c, &c->d_xfrag, (size_t)64 * 5120 * 2));
     CWCHK(c, dmalloc(c, &c->d_xfrag2, (size_t)64 * 5120 * 2));
@@ -481,6 +485,7 @@ void cw_destroy(cw_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 static int load_tensor_impl(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim);
 static int apply_folds(cw_ctx* c);
+static int pack_decoder_weights(cw_ctx* c);
 
 int32_t cw_load_tensor(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
     if (!name || !data || !shape) return fail(c, CW_ERR_INVALID, "cw_load_tensor: null argument");
@@ -518,6 +523,7 @@ int32_t cw_check_weights(cw_ctx* c) {
         if (!c->loaded.count(w)) { if (n_missing < 4) missing += (n_missing ? ", " : "") + w; ++n_missing; }
     if (n_missing) return fail(c, CW_ERR_STATE, "%d of %zu weight tensors were never loaded (e.g. %s): incomplete checkpoint", n_missing, want.size(), missing.c_str());
     CWCHK(c, apply_folds(c));
+    CWCHK(c, pack_decoder_weights(c));
     c->weights_ok = true;
     return CW_OK;
 }
@@ -569,6 +575,40 @@ static int apply_folds(cw_ctx* c) {
     return CW_OK;
 }
 
+// 16-bit engines: the decoder's GEMV weight matrices go fragment-major once every tensor is in and folded (gemm.hip:
+// wfrag_pack_kernel) -- in place through one scratch buffer -- and the tied embedding gets a packed copy for the logits GEMV.
+// A tensor loaded afterwards would land row-major in a packed matrix: refused like a load after folding.
+static int pack_decoder_weights(cw_ctx* c) {
+    if (!c->bf16 || !c->wpack_enabled || c->wpacked) return CW_OK;
+    const int D = c->d.d_model, F = c->d.ffn_dim, V = c->d.vocab_size;
+    if (D % 32 || F % 32) return CW_OK;
+    const size_t emb_elems = KD(c, cw_wfrag_elems, V, D);
+    size_t tmp_elems = (size_t)(2 * F + D) * D;
+    if ((size_t)3 * D * D > tmp_elems) tmp_elems = (size_t)3 * D * D;
+    void* tmp = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, tmp_elems * 2));
+    auto pack = [&](void* w, int N, int K) -> int {
+        CWCHK(c, KD(c, cw_launch_wfrag_pack, w, N, K, tmp, c->st));
+        HIPCHK(c, hipMemcpyAsync(w, tmp, (size_t)N * K * 2, hipMemcpyDeviceToDevice, c->st));
+        return CW_OK;
+    };
+    int r = CW_OK;
+    for (auto& L : c->dec) {
+        if (r == CW_OK) r = pack(L.wqkv, 3 * D, D);
+        if (r == CW_OK) r = pack(L.ws3, 3 * D, D);            // [W'q_c ; W'q_c Wo ; Wo]: wq_c / wo point into it
+        if (r == CW_OK) r = pack(L.ws5, 2 * F + D, D);        // [W'1 ; W'1 Wo_c ; Wo_c]: w1 / wo_c point into it
+        if (r == CW_OK) r = pack(L.w2, D, F);
+    }
+    if (r == CW_OK && !c->embed_pk) r = dmalloc(c, &c->embed_pk, emb_elems * 2, false);
+    if (r == CW_OK) r = KD(c, cw_launch_wfrag_pack, c->embed, V, D, c->embed_pk, c->st);
+    hipStreamSynchronize(c->st);
+    hipFree(tmp);
+    if (r != CW_OK) return r;
+    KCHK(c);
+    c->wpacked = true;
+    return CW_OK;
+}
+
 static int load_tensor_impl(cw_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
     const int D = c->d.d_model, F = c->d.ffn_dim, V = c->d.vocab_size, NM = c->d.n_mels;
     size_t n = 1;
@@ -593,7 +633,11 @@ static int load_tensor_impl(cw_ctx* c, const char* name, const float* data, cons
     if (s == "model.encoder.conv2.bias") { CWCHK(c, expect(D)); return upload_f32(c, c->conv2_b, 0, data, n); }
     if (s == "model.encoder.embed_positions.weight") { CWCHK(c, expect((size_t)CW_N_CTX * D)); return upload_f32(c, c->enc_pos, 0, data, n); }
     if (s == "model.decoder.embed_positions.weight") { CWCHK(c, expect((size_t)c->d.max_target_positions * D)); return upload_f32(c, c->dec_pos, 0, data, n); }
-    if (s == "model.decoder.embed_tokens.weight") { CWCHK(c, expect((size_t)V * D)); return upload_T(c, c->embed, 0, data, n); }
+    if (s == "model.decoder.embed_tokens.weight") {
+        CWCHK(c, expect((size_t)V * D));
+        if (c->wpacked) return fail(c, CW_ERR_STATE, "decoder weights were already packed for the decode GEMVs: create a new context to load another checkpoint");
+        return upload_T(c, c->embed, 0, data, n);
+    }
     if (s == "model.encoder.layer_norm.weight") { CWCHK(c, expect(D)); return upload_f32(c, c->enc_ln_g, 0, data, n); }
     if (s == "model.encoder.layer_norm.bias") { CWCHK(c, expect(D)); return upload_f32(c, c->enc_ln_b, 0, data, n); }
     if (s == "model.decoder.layer_norm.weight") { CWCHK(c, expect(D)); return upload_f32(c, c->dec_ln_g, 0, data, n); }
@@ -609,6 +653,8 @@ static int load_tensor_impl(cw_ctx* c, const char* name, const float* data, cons
     std::string r(rest);
     const float qs = 0.125f;  // head_dim ** -0.5, folded into q projections (exact: power of two)
     const size_t DD = (size_t)D * D;
+    if (c->wpacked && is_dec)
+        return fail(c, CW_ERR_STATE, "decoder weights were already packed for the decode GEMVs: create a new context to load another checkpoint");
     if (is_dec && c->bf16 && c->fold_enabled) {   // LayerNorm-fed decode projections: folded once all tensors are in
         if (c->ln_folded) return fail(c, CW_ERR_STATE, "weights were already folded: create a new context to load another checkpoint");
         if (r == "self_attn.q_proj.weight") { CWCHK(c, expect(DD)); return stage_fold(c, li, 0, data, D, D, L.wqkv, 0, L.bqkv, 0, qs); }
@@ -836,7 +882,7 @@ int32_t cw_get_encoder_output(cw_ctx* c, float* out, int32_t nb) {
 // ------------------------------------------------------------------------------------------------
 static int gemv_ln(cw_ctx* c, int epi, const float* x, int Mb, int K, const void* W, int N, const float* g,
                    const float* b, const EpiParams& ep) {
-    if (c->bf16 || !g) return KD(c, cw_launch_gemv, c->bf16, epi, x, Mb, K, W, N, g, b, ep, c->st, nullptr, c->d_xfrag);
+    if (c->bf16 || !g) return KD(c, cw_launch_gemv, c->bf16, epi, x, Mb, K, W, N, g, b, ep, c->st, nullptr, c->d_xfrag, c->bf16 && c->wpacked);
     int r = KD(c, cw_launch_layernorm_f32, x, g, b, c->dxn, Mb, K, c->st);   // f32 parity mode: unfused LN
     if (r != CW_OK) return r;
     return KD(c, cw_launch_gemv, false, epi, c->dxn, Mb, K, W, N, nullptr, nullptr, ep, c->st);
@@ -850,7 +896,8 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     const bool frag = c->bf16 && nb > 16;
     // fused out-projection / cross-query stage (decfuse.hip): greedy rows of one MFMA half tile, 16-bit caches.  The residual
     // stream then alternates between two buffers: a layer reads x from `xin` and leaves x1, x2, x3 in `xalt`.
-    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 8 && c->beam_K == 0 && !c->kv8;
+    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 16 && c->beam_K == 0 && !c->kv8 &&
+                      !((c->fuse_mlp || c->mlp_pair) && nb > 8);
     float *xin = c->dx, *xalt = c->dx1;
     for (int l = 0; l < c->d.dec_layers; ++l) {
         LayerW& L = c->dec[l];
@@ -871,7 +918,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             {   // X1 over [W'q_c ; W'q_c Wo ; Wo]:  qa = W'q_c x + W'q_c bo,  qb = (W'q_c Wo) a,  x1 = x + Wo a + bo
                 StackParams sp;
                 memset(&sp, 0, sizeof(sp));
-                sp.W = L.ws3; sp.K = D; sp.Mb = nb; sp.nseg = 3;
+                sp.W = L.ws3; sp.wpk = c->wpacked ? 1 : 0; sp.K = D; sp.Mb = nb; sp.nseg = 3;
                 sp.seg[0].x = xin;      sp.seg[0].bias = L.qa_bias; sp.seg[0].out = c->d_qa; sp.seg[0].tile0 = 0;      sp.seg[0].n_tiles = TD; sp.seg[0].epi = 0;
                 sp.seg[1].x = c->dattn; sp.seg[1].bias = nullptr;   sp.seg[1].out = c->d_qb; sp.seg[1].tile0 = TD;     sp.seg[1].n_tiles = TD; sp.seg[1].epi = 0;
                 sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo;      sp.seg[2].out = xalt;    sp.seg[2].tile0 = 2 * TD; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
@@ -891,11 +938,11 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 {   // out-projection combines the key-split partials; x2 = x1 + Wo_c a_c + bo_c in place
                     EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.bo_c; ep.ldo = D;
                     CombineParams cb{c->d_part_ml, H, nb * D};
-                    CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
+                    CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag, c->wpacked));
                 }
                 if (c->mlp_pair && F % D == 0 && D % 32 == 0 && F / 32 <= 256 && F / D <= 32) {
                     // LN + fc1 + GELU, group barrier, fc2 + residual in one launch (decfuse.hip: mlp_pair_kernel)
-                    MlpPairParams mp{xalt, L.w1, L.b1, L.w2, L.b2, c->d_xfrag2, c->d_bar, c->d_err, nb, D, F};
+                    MlpPairParams mp{xalt, L.w1, L.b1, L.w2, L.b2, c->d_xfrag2, c->d_bar, c->d_err, nb, D, F, c->wpacked ? 1 : 0};
                     CWCHK(c, KD(c, cw_launch_mlp_pair, mp, c->st));
                 } else {
                     {
@@ -920,7 +967,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 // fc2 takes the LayerNorm statistics of while its atomics are already modifying the stream)
                 StackParams sp;
                 memset(&sp, 0, sizeof(sp));
-                sp.W = L.ws5; sp.K = D; sp.Mb = nb; sp.nseg = 3;
+                sp.W = L.ws5; sp.wpk = c->wpacked ? 1 : 0; sp.K = D; sp.Mb = nb; sp.nseg = 3;
                 sp.seg[0].x = xalt;     sp.seg[0].bias = L.u1_bias; sp.seg[0].out = c->d_u1; sp.seg[0].tile0 = 0;      sp.seg[0].n_tiles = TF; sp.seg[0].epi = 2;
                 sp.seg[1].x = c->dattn; sp.seg[1].bias = nullptr;   sp.seg[1].out = c->d_u1; sp.seg[1].tile0 = TF;     sp.seg[1].n_tiles = TF; sp.seg[1].epi = 2;
                 sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo_c;    sp.seg[2].out = xin;     sp.seg[2].tile0 = 2 * TF; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
@@ -928,14 +975,14 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 CWCHK(c, KD(c, cw_launch_gemv_stack, sp, c->stack_nt5, c->st));
             }
             {   // fc2: mid = gelu(rstd(x2) (u1 - mean(x2) W'1 1) + b'1) on load; x3 = x2 + W2 mid + b2 in place
-                Fc2xParams fp{c->dx2c, c->d_u1, L.u1_wsum, L.b1, L.w2, L.b2, xin, nb, D, F};
+                Fc2xParams fp{c->dx2c, c->d_u1, L.u1_wsum, L.b1, L.w2, L.b2, xin, nb, D, F, c->wpacked ? 1 : 0};
                 CWCHK(c, KD(c, cw_launch_gemv_fc2x, fp, c->st));
             }
             continue;
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
-            if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
+            if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));
         }
         {   // cross-attention: LN + q projection, attention over the cached encoder K/V
@@ -954,7 +1001,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             } else CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CombineParams cb{c->d_part_ml, H, nb * D};
-            CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag));
+            CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag, c->wpacked));
         } else {
             DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn, nb, H);
             p.align_out = c->d.n_align > 0 ? c->d_align : nullptr; p.align_slot = c->d_align_slot + (size_t)l * H;
@@ -970,13 +1017,13 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.b2; ep.ldo = D;
-            if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2));
+            if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
         }
     }
     if (want_logits) {   // final LN + tied proj_out (:790, :1080), logits in f32 (utils.py:2894)
         EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = c->Vpad;
-        CWCHK(c, gemv_ln(c, EPI_STORE_F32, xin, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep));
+        CWCHK(c, gemv_ln(c, EPI_STORE_F32, xin, nb, D, (c->bf16 && c->wpacked) ? c->embed_pk : c->embed, V, c->dec_ln_g, c->dec_ln_b, ep));
     }
     return CW_OK;
 }
@@ -1967,10 +2014,15 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
                 EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
                 return gemv_ln(c, EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, c->ln_folded ? nullptr : L.ln2_b, ep);
             }
-            case 1: {   // cross-attention
+            case 1: {   // cross-attention (the variant the decode step launches: with the fused stage in front it finishes the query)
                 if (c->bf16) {
                     CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml, nullptr, c->d_align_ml, nullptr,
                                        c->d_pos, 0, 0, nb, H};
+                    if (c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 16 && !c->kv8) {
+                        p.kv_div = 1; p.qa = c->d_qa; p.qb = c->d_qb; p.qw = L.q_wsum; p.qbias = L.bq_c;
+                        p.pstats = c->d_pstats; p.n_pstats = D / 16;
+                        return KD(c, cw_launch_attn_cross_split, true, p, c->st);
+                    }
                     if (c->kv8) { p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs; return KD(c, cw_launch_attn_cross_split_fp8, p, c->st); }
                     return KD(c, cw_launch_attn_cross_split, true, p, c->st);
                 }
@@ -2000,7 +2052,7 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
             }
             case 7: {   // logits
                 EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = c->Vpad;
-                return gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, c->embed, V, c->dec_ln_g, c->dec_ln_b, ep);
+                return gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, (c->bf16 && c->wpacked) ? c->embed_pk : c->embed, V, c->dec_ln_g, c->dec_ln_b, ep);
             }
             case 8:     // near-empty kernel: launch/boundary floor
                 return KD(c, cw_launch_set_pos, c->d_pos, 64, nb, c->st);

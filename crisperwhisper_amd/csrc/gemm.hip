@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
                                                          const bf16_t* __restrict__ W, int N,
                                                          const float* __restrict__ ln_g,
                                                          const float* __restrict__ ln_b, EpiParams ep,
-                                                         CombineParams cb, int m_base) {
+                                                         CombineParams cb, int m_base, int wpk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     x += (size_t)m_base * K;                                  // this launch handles batch rows m_base .. m_base+Mb-1
     const int xs_stride = Kb + 8;
@@ -1247,9 +1247,13 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
         for (int s = 0; s < NSLOT; ++s) {
             int step = wave + 4 * s;
             step = step < steps ? step : steps - 1;
-            const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
+            // wpk: fragment-major weights (wfrag_pack_kernel): the 64 lanes' 16-byte fragments of one MFMA operand are 1 KB of
+            // contiguous memory, i.e. 8 full cache lines per wave instruction instead of 16 half lines at a row stride
+            const u32x4_t* wp = wpk ? (const u32x4_t*)(W + ((((size_t)(ncl[t] >> 4) * (K >> 5)) + (kbase >> 5) + step * 4) * 64 + g * 16 + (ncl[t] & 15)) * 8)
+                                    : (const u32x4_t*)(wrow + step * 128);
+            const int sj = wpk ? 64 : 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * 4];   // +32 bf16  (non-temporal loads measured slower here: decode 436 vs 418 ms / step)
+            for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * sj];   // (non-temporal loads measured slower here: decode 436 vs 418 ms / step)
         }
     }
 
@@ -1443,7 +1447,7 @@ __global__ __launch_bounds__(256) void gemv_prep_kernel(const float* __restrict_
 
 template <int EPI, int MT, bool ATOMIC, int NSLOT>
 __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__ xf, int Mb, int K, int Kb,
-                                                      const bf16_t* __restrict__ W, int N, EpiParams ep) {
+                                                      const bf16_t* __restrict__ W, int N, EpiParams ep, int wpk) {
     __shared__ float red[4 * MT * 4 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1461,9 +1465,11 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
     for (int s = 0; s < NSLOT; ++s) {
         int step = wave + 4 * s;
         step = step < steps ? step : steps - 1;               // clamped (unconditional) load, zeroed below
-        const u32x4_t* wp = (const u32x4_t*)(wrow + step * 128);
+        const u32x4_t* wp = wpk ? (const u32x4_t*)(W + ((((size_t)(nc >> 4) * (K >> 5)) + (kbase >> 5) + step * 4) * 64 + g * 16 + (nc & 15)) * 8)
+                                : (const u32x4_t*)(wrow + step * 128);
+        const int sj = wpk ? 64 : 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * 4];
+        for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * sj];
     }
     f32x4_t acc[MT];
 #pragma unroll
@@ -1657,39 +1663,46 @@ int cw_gemv_kc(int Mb, int K) {
 template <int EPI, int RPW, int NSLOT, int PER_LANE>
 static void launch_gemv2_shape(dim3 grid, size_t lds, int ksplit, const float* x, int Mb, int K, int Kb, const void* W,
                                int N, const float* ln_g, const float* ln_b, const EpiParams& ep, hipStream_t st,
-                               const CombineParams& cb, int m_base) {
+                               const CombineParams& cb, int m_base, int wpk) {
     if (EPI == EPI_RESID_F32 && cb.part_ml) {
         if (ksplit > 1)
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, true, NSLOT, PER_LANE>), grid, dim3(256), lds, st,
-                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
         else
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, false, true, NSLOT, PER_LANE>), grid, dim3(256), lds, st,
-                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
     } else if (EPI == EPI_RESID_F32 && ksplit > 1) {
         if (N % 32 == 0 && (int)(grid.x * grid.y) > 256 && (int)(grid.x * grid.y) / 2 >= 128) {   // fc2: (80, 4) -> (40, 4)
             dim3 g2(grid.x / 2, grid.y);
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE, 2>), g2, dim3(256),
-                               lds + 4 * 4 * 64 * 4, st, x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
+                               lds + 4 * 4 * 64 * 4, st, x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
         } else
         hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x,
-                           Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
+                           Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
     } else {
         // wide LayerNorm GEMVs (fc1: 320 16-column tiles on 256 CUs put two blocks on 64 CUs, whose 2 x 120 KB of loads are
         // the kernel's critical path): two column tiles per block share the activation rows and the LayerNorm work,
         // every CU gets at most one block
-        if (ln_g && ksplit == 1 && N % 32 == 0 && grid.x > 256 && grid.x / 2 >= 128) {
-            dim3 g2(grid.x / 2, 1);
+        // (column indices are clamped and stores masked per column, so N need not be a multiple of the block's columns.)  Very wide
+        // outputs (the 51866-column logits: 3242 tiles, 12.7 per CU) take three tiles per block: every tile re-reads the 40 KB of
+        // activation rows, which at one tile per block is half of all the bytes a CU takes in
+        if (ln_g && ksplit == 1 && grid.x >= 1024) {
+            dim3 g3((grid.x + 2) / 3, 1);
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false, NSLOT, PER_LANE, 3>), g3, dim3(256), lds + 2 * 4 * 4 * 64 * 4, st,
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
+        } else if (ln_g && ksplit == 1 && grid.x > 256 && grid.x / 2 >= 128) {
+            dim3 g2((grid.x + 1) / 2, 1);
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false, NSLOT, PER_LANE, 2>), g2, dim3(256), lds + 4 * 4 * 64 * 4, st,
-                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
         } else
         hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x, Mb, K,
-                           Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base);
+                           Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
     }
 }
 
 template <int EPI, int RPW>
 static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b,
-                         const EpiParams& ep, hipStream_t st, const CombineParams* comb, int m_base) {
+                         const EpiParams& ep, hipStream_t st, const CombineParams* comb, int m_base, int wpk) {
     CombineParams cb{nullptr, 0, 0};
     if (comb) cb = *comb;
     // K split: only for the in-place residual epilogue (f32 atomics into the residual stream), sized so that
@@ -1703,9 +1716,9 @@ static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, co
     const int Kb = K / ksplit;
     const size_t lds = (size_t)16 * (Kb + 8) * 2 + 4 * 4 * 64 * 4;
     dim3 grid((N + 15) / 16, ksplit);
-    if (Kb <= 256) launch_gemv2_shape<EPI, RPW, 1, 1>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base);
-    else if (Kb <= 768) launch_gemv2_shape<EPI, RPW, 2, 3>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base);
-    else launch_gemv2_shape<EPI, RPW, 3, 5>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base);
+    if (Kb <= 256) launch_gemv2_shape<EPI, RPW, 1, 1>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base, wpk);
+    else if (Kb <= 768) launch_gemv2_shape<EPI, RPW, 2, 3>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base, wpk);
+    else launch_gemv2_shape<EPI, RPW, 3, 5>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base, wpk);
 }
 
 static bool gemv2_ok(int epi, int Mb, int K, const float* ln_g, const EpiParams& ep) {
@@ -1720,7 +1733,7 @@ static bool gemv2_ok(int epi, int Mb, int K, const float* ln_g, const EpiParams&
 
 template <int EPI, int MT>
 static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N, const EpiParams& ep, bool allow_split,
-                           hipStream_t st) {
+                           hipStream_t st, int wpk) {
     int ksplit = 1;
     if (EPI == EPI_RESID_F32 && allow_split) {
         const int tiles = (N + 15) / 16, steps = K / 128;
@@ -1734,10 +1747,10 @@ static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N
     do {                                                                                                              \
         if (atomic)                                                                                                   \
             hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, MT, true, NS>), grid, dim3(256), 0, st, xf, Mb, K, Kb,   \
-                               (const bf16_t*)W, N, ep);                                                              \
+                               (const bf16_t*)W, N, ep, wpk);                                                         \
         else                                                                                                          \
             hipLaunchKernelGGL((gemv_mt_kernel<EPI, MT, false, NS>), grid, dim3(256), 0, st, xf, Mb, K, Kb,            \
-                               (const bf16_t*)W, N, ep);                                                              \
+                               (const bf16_t*)W, N, ep, wpk);                                                         \
     } while (0)
     const int steps = Kb / 128;
     if (steps <= 4) CW_MT_LAUNCH(1);
@@ -1749,7 +1762,7 @@ static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N
 // Mb in 17..64, bf16: prep (combine / LayerNorm -> bf16 fragments in `scratch`) + one weight pass for all rows
 template <int EPI>
 static int launch_gemv_large(const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b,
-                             const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch) {
+                             const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch, int wpk) {
     if (K > 5120 || K % 128 != 0) return CW_ERR_INVALID;
     bf16_t* xf = (bf16_t*)scratch;
     CombineParams cb{nullptr, 0, 0};
@@ -1764,17 +1777,17 @@ static int launch_gemv_large(const float* x, int Mb, int K, const void* W, int N
     while (K / ks > 1280) ks *= 2;
     if (ks > 1 && (!allow_split || K % ks != 0 || (K / ks) % 128 != 0)) return CW_ERR_INVALID;
     const int MT = (Mb + 15) / 16;
-    if (MT == 2) launch_gemv_mt<EPI, 2>(xf, Mb, K, W, N, ep, allow_split, st);
-    else if (MT == 3) launch_gemv_mt<EPI, 3>(xf, Mb, K, W, N, ep, allow_split, st);
-    else launch_gemv_mt<EPI, 4>(xf, Mb, K, W, N, ep, allow_split, st);
+    if (MT == 2) launch_gemv_mt<EPI, 2>(xf, Mb, K, W, N, ep, allow_split, st, wpk);
+    else if (MT == 3) launch_gemv_mt<EPI, 3>(xf, Mb, K, W, N, ep, allow_split, st, wpk);
+    else launch_gemv_mt<EPI, 4>(xf, Mb, K, W, N, ep, allow_split, st, wpk);
     return CW_OK;
 }
 
 template <int EPI>
 static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
                            const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb,
-                           void* scratch) {
-    if (bf16 && Mb > 16 && scratch) return launch_gemv_large<EPI>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
+                           void* scratch, int wpk) {
+    if (bf16 && Mb > 16 && scratch) return launch_gemv_large<EPI>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
     if (comb && !(bf16 && gemv2_ok(EPI, Mb, K, ln_g, ep) && EPI == EPI_RESID_F32)) return CW_ERR_INVALID;
     if (bf16) {
         if (gemv2_ok(EPI, Mb, K, ln_g, ep)) {
@@ -1782,11 +1795,12 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
             // L2 / Infinity Cache (the layer's weights were just streamed by the first group)
             for (int m_base = 0; m_base < Mb; m_base += 16) {
                 const int rows = Mb - m_base < 16 ? Mb - m_base : 16;
-                if (rows <= 8) launch_gemv2<EPI, 2>(x, rows, K, W, N, ln_g, ln_b, ep, st, comb, m_base);
-                else launch_gemv2<EPI, 4>(x, rows, K, W, N, ln_g, ln_b, ep, st, comb, m_base);
+                if (rows <= 8) launch_gemv2<EPI, 2>(x, rows, K, W, N, ln_g, ln_b, ep, st, comb, m_base, wpk);
+                else launch_gemv2<EPI, 4>(x, rows, K, W, N, ln_g, ln_b, ep, st, comb, m_base, wpk);
             }
             return CW_OK;
         }
+        if (wpk) return CW_ERR_INVALID;                         // the first-generation kernel reads row-major weights only
         int kc = cw_gemv_kc(Mb, K);
         if (kc % 128 != 0 || K % kc != 0) return CW_ERR_INVALID;
         int Mpad = (Mb + 15) & ~15;
@@ -1794,7 +1808,7 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
         hipLaunchKernelGGL((gemv_bf16_kernel<EPI>), dim3((N + 15) / 16), dim3(256), lds, st, x, Mb, K, kc,
                            (const bf16_t*)W, N, ln_g, ln_b, ep);
     } else {
-        if (ln_g) return CW_ERR_INVALID;
+        if (ln_g || wpk) return CW_ERR_INVALID;
         hipLaunchKernelGGL((gemv_f32_kernel<EPI>), dim3((N + 3) / 4), dim3(256), 0, st, x, Mb, K, (const float*)W, N,
                            ep);
     }
@@ -1802,21 +1816,55 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
 }
 
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
-                   const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch) {
+                   const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch, bool wpacked) {
+    const int wpk = wpacked ? 1 : 0;
     if (Mb <= 0 || Mb > GV_MAXM || K % 128 != 0) return CW_ERR_INVALID;
     if (!x && !(bf16 && Mb > 16 && scratch)) return CW_ERR_INVALID;
     switch (epi) {
-        case EPI_GELU_F32: return launch_gemv_epi<EPI_GELU_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
+        case EPI_GELU_F32: return launch_gemv_epi<EPI_GELU_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
         case EPI_GELU_FRAG:
             if (!(bf16 && Mb > 16 && scratch)) return CW_ERR_INVALID;
-            return launch_gemv_large<EPI_GELU_FRAG>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
-        case EPI_RESID_F32: return launch_gemv_epi<EPI_RESID_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
-        case EPI_STORE_F32: return launch_gemv_epi<EPI_STORE_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
-        case EPI_QKV_CACHE: return launch_gemv_epi<EPI_QKV_CACHE>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch);
+            return launch_gemv_large<EPI_GELU_FRAG>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
+        case EPI_RESID_F32: return launch_gemv_epi<EPI_RESID_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
+        case EPI_STORE_F32: return launch_gemv_epi<EPI_STORE_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
+        case EPI_QKV_CACHE: return launch_gemv_epi<EPI_QKV_CACHE>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
         default: return CW_ERR_INVALID;
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Fragment-major weight layout of the decode GEMVs (round 3).  A wave instruction of the row-major weight stream fetches, for
+// 16 output columns, 64 contiguous bytes of each row: 16 half cache lines at a stride of one row; the stream then runs at
+// 3.7 TB/s at best (the 133 MB logits GEMV: 36 us).  Packed, element (n, k) of a [N][K] matrix sits at
+//     (((n >> 4) * (K >> 5) + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) * 8 + (k & 7)          (= frag_index(n, k, K))
+// so the 64 lanes' 16-byte MFMA fragments of one (16-column tile, 32-wide k step) are 1 KB of contiguous memory: 8 full lines
+// per instruction.  Rows are padded to a multiple of 16 (the pad rows repeat the last row and are never stored).  The engine
+// packs the decoder's GEMV matrices once, after folding; the kernels take either layout (`wpk`).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wfrag_pack_kernel(const bf16_t* __restrict__ src, int N, int K, bf16_t* __restrict__ dst,
+                                                         long long n_chunks) {
+    const long long ci = (long long)blockIdx.x * 256 + threadIdx.x;   // one 16-byte chunk (8 elements) of the packed image
+    if (ci >= n_chunks) return;
+    const int lane = (int)(ci & 63);
+    const long long tk = ci >> 6;
+    const int KS = K >> 5;
+    const int kj = (int)(tk % KS);
+    const int tile = (int)(tk / KS);
+    int n = tile * 16 + (lane & 15);
+    n = n < N ? n : N - 1;
+    const int k = kj * 32 + (lane >> 4) * 8;
+    *(u32x4_t*)(dst + ci * 8) = *(const u32x4_t*)(src + (size_t)n * K + k);
+}
+
+size_t cw_wfrag_elems(int N, int K) { return (size_t)((N + 15) & ~15) * K; }
+int cw_launch_wfrag_pack(const void* src, int N, int K, void* dst, hipStream_t st) {
+    if (K % 32 || N < 1) return CW_ERR_INVALID;
+    const long long n_chunks = (long long)(cw_wfrag_elems(N, K) / 8);
+    hipLaunchKernelGGL(wfrag_pack_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const bf16_t*)src, N, K,
+                       (bf16_t*)dst, n_chunks);
+    return CW_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm affine folding (bf16 decode engine): a projection fed by LN(x) = n(x) * g + beta is rewritten as

@@ -99,7 +99,7 @@ struct CrossSplitParams {
     // fused out-projection / query stage (decfuse.hip): q is finished here from the two partial projections and the statistics of
     // the residual row,  q = rstd(xs) * (qa + qb - mean(xs) * qw) + qbias;  all null: `q` holds the finished query
     const float* xstat;    // [B][H*64] residual rows the LayerNorm statistics are taken of (null: plain q), or
-    const float* pstats;   // [n_pstats][8][2] per-block (sum, sum of squares) of those rows, left by the producing GEMV
+    const float* pstats;   // [n_pstats][16][2] per-block (sum, sum of squares) of those rows, left by the producing GEMV
     int n_pstats;
     const float* qa;       // [B][H*64] W'q x + W'q bo
     const float* qb;       // [B][H*64] (W'q Wo) a
@@ -121,7 +121,7 @@ struct StackSeg {
     const float* resid;    // epi 1: [Mb][n_tiles*16]
     float* out;            // [Mb][n_tiles*16]
     float* out2;           // epi 1: optional second copy of the result
-    float* pstats;         // epi 1: optional [blocks of the segment][8][2] per-block (sum, sum of squares) of every output row
+    float* pstats;         // epi 1: optional [blocks of the segment][16][2] per-block (sum, sum of squares) of every output row
     int tile0, n_tiles;    // rows [tile0*16, (tile0+n_tiles)*16) of W
     int nt;                // 16-column tiles per block of this segment (<= the launch's NT; 0 = NT)
     int block0;            // filled in by the launcher
@@ -130,6 +130,7 @@ struct StackSeg {
 };
 struct StackParams {
     const void* W;
+    int wpk;               // W is fragment-major (gemm.hip: wfrag_pack_kernel) instead of row-major
     int K, Mb, nseg;
     StackSeg seg[3];
     float* zero;           // optional: the launch also clears zero_n4 float4 (a buffer a LATER launch accumulates into)
@@ -146,6 +147,7 @@ struct Fc2xParams {
     const float* b2;       // [D]
     float* x;              // [Mb][D] residual stream, accumulated in place
     int Mb, D, F;
+    int wpk;               // W2 is fragment-major
 };
 
 // decfuse.hip: fc1 -> GELU -> fc2 in ONE launch.  The F / 32 blocks form F / D independent groups of D / 32 blocks (a group =
@@ -161,6 +163,7 @@ struct MlpPairParams {
     unsigned int* bar;     // [2 * F / D]: arrival counter and generation of every group (zero-initialised, reusable)
     int* err;              // set to 1 when a block gave up waiting at the barrier (never expected; results are then invalid)
     int Mb, D, F;
+    int wpk;               // W1 / W2 are fragment-major
 };
 
 // mel.hip
@@ -184,7 +187,9 @@ struct MelTables {
     int cw_launch_quant_rows_fp8(const void* x, int rows, int K, void* out8, float* scale, hipStream_t st); \
     int cw_launch_gemm_fp8(int epi, const void* A8, int lda, const void* W8, int M, int N, int K, const float* sa, const float* sw, const EpiParams& ep, hipStream_t st); \
     int cw_launch_fold_layernorm(const float* Wf, int N, int K, const float* g, const float* beta, float scale, void* w_out, float* bias, hipStream_t st); \
-    int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr, void* scratch = nullptr ); \
+    int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr, void* scratch = nullptr, bool wpacked = false); \
+    size_t cw_wfrag_elems(int N, int K); \
+    int cw_launch_wfrag_pack(const void* src, int N, int K, void* dst, hipStream_t st); \
     int cw_launch_fold_product(const float* A, const float* s, float scale, const float* B, int N, int J, int K, void* C16, hipStream_t st); \
     int cw_launch_fold_rowvec(const float* A, const float* s, float scale, const float* v, const void* W16, int N, int J, float* c_out, float* w_out, hipStream_t st); \
     int cw_launch_gemv_stack(const StackParams& p, int nt, hipStream_t st); \

@@ -1035,3 +1035,47 @@ def test_unknown_generate_kwargs_raise_instead_of_being_dropped(tiny):
                                  "do_sample": False, "compression_ratio_threshold": 1.35})
     finally:
         pipe.engine.close()
+
+
+@pytest.mark.parametrize("rows", [3, 8, 12])
+def test_fused_decoder_stage_tracks_eight_launch_layer(rows):
+    """csrc/decfuse.hip: the out-projection + cross-query stage applied through the load-time product matrix (7 launches per
+    layer) against the same engine with the stage switched off (CW_NO_FUSE6=1, 8 launches), large-v3 shapes on a 2+2-layer stack,
+    teacher-forced, 1..16 rows (two or four rows per wave): logits within bf16 rounding of each other, same tokens, alignment
+    rows within 2e-2 -- the two differ only in where the 16-bit roundings fall (x before the mean is subtracted, the product
+    W'q Wo rounded once)."""
+    import os
+    g, v = syn.large_v3_geometry()
+    g.enc_layers = g.dec_layers = 2
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19)]
+    W = syn.random_weights(g, seed=9)
+    T = 10
+    clips = [syn.synth_audio(300 + i, 480000 - 15000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
+    rng = np.random.default_rng(2)
+    ids = np.concatenate([[v.sot, v.lang_id("en"), v.transcribe], [v.timestamp_begin], rng.integers(300, 50000, T - 4)])
+    forced = np.full((rows, T), -1, np.int32); forced[:, 3:] = ids[3:]
+    prompt = np.tile(ids[None, :3], (rows, 1))
+    res = {}
+    for mode in ("fused", "eight"):
+        if mode == "eight":
+            os.environ["CW_NO_FUSE6"] = "1"
+        try:
+            eng = Engine(spec, dtype="bf16", max_batch=rows)
+        finally:
+            os.environ.pop("CW_NO_FUSE6", None)
+        try:
+            eng.load_state_dict(W)
+            eng.mel(clips)
+            eng.encode(list(range(rows)), [0] * rows, [3000] * rows)
+            cap = eng.capture_logits(rows, T)
+            eng.decode(prompt, max_length=T, forced=forced)
+            res[mode] = (cap[:T - 3].copy(), eng.alignment(rows, T - 1))
+            eng.stop_capture()
+        finally:
+            eng.close()
+    (lf, af), (le, ae) = res["fused"], res["eight"]
+    rel = np.abs(lf - le).max() / np.abs(le).max()
+    assert rel < 0.03, rel
+    assert (lf.argmax(-1) == le.argmax(-1)).mean() > 0.95
+    assert np.abs(af - ae).max() < 2e-2
