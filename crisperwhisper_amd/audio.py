@@ -77,6 +77,9 @@ def parse_wav(data: bytes):
     return code, ch, sr, n_frames, payload[: n_frames * ch * (bits // 8)]
 
 
+MAX_DECODED_SECONDS = 24 * 3600          # upper bound on what a single compressed file may expand to
+
+
 def decode_flac(data: bytes):
     """FLAC bytes -> (int32 samples [frames, channels] left-justified to 32 bits, sample rate) through the native decoder
     (csrc/flac.cpp: RFC 9639 incl. CRC and MD5 verification; raises ValueError with the decoder's message)."""
@@ -89,12 +92,23 @@ def decode_flac(data: bytes):
     ptr = buf.ctypes.data_as(C.c_void_p)
     if lib.cw_flac_info(ptr, len(buf), C.byref(sr), C.byref(ch), C.byref(bps), C.byref(total)) != 0:
         raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
-    if lib.cw_flac_decode(ptr, len(buf), None, 0, C.byref(n)) != 0:
+    # one decoding pass when STREAMINFO states the length (it is verified against the frames); a stream of unknown length
+    # (total = 0) is sized by a first pass.  Either way the decoded audio is capped: a few hundred bytes of CONSTANT frames
+    # would otherwise expand without bound.
+    max_frames = MAX_DECODED_SECONDS * max(int(sr.value), 1)
+    if total.value > max_frames:
+        raise ValueError(f"FLAC stream declares {total.value} sample frames: more than the {MAX_DECODED_SECONDS} s this path accepts")
+    cap = int(total.value)
+    if cap <= 0:
+        if lib.cw_flac_decode(ptr, len(buf), None, 0, C.byref(n)) != 0:
+            raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
+        cap = int(n.value)
+        if cap > max_frames:
+            raise ValueError(f"FLAC stream decodes to {cap} sample frames: more than the {MAX_DECODED_SECONDS} s this path accepts")
+    out = np.empty((cap, int(ch.value)), dtype=np.int32)
+    if lib.cw_flac_decode(ptr, len(buf), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)) != 0:
         raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
-    out = np.empty((int(n.value), int(ch.value)), dtype=np.int32)
-    if lib.cw_flac_decode(ptr, len(buf), out.ctypes.data_as(C.c_void_p), int(n.value), C.byref(n)) != 0:
-        raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
-    return out, int(sr.value)
+    return out[: int(n.value)], int(sr.value)
 
 
 def _need(engine):

@@ -5,7 +5,7 @@ OUT=${1:-gpurun_out/pmc_traffic.json}; shift
 mkdir -p gpurun_out/pmc2
 export PYTHONUNBUFFERED=1
 R=$GRAFT_REPO_ROOT
-ARGS="--batch 8 --tokens 4 --steps 1 --warmup 0 --no-cpu-baseline --no-longform --kernel-iters 3 $*"
+ARGS="--batch 8 --tokens 4 --steps 1 --warmup 0 --no-cpu-baseline --no-longform --no-config3 --kernel-iters 3 $*"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc2 -o fetch -- python $R/bench.py $ARGS > $R/gpurun_out/pmc2_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc2 -o write -- python $R/bench.py $ARGS > $R/gpurun_out/pmc2_write.log 2>&1
