@@ -631,12 +631,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const bf16_t* __rest
         for (int q = 0; q < 2; ++q) va[h][q] = (min(m0 + h * 128 + wave * 16 + q * 8 + lrow, M - 1) * lda + csrc) * 2;
     const int vw = ((n0 + wave * 16 + lrow) * K + csrc) * 2;
     auto issue_a = [&](int k0, int buf, int h) {
+#ifdef CW_8PH_NO_DMA
+        return;
+#endif
         unsigned char* base = gsm4 + buf * 65536 + (h * 128 + wave * 16) * 128;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(base + q * 1024), 16, va[h][q], k0 * 2, 0, 0);
     };
     auto issue_w = [&](int k0, int buf, int h) {
+#ifdef CW_8PH_NO_DMA
+        return;
+#endif
         unsigned char* base = gsm4 + buf * 65536 + 32768 + (h * 128 + wave * 16) * 128;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -648,6 +654,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const bf16_t* __rest
     const int aoff = (wr * 64 + l15) * 128, woff = 32768 + (wn * 32 + l15) * 128;
     bf16x8_t fa[2][4], fw[2][2][2];                             // fw[column half]: the W_h0 fragments serve phases 1 and 4
     auto read_a = [&](int buf, int h) {
+#ifdef CW_8PH_NO_READS
+        if (buf >= 0) return;
+#endif
         const unsigned char* sb = gsm4 + buf * 65536 + aoff + h * 16384;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -657,6 +666,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const bf16_t* __rest
         }
     };
     auto read_w = [&](int buf, int h) {
+#ifdef CW_8PH_NO_READS
+        if (buf >= 0) return;
+#endif
         const unsigned char* sb = gsm4 + buf * 65536 + woff + h * 16384;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -689,9 +701,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const bf16_t* __rest
     } while (0)
     // counted wait on the LDS-DMA: three half tiles (6 loads) may stay in flight; once fewer are being issued (the last two
     // K-tiles) everything is drained instead
+#ifndef CW_8PH_VMCNT
+#define CW_8PH_VMCNT 6
+#endif
+#define CW_8PH_STR2(x) #x
+#define CW_8PH_STR(x) CW_8PH_STR2(x)
 #define CW_8PH_WAIT(steady)                                                                                 \
     do {                                                                                                    \
-        if (steady) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                        \
+        if (steady) asm volatile("s_waitcnt vmcnt(" CW_8PH_STR(CW_8PH_VMCNT) ")" ::: "memory");             \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
     } while (0)
