@@ -2007,8 +2007,10 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
     // from HBM (one layer's 61 MB cross cache alone would otherwise sit in the 256 MB Infinity Cache and flatter the
     // kernel: 11.6 us "hot" vs 14.1 us inside the step)
     int launch_no = 0;
+    const bool hot = which >= 200;                              // 200 + k: kernel k on ONE layer's operands (L2 / Infinity-Cache resident)
+    if (hot) which -= 200;
     auto launch = [&]() -> int {
-        LayerW& L = c->dec[(launch_no++) % c->d.dec_layers];
+        LayerW& L = c->dec[hot ? 0 : (launch_no++) % c->d.dec_layers];
         switch (which) {
             case 0: {   // fc1: LN + GEMV + GELU
                 EpiParams ep = epi0(); ep.outf = c->dmid; ep.bias = L.b1; ep.ldo = F;
