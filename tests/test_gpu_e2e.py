@@ -1079,3 +1079,25 @@ def test_fused_decoder_stage_tracks_eight_launch_layer(rows):
     assert rel < 0.03, rel
     assert (lf.argmax(-1) == le.argmax(-1)).mean() > 0.95
     assert np.abs(af - ae).max() < 2e-2
+
+
+@pytest.mark.parametrize("name", ["mixed450_b16_n24", "noise400_b16_free"])
+@pytest.mark.parametrize("dtype", ["float32"])
+def test_pipeline_at_the_reference_batch_size_16(tiny, name, dtype):
+    """REF/transcribe.py:27 constructs its pipeline with batch_size=16: a recording of 400-450 s (16-22 windows: one full
+    batch of 16 and a ragged one) through the same call, against transformers (tests/golden/gen_golden_b16.py) -- batch
+    composition changes what the reference computes (double crop of the alignment matrix when all windows of a call have the same
+    length, batch shrinking in the seek loop), so batch 16 is pinned separately.  f32 engine: word for word."""
+    g, v, W, spec = tiny
+    meta = Hh.gold_json("e2e_b16_golden.json")[name]
+    x = syn.synth_audio(meta["seed"], int(round(meta["secs"] * 16000)), meta["kind"])
+    pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, W),
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30,
+                       batch_size=16, return_timestamps="word", torch_dtype=dtype, device="cuda:0", num_beams=1)
+    try:
+        out = pipe(x, generate_kwargs={**Hh.GEN_KW, **meta["extra"]})
+        assert out["text"] == meta["text"]
+        ok, why = Hh.words_equal(out["chunks"], meta["chunks"], tol=0.02)
+        assert ok, why
+    finally:
+        pipe.engine.close()
