@@ -246,6 +246,7 @@ struct EpiParams {
     int H;                // heads
     int d_model;          // columns per `which`
     const int* row_pos;   // EPI_QKV_CACHE: [batch] device array, cache row to write for each batch row
+    int x16;              // decode GEMV: the activation rows are 16-bit (a producer's EPI_GELU output) instead of f32
 };
 
 // MFMA 16x16x32 A-operand fragment-major position of activation (row m, column k) of a [rows][K] matrix:

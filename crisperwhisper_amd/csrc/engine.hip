@@ -945,13 +945,15 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                     MlpPairParams mp{xalt, L.w1, L.b1, L.w2, L.b2, c->d_xfrag2, c->d_bar, c->d_err, nb, D, F, c->wpacked ? 1 : 0};
                     CWCHK(c, KD(c, cw_launch_mlp_pair, mp, c->st));
                 } else {
+                    // fc1 writes gelu(.) in the 16-bit type fc2 would round it to anyway (bit-identical): fc2's activation load halves
+                    const bool mid16 = F > 1280 && !getenv("CW_NO_MID16");
                     {
                         EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
-                        CWCHK(c, gemv_ln(c, EPI_GELU_F32, xalt, nb, D, L.w1, F, L.ln2_g, nullptr, ep));
+                        CWCHK(c, gemv_ln(c, mid16 ? EPI_GELU : EPI_GELU_F32, xalt, nb, D, L.w1, F, L.ln2_g, nullptr, ep));
                     }
                     {
-                        EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.b2; ep.ldo = D;
-                        CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
+                        EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.b2; ep.ldo = D; ep.x16 = mid16 ? 1 : 0;
+                        CWCHK(c, gemv_ln(c, EPI_RESID_F32, mid16 ? (const float*)c->d_xfrag2 : c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
                     }
                 }
                 float* t = xin; xin = xalt; xalt = t;

@@ -1173,7 +1173,8 @@ extern "C" int cw_debug_phases(unsigned long long* out) {
 #define PH(i) do { } while (0)
 #endif
 
-template <int EPI, int RPW, bool ATOMIC, bool COMBINE, int NSLOT, int PER_LANE, int NT = 1 /* 16-column tiles per block */>
+template <int EPI, int RPW, bool ATOMIC, bool COMBINE, int NSLOT, int PER_LANE, int NT = 1 /* 16-column tiles per block */,
+          bool X16 = false /* activation rows arrive in the engine's 16-bit type (no LayerNorm, no combine) */>
 __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict__ x, int Mb, int K, int Kb,
                                                          const bf16_t* __restrict__ W, int N,
                                                          const float* __restrict__ ln_g,
@@ -1204,9 +1205,27 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     for (int t = 0; t < NT; ++t) bias_v[t] = ep.bias ? ep.bias[ncl[t]] : 0.f;
 
     // activation rows -> registers
+    constexpr int PER8 = (PER_LANE + 1) / 2;                  // X16: 8 elements per 16-byte load
+    u32x4_t xh[RPW][PER8];
     float4 xv[RPW][PER_LANE];
+    if (X16) {
+        const bf16_t* xb = (const bf16_t*)x;                  // (x was advanced by m_base * K floats: undo in 16-bit units below)
+        xb = xb - (size_t)m_base * K * 2 + (size_t)m_base * K;
+        const int nv8 = Kb >> 3;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
+        for (int i = 0; i < RPW; ++i) {
+            int row = wave + 4 * i;
+            row = row < Mb ? row : Mb - 1;
+#pragma unroll
+            for (int c = 0; c < PER8; ++c) {
+                int v8 = lane + 64 * c;
+                v8 = v8 < nv8 ? v8 : nv8 - 1;
+                xh[i][c] = *(const u32x4_t*)(xb + (size_t)row * K + kbase + v8 * 8);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (X16 ? 0 : RPW); ++i) {
         int row = wave + 4 * i;
         row = row < Mb ? row : Mb - 1;
 #pragma unroll
@@ -1311,8 +1330,21 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
         }
     }
     // rows -> bf16 -> LDS.  Rows >= Mb are never written: they only feed MFMA output rows that are dropped.
+    if (X16) {
+        const int nv8 = Kb >> 3;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + 4 * i;
+#pragma unroll
+            for (int c = 0; c < PER8; ++c) {
+                int v8 = lane + 64 * c;
+                v8 = v8 < nv8 ? v8 : nv8 - 1;                   // clamped lanes rewrite identical data
+                *(u32x4_t*)(xs + (size_t)row * xs_stride + v8 * 8) = xh[i][c];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (X16 ? 0 : RPW); ++i) {
         const int row = wave + 4 * i;
 #pragma unroll
         for (int c = 0; c < PER_LANE; ++c) {
@@ -1691,9 +1723,16 @@ static void launch_gemv2_shape(dim3 grid, size_t lds, int ksplit, const float* x
     } else if (EPI == EPI_RESID_F32 && ksplit > 1) {
         if (N % 32 == 0 && (int)(grid.x * grid.y) > 256 && (int)(grid.x * grid.y) / 2 >= 128) {   // fc2: (80, 4) -> (40, 4)
             dim3 g2(grid.x / 2, grid.y);
+            if (ep.x16)
+                hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE, 2, true>), g2, dim3(256),
+                                   lds + 4 * 4 * 64 * 4, st, x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
+            else
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE, 2>), g2, dim3(256),
                                lds + 4 * 4 * 64 * 4, st, x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
-        } else
+        } else if (ep.x16)
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE, 1, true>), grid, dim3(256), lds, st, x,
+                               Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
+        else
         hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, false, NSLOT, PER_LANE>), grid, dim3(256), lds, st, x,
                            Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
     } else {
@@ -1835,10 +1874,15 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
                    const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch, bool wpacked) {
     const int wpk = wpacked ? 1 : 0;
+    // 16-bit activation rows: only the K-split residual GEMV of <= 16 rows takes them (fc2 behind an EPI_GELU fc1)
+    if (ep.x16 && !(bf16 && epi == EPI_RESID_F32 && !ln_g && !comb && Mb <= 16 && K > 1280 && ep.outf == ep.resid)) return CW_ERR_INVALID;
     if (Mb <= 0 || Mb > GV_MAXM || K % 128 != 0) return CW_ERR_INVALID;
     if (!x && !(bf16 && Mb > 16 && scratch)) return CW_ERR_INVALID;
     switch (epi) {
         case EPI_GELU_F32: return launch_gemv_epi<EPI_GELU_F32>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
+        case EPI_GELU:                                           // 16-bit row-major output [Mb][ldo] for a consumer launched with ep.x16
+            if (!bf16 || Mb > 16) return CW_ERR_INVALID;
+            return launch_gemv_epi<EPI_GELU>(bf16, x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
         case EPI_GELU_FRAG:
             if (!(bf16 && Mb > 16 && scratch)) return CW_ERR_INVALID;
             return launch_gemv_large<EPI_GELU_FRAG>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
