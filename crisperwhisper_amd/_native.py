@@ -93,6 +93,7 @@ _SIGS = {
     "cw_test_gemm_fp8": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "cw_test_gemv": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
     "cw_test_attention": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "cw_test_cross_attention": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),
     "cw_test_sample": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "cw_stage_times": (_I, [_P, _P, _P, _I]),
     "cw_time_kernel": (_I, [_P, _I, _I, _I, _P, _P]),

@@ -1110,6 +1110,180 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_full_kernel(CrossSpl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Cross-attention decode for nq = 2..16 rows that share one K/V (the hypotheses of one audio item under beam search), on the
+// matrix cores.  grid (H, B / nq, ATT_NS), 512 threads, 16-bit caches.  The VALU kernel above does nq x 250 dot products, the
+// exponentials and nq x 250 x 64 multiply-adds per block in 8-lane groups: at 5 hypotheses it is instruction-bound (2600
+// instructions per wave, 25.8 us per layer against 13 us at one row for the same 61 MB of K/V).  Here a wave owns 32 consecutive
+// keys of the block's slice and
+//   * S^T = K Q^T is four 16x16x32 MFMAs per 16-key tile (A = the K rows as loaded from HBM, B = the queries; the queries are
+//     split q = hi + lo into two 16-bit numbers so the product keeps ~16 mantissa bits of the f32 query the VALU kernel used;
+//     the contraction index is permuted, dim = g*16 + s*8 + j, so that a lane's two K loads are 32 contiguous bytes),
+//   * the C fragment of S^T (lane: query l&15, keys g*4 .. g*4+3 of each tile) IS the B fragment of the second product
+//     O^T = V^T P^T under the key order (g*4+j of tile 0, then of tile 1): no cross-lane movement for P (again hi + lo),
+//   * V^T comes out of a wave-private LDS image of the wave's 32 V rows (row-major as loaded, 144-byte rows) through
+//     `ds_read_b64_tr_b16`, the gfx950 transposing read: each 16-lane group hands the hardware four rows x 16 columns and gets
+//     column l&15 of them.
+// The running maximum (one exchange through LDS), the partial planes, (m, l) pairs and alignment rows are exactly those of the
+// VALU kernel, so the out-projection's combine and align_normalize_kernel do not change.
+// ---------------------------------------------------------------------------------------------------
+#define XM_VS 72                                                  // V image row stride (elements): 16-byte aligned rows
+__device__ inline void split_hi_lo(const float* x, bf16x8_t& hi, bf16x8_t& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bf16_t h = f32_to_bf16(x[e]);
+        hi[e] = (short)h;
+        lo[e] = (short)f32_to_bf16(x[e] - bf16_to_f32(h));
+    }
+}
+typedef short xm_v4s __attribute__((ext_vector_type(4)));
+template <bool TR>
+__global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma_kernel(CrossSplitParams p, int nq) {
+    __shared__ __attribute__((aligned(16))) bf16_t s_v[8 * 32 * XM_VS];   // per wave: 32 V rows, later its 16 x 64 partial outputs
+    __shared__ float s_max[8 * 16];
+    __shared__ float red_l[8 * 16];
+    const int h = blockIdx.x, b0 = blockIdx.y * nq, sp = blockIdx.z;
+    const int bk = b0 / p.kv_div;
+    const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
+    const int k_lo = sp * per, k_hi = min(p.n_keys, k_lo + per), nk = k_hi - k_lo;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = wave * 32;
+    const int D = p.H * 64;
+    const bf16_t* Kh = (const bf16_t*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64;
+    const bf16_t* Vh = (const bf16_t*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64;
+    // every load of the block first: 4 x 16 B of K (A fragments), 4 x 16 B of V (row-major), the lane's 16 query values
+    uint4 kf[2][2], vr[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const bf16_t* kp = Kh + (size_t)min(kb + t * 16 + r, nk - 1) * 64 + g * 16;
+        kf[t][0] = *(const uint4*)kp; kf[t][1] = *(const uint4*)(kp + 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        vr[u] = *(const uint4*)(Vh + (size_t)min(kb + (lane >> 3) + 8 * u, nk - 1) * 64 + (lane & 7) * 8);
+    float qf[2][8];
+    {
+        const float* qp = p.q + (size_t)(b0 + min(r, nq - 1)) * D + h * 64 + g * 16;
+        const float4 q0 = *(const float4*)qp, q1 = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
+        const float z = r < nq ? 1.f : 0.f;                       // fragment columns past the last row: zero queries
+        qf[0][0] = q0.x * z; qf[0][1] = q0.y * z; qf[0][2] = q0.z * z; qf[0][3] = q0.w * z;
+        qf[0][4] = q1.x * z; qf[0][5] = q1.y * z; qf[0][6] = q1.z * z; qf[0][7] = q1.w * z;
+        qf[1][0] = q2.x * z; qf[1][1] = q2.y * z; qf[1][2] = q2.z * z; qf[1][3] = q2.w * z;
+        qf[1][4] = q3.x * z; qf[1][5] = q3.y * z; qf[1][6] = q3.z * z; qf[1][7] = q3.w * z;
+    }
+    bf16x8_t qh[2], ql[2];
+    split_hi_lo(qf[0], qh[0], ql[0]);
+    split_hi_lo(qf[1], qh[1], ql[1]);
+    // S^T: lane holds query r, keys kb + t*16 + g*4 + i
+    f32x4_t st[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, kf[t][0]), a1 = __builtin_bit_cast(bf16x8_t, kf[t][1]);
+        c = cw_mfma_16x16x32(a0, ql[0], c);
+        c = cw_mfma_16x16x32(a1, ql[1], c);
+        c = cw_mfma_16x16x32(a0, qh[0], c);
+        c = cw_mfma_16x16x32(a1, qh[1], c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c[i] = (kb + t * 16 + g * 4 + i < nk) ? c[i] : -INFINITY;
+            mx = fmaxf(mx, c[i]);
+        }
+        st[t] = c;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (g == 0) s_max[wave * 16 + r] = mx;
+    // the wave's V rows into its LDS image (row-major, as loaded)
+    bf16_t* sv = s_v + wave * (32 * XM_VS);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *(uint4*)(sv + ((lane >> 3) + 8 * u) * XM_VS + (lane & 7) * 8) = vr[u];
+    __syncthreads();
+    {
+        float m = s_max[r];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, s_max[w * 16 + r]);
+        mx = m;
+    }
+    const int slot = p.align_out ? p.align_slot[h] : -1;
+    float pr[8], lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = kb + t * 16 + g * 4 + i;
+            const float pk = (k < nk) ? expf(st[t][i] - mx) : 0.f;
+            pr[t * 4 + i] = pk;
+            lsum += pk;
+        }
+    if (slot >= 0 && r < nq) {                                    // un-normalised; align_normalize_kernel finishes the row
+        const size_t rowi = ((size_t)(b0 + r) * p.n_align + slot) * p.align_rows + p.pos[b0 + r];
+        float* ao = p.align_out + rowi * p.n_keys + k_lo;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kb + t * 16 + g * 4 + i;
+                if (k < nk) ao[k] = pr[t * 4 + i];
+            }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (g == 0) red_l[wave * 16 + r] = lsum;
+    // O^T = V^T P^T: B fragment = the probabilities this lane already holds (k index g*8 + j <-> key g*4 + j of tile j / 4)
+    bf16x8_t ph, pl;
+    split_hi_lo(pr, ph, pl);
+    f32x4_t oc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        bf16x8_t a;
+        if (TR) {
+            // a 16-lane group passes 4 rows x 16 columns (lane i: row i / 4, columns 4 (i % 4) .. +3) and receives column i of them
+            const bf16_t* a0 = sv + (g * 4 + (r >> 2)) * XM_VS + dt * 16 + (r & 3) * 4;
+            const xm_v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((xm_v4s __attribute__((address_space(3)))*)a0);
+            const xm_v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((xm_v4s __attribute__((address_space(3)))*)(a0 + 16 * XM_VS));
+            a = (bf16x8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = (short)sv[(g * 4 + j) * XM_VS + dt * 16 + r];
+                a[4 + j] = (short)sv[(16 + g * 4 + j) * XM_VS + dt * 16 + r];
+            }
+        }
+        f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        c = cw_mfma_16x16x32(a, pl, c);
+        c = cw_mfma_16x16x32(a, ph, c);
+        oc[dt] = c;                                               // query r, dims dt*16 + g*4 + i
+    }
+    // partial outputs of the wave over its own V image (wave-private; the LDS pipe keeps a wave's accesses in order)
+    float* red = (float*)sv;
+    if (r < nq) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(f32x4_t*)(red + r * 64 + dt * 16 + g * 4) = oc[dt];
+    }
+    __syncthreads();
+    for (int i = tid; i < nq * 64; i += CROSS_THREADS) {
+        const int q = i >> 6, c = i & 63;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc += ((const float*)(s_v + w * (32 * XM_VS)))[q * 64 + c];
+        p.part_o[((size_t)sp * p.B + b0 + q) * D + h * 64 + c] = acc;
+    }
+    if (tid < nq) {                                               // lane tid of wave 0: query r = tid, mx is that query's maximum
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) l += red_l[w * 16 + tid];
+        float* ml = p.part_ml + (((size_t)(b0 + tid) * p.H + h) * ATT_NS + sp) * 2;
+        ml[0] = mx; ml[1] = l;
+        if (slot >= 0) {
+            const size_t rowi = ((size_t)(b0 + tid) * p.n_align + slot) * p.align_rows + p.pos[b0 + tid];
+            p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l;
+        }
+    }
+}
+
 template <int NQ>
 static void launch_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
     dim3 grid(p.H, p.B / NQ, ATT_NS);
@@ -1117,6 +1291,8 @@ static void launch_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
     else hipLaunchKernelGGL((attn_cross_split_kernel<float, NQ, false>), grid, dim3(CROSS_THREADS), 0, st, p);
 }
 
+static int g_cross_valu = 0;
+void cw_cross_set_valu(int on) { g_cross_valu = on; }
 int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > 4 * (CROSS_THREADS / 8) || CROSS_THREADS != 512) return CW_ERR_INVALID;
     if (p.xstat || p.pstats) {   // fused out-projection / query stage: the query is finished in the kernel; 16-bit caches
@@ -1132,6 +1308,15 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
         return CW_OK;
     }
     static const bool per_row = getenv("CW_CROSS_PER_ROW") != nullptr;   // A/B: one block per row even under beam search
+    static const int valu = getenv("CW_CROSS_VALU") ? 1 : 0;             // A/B: instruction-bound 8-lane-group kernel for 2..6 rows per K/V
+    static const bool no_tr = getenv("CW_CROSS_NO_TR") != nullptr;       // A/B: 2-byte LDS reads instead of the transposing read
+    if (bf16 && p.kv_div > 1 && p.kv_div <= 16 && p.B % p.kv_div == 0 && !per_row && !(valu || g_cross_valu) &&
+        (p.n_keys + ATT_NS - 1) / ATT_NS <= 256) {
+        dim3 grid(p.H, p.B / p.kv_div, ATT_NS);
+        if (no_tr) hipLaunchKernelGGL((attn_cross_mfma_kernel<false>), grid, dim3(CROSS_THREADS), 0, st, p, p.kv_div);
+        else hipLaunchKernelGGL((attn_cross_mfma_kernel<true>), grid, dim3(CROSS_THREADS), 0, st, p, p.kv_div);
+        return CW_OK;
+    }
     const int nq = (p.kv_div > 1 && p.kv_div <= 6 && p.B % p.kv_div == 0 && !per_row) ? p.kv_div : 1;
     switch (nq) {
         case 2: launch_cross_split<2>(bf16, p, st); break;

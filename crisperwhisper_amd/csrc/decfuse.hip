@@ -709,4 +709,194 @@ int cw_launch_mlp_pair(const MlpPairParams& p, hipStream_t st) {
     return CW_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// gemv_rows_kernel: 17..64 rows (kernels.h: RowsParams).  grid N / 16, NW waves; wave w takes the 128-wide K steps w, w + NW, ..
+// of the WHOLE K (no K split, no atomics): all of the block's weights are requested before the first wait (NSLOT x 4
+// fragments of 16 B per lane), A fragments come straight from the fragment-major activations (L2 resident), the waves'
+// partial tiles meet in LDS.
+// ---------------------------------------------------------------------------------------------------
+template <int EPI, int MT, int NSLOT, int NW, bool PRODUCE, bool HILO>
+__global__ __launch_bounds__(NW * 64) void gemv_rows_kernel(RowsParams p) {
+    __shared__ float red[NW * MT * 4 * 64];
+    __shared__ float s_st[PRODUCE ? 1 : NW * 64 * 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int K = p.K, N = p.N;
+    const int n0 = blockIdx.x * 16;
+    const int steps = K >> 7, KS = K >> 5;
+    const int n = n0 + l15;
+    const int nc = n < N ? n : N - 1;
+    const bf16_t* W = (const bf16_t*)p.W;
+    const bool ln = !PRODUCE && p.ln_pstats != nullptr;
+    // consumer: this thread's share of the LayerNorm partial sums (row = lane, blocks wave, wave + NW, ..), requested first
+    float s1 = 0.f, s2 = 0.f;
+    if (ln) {
+        for (int b = wave; b < p.ln_nblk; b += NW) {
+            const float2 t = *(const float2*)(p.ln_pstats + ((size_t)b * 64 + lane) * 2);
+            s1 += t.x; s2 += t.y;
+        }
+    }
+    u32x4_t wq[NSLOT][4];
+    const bf16_t* wrow = W + (size_t)nc * K + g * 8;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        int step = wave + NW * s;
+        step = step < steps ? step : steps - 1;               // clamped (unconditional) load, zeroed below
+        const u32x4_t* wp = p.wpk ? (const u32x4_t*)(W + ((((size_t)(nc >> 4) * KS) + step * 4) * 64 + g * 16 + (nc & 15)) * 8)
+                                  : (const u32x4_t*)(wrow + step * 128);
+        const int sj = p.wpk ? 64 : 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * sj];
+    }
+    const float bias_v = p.ep.bias ? p.ep.bias[nc] : 0.f;
+    const float wsum_v = ln ? p.ln_wsum[nc] : 0.f;
+    if (ln) { s_st[(wave * 64 + lane) * 2] = s1; s_st[(wave * 64 + lane) * 2 + 1] = s2; }
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const u32x4_t* xq = (const u32x4_t*)p.xf;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const int step_raw = wave + NW * s;
+        const bool live = step_raw < steps;                    // wave-uniform
+        const int step = live ? step_raw : steps - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4_t w = wq[s][j];
+            if (!live) w = (u32x4_t){0u, 0u, 0u, 0u};          // a dead slot contributes exactly zero
+            const int ks = step * 4 + j;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const u32x4_t a = xq[((size_t)t * KS + ks) * 64 + lane];
+                if (HILO) {                                     // low halves first: the small terms meet before the large ones
+                    const u32x4_t al = xq[(size_t)p.lo_off + ((size_t)t * KS + ks) * 64 + lane];
+                    acc[t] = mfma16x(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, w), acc[t]);
+                }
+                acc[t] = mfma16x(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, w), acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * MT + t) * 4 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    const float inv_k = 1.0f / (float)K;
+    for (int idx = wave; idx < 4 * MT; idx += NW) {           // (row tile t, row r of the lane's group) pairs over the waves
+        const int t = idx >> 2, r = idx & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[((w * MT + t) * 4 + r) * 64 + lane];
+        const int m = t * 16 + g * 4 + r;
+        const bool live = m < p.Mb && n < N;
+        if (!PRODUCE) {
+            if (ln) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { a1 += s_st[(w * 64 + m) * 2]; a2 += s_st[(w * 64 + m) * 2 + 1]; }
+                const float mean = a1 * inv_k;
+                const float rstd = 1.0f / sqrtf(fmaxf(a2 * inv_k - mean * mean, 0.f) + 1e-5f);
+                v = (v - mean * wsum_v) * rstd;
+            }
+            if (live) {
+                EpiParams e2 = p.ep;
+                e2.bias = nullptr;
+                epi_store1<bf16_t, EPI>(e2, m, n, v + bias_v);
+            }
+        } else {
+            float xn = 0.f;
+            if (live) {
+                const size_t o = (size_t)m * p.ep.ldo + n;
+                xn = p.ep.resid[o] + (v + bias_v);
+                p.ep.outf[o] = xn;
+                const bf16_t hi = f32_to_bf16(xn);
+                ((bf16_t*)p.xf_out)[frag_index(m, n, N)] = hi;
+                if (p.lo_off) ((bf16_t*)p.xf_out)[(size_t)p.lo_off * 8 + frag_index(m, n, N)] = f32_to_bf16(xn - bf16_to_f32(hi));
+            }
+            float ps1 = xn, ps2 = xn * xn;                      // over the block's 16 columns: lane 15 of each row of lanes
+            ps1 += dpp_mov<0x111, 0xf>(0.f, ps1); ps2 += dpp_mov<0x111, 0xf>(0.f, ps2);
+            ps1 += dpp_mov<0x112, 0xf>(0.f, ps1); ps2 += dpp_mov<0x112, 0xf>(0.f, ps2);
+            ps1 += dpp_mov<0x114, 0xf>(0.f, ps1); ps2 += dpp_mov<0x114, 0xf>(0.f, ps2);
+            ps1 += dpp_mov<0x118, 0xf>(0.f, ps1); ps2 += dpp_mov<0x118, 0xf>(0.f, ps2);
+            if (l15 == 15 && m < p.Mb) *(float2*)(p.pstats_out + ((size_t)blockIdx.x * 64 + m) * 2) = make_float2(ps1, ps2);
+        }
+    }
+}
+
+// first rows of a decode step (token + position embedding, f32): 16-bit fragment-major copy + whole-row sums as ONE partial
+__global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict__ x, int K, bf16_t* __restrict__ xf,
+                                                        float* __restrict__ pstats, int lo_off) {
+    __shared__ float s_red[8];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = tid * 4; k < K; k += 1024) {
+        const float4 v = *(const float4*)(x + (size_t)m * K + k);
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        ushort4 o;
+        o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+        *(ushort4*)(xf + frag_index(m, k, K)) = o;
+        if (lo_off) {
+            ushort4 l;
+            l.x = f32_to_bf16(v.x - bf16_to_f32(o.x)); l.y = f32_to_bf16(v.y - bf16_to_f32(o.y));
+            l.z = f32_to_bf16(v.z - bf16_to_f32(o.z)); l.w = f32_to_bf16(v.w - bf16_to_f32(o.w));
+            *(ushort4*)(xf + (size_t)lo_off * 8 + frag_index(m, k, K)) = l;
+        }
+    }
+    s1 = block_sum(s1, s_red);
+    s2 = block_sum(s2, s_red);
+    if (tid == 0) *(float2*)(pstats + (size_t)m * 2) = make_float2(s1, s2);
+}
+
+int cw_launch_rows_prep(const float* x, int Mb, int K, void* xf, float* pstats, int lo_off, hipStream_t st) {
+    if (Mb < 1 || Mb > 64 || K % 32) return CW_ERR_INVALID;
+    hipLaunchKernelGGL(rows_prep_kernel, dim3(Mb), dim3(256), 0, st, x, K, (bf16_t*)xf, pstats, lo_off);
+    return CW_OK;
+}
+
+template <int EPI, int MT, bool PRODUCE>
+static int launch_rows_mt(const RowsParams& p, hipStream_t st) {
+    const int steps = p.K / 128;
+    const dim3 grid((p.N + 15) / 16);
+    const bool hilo = !PRODUCE && p.lo_off != 0;                 // consumers of a residual copy carried as hi + lo halves
+#define CW_ROWS(NS, NW)                                                                                                 \
+    do {                                                                                                                \
+        if (hilo) hipLaunchKernelGGL((gemv_rows_kernel<EPI, MT, NS, NW, PRODUCE, !PRODUCE>), grid, dim3(NW * 64), 0, st, p); \
+        else hipLaunchKernelGGL((gemv_rows_kernel<EPI, MT, NS, NW, PRODUCE, false>), grid, dim3(NW * 64), 0, st, p);    \
+    } while (0)
+    if (steps <= 4) CW_ROWS(1, 4);
+    else if (steps <= 8) CW_ROWS(2, 4);
+    else if (steps <= 12) CW_ROWS(3, 4);
+    else if (steps <= 16) CW_ROWS(2, 8);
+    else if (steps <= 24) CW_ROWS(3, 8);
+    else if (steps <= 32) CW_ROWS(4, 8);
+    else if (steps <= 40) CW_ROWS(5, 8);
+    else return CW_ERR_INVALID;
+#undef CW_ROWS
+    return CW_OK;
+}
+template <int EPI, bool PRODUCE>
+static int launch_rows(const RowsParams& p, hipStream_t st) {
+    const int MT = (p.Mb + 15) / 16;
+    if (MT == 2) return launch_rows_mt<EPI, 2, PRODUCE>(p, st);
+    if (MT == 3) return launch_rows_mt<EPI, 3, PRODUCE>(p, st);
+    return launch_rows_mt<EPI, 4, PRODUCE>(p, st);
+}
+
+int cw_launch_gemv_rows(int epi, bool produce, const RowsParams& p, hipStream_t st) {
+    if (p.Mb <= 16 || p.Mb > 64 || p.K % 128 || p.K > 5120 || p.N < 1 || !p.xf || !p.W) return CW_ERR_INVALID;
+    if (produce) {
+        if (epi != EPI_RESID_F32 || !p.xf_out || !p.pstats_out || !p.ep.outf || !p.ep.resid || p.N % 16) return CW_ERR_INVALID;
+        return launch_rows<EPI_RESID_F32, true>(p, st);
+    }
+    if (p.ln_pstats && (!p.ln_wsum || p.ln_nblk < 1)) return CW_ERR_INVALID;
+    switch (epi) {
+        case EPI_STORE_F32: return launch_rows<EPI_STORE_F32, false>(p, st);
+        case EPI_QKV_CACHE: return launch_rows<EPI_QKV_CACHE, false>(p, st);
+        case EPI_GELU_FRAG: return launch_rows<EPI_GELU_FRAG, false>(p, st);
+        default: return CW_ERR_INVALID;
+    }
+}
+
 }  // namespace CW_NS

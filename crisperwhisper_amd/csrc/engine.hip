@@ -40,6 +40,7 @@ struct LayerW {
     void *ws3 = nullptr, *ws5 = nullptr;
     float *qa_bias = nullptr, *q_wsum = nullptr;     // [D]  W'q_c bo ;  W'q_c 1
     float *u1_bias = nullptr, *u1_wsum = nullptr;    // [F]  W'1 bo_c ;  W'1 1
+    float* qkv_wsum = nullptr;                       // [3D] W'qkv 1 (17..64-row path: LayerNorm through its linearity)
 };
 
 struct cw_ctx {
@@ -61,6 +62,10 @@ struct cw_ctx {
     struct OutStage { float* stage; int layer, which; };   // f32 copies of the decoder out-projections (which: 0 self, 1 cross)
     std::vector<OutStage> out_stages;
     bool fuse6_ready = false;       // product matrices of the fused decoder stages are in place
+    bool rows_ln_ready = false;     // row sums of the LayerNorm-folded q/k/v, cross-q and fc1 weights are in place (gemv_rows_kernel)
+    bool rows_ln_enabled = true;    // CW_NO_ROWS_LN=1: 17..64 rows keep the preparation launch in front of every GEMV
+    bool rows_hilo = true;          // CW_NO_ROWS_HILO=1: single 16-bit copy of the residual rows (A/B)
+    float* d_rstats = nullptr;      // [max(D, F) / 16][64][2] per-block LayerNorm partial sums of the 17..64-row producers
     bool fuse6_enabled = true;      // CW_NO_FUSE6=1: eight launches per layer (A/B)
     bool fuse_mlp = false;          // CW_FUSE_MLP=1: also fuse cross out-projection + fc1 (six launches; measured slower, A/B)
     bool mlp_pair = false;          // CW_MLP_PAIR=1: fc1 + fc2 in one launch with an in-kernel group barrier (A/B: 23 us against 12.8 for two launches)
@@ -271,6 +276,8 @@ static int create_impl(cw_ctx* c) {
     if (getenv("CW_NO_GRAPH")) c->use_graph = false;
     if (getenv("CW_NO_LN_FOLD")) c->fold_enabled = false;
     if (getenv("CW_NO_FUSE6")) c->fuse6_enabled = false;
+    if (getenv("CW_NO_ROWS_LN")) c->rows_ln_enabled = false;
+    if (getenv("CW_NO_ROWS_HILO")) c->rows_hilo = false;
     if (getenv("CW_FUSE_MLP")) c->fuse_mlp = true;
     if (getenv("CW_NO_WPACK")) c->wpack_enabled = false;
     if (getenv("CW_MLP_PAIR")) c->mlp_pair = true;
@@ -316,6 +323,7 @@ static int create_impl(cw_ctx* c) {
             L.w1 = L.ws5;   L.wo_c = (char*)L.ws5 + (size_t)2 * F * D * e;
             CWCHK(c, dmalloc(c, &L.qa_bias, D * 4)); CWCHK(c, dmalloc(c, &L.q_wsum, D * 4));
             CWCHK(c, dmalloc(c, &L.u1_bias, F * 4)); CWCHK(c, dmalloc(c, &L.u1_wsum, F * 4));
+            CWCHK(c, dmalloc(c, &L.qkv_wsum, (size_t)3 * D * 4));
         } else {
             CWCHK(c, dmalloc(c, &L.wq_c, (size_t)D * D * e));
             CWCHK(c, dmalloc(c, &L.wo_c, (size_t)D * D * e));
@@ -403,6 +411,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->dx1, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dx2c, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->d_qa, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->d_qb, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->d_u1, (size_t)Bm * F * 4)); CWCHK(c, dmalloc(c, &c->d_pstats, (size_t)128 * 16 * 2 * 4));
+    CWCHK(c, dmalloc(c, &c->d_rstats, (size_t)((D > F ? D : F) / 16 + 1) * 64 * 2 * 4));
     CWCHK(c, dmalloc(c, &c->d_bar, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_err, 4));
     CWCHK(c, dmalloc(c, &c->d_xfrag, (size_t)64 * 5120 * 2));
     CWCHK(c, dmalloc(c, &c->d_xfrag2, (size_t)64 * 5120 * 2));
@@ -564,9 +573,21 @@ static int apply_folds(cw_ctx* c) {
             CWCHK(c, KD(c, cw_launch_fold_rowvec, f1->stage, L.ln2_g, f1->scale, L.bo_c, L.w1, F, D, L.u1_bias, L.u1_wsum, c->st));
         }
     }
+    // 17..64-row path: row sums of the folded 16-bit matrices (row-major here: packing comes after the folds)
+    bool rows_ok = !c->folds.empty() && c->bf16 && D % 128 == 0 && F % 128 == 0 && F <= 5120;
+    for (int l = 0; l < c->d.dec_layers && rows_ok; ++l) {
+        LayerW& L = c->dec[l];
+        if (!L.qkv_wsum || !L.q_wsum || !L.u1_wsum) { rows_ok = false; break; }
+        CWCHK(c, KD(c, cw_launch_fold_rowvec, nullptr, nullptr, 1.0f, nullptr, L.wqkv, 3 * D, D, nullptr, L.qkv_wsum, c->st));
+        if (!all) {
+            CWCHK(c, KD(c, cw_launch_fold_rowvec, nullptr, nullptr, 1.0f, nullptr, L.wq_c, D, D, nullptr, L.q_wsum, c->st));
+            CWCHK(c, KD(c, cw_launch_fold_rowvec, nullptr, nullptr, 1.0f, nullptr, L.w1, F, D, nullptr, L.u1_wsum, c->st));
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->st));
     KCHK(c);
     c->fuse6_ready = all;
+    c->rows_ln_ready = rows_ok;
     for (auto& f : c->folds) hipFree(f.stage);
     for (auto& o : c->out_stages) hipFree(o.stage);
     c->out_stages.clear();
@@ -899,12 +920,38 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 16 && c->beam_K == 0 && !c->kv8 &&
                       !((c->fuse_mlp || c->mlp_pair) && nb > 8);
     float *xin = c->dx, *xalt = c->dx1;
+    // 17..64 rows without preparation launches (decfuse.hip: gemv_rows_kernel): the residual GEMVs own whole columns and leave
+    // the stream in f32, its 16-bit fragment-major copy in d_xfrag and LayerNorm partial sums in d_rstats; the LayerNorm
+    // GEMVs read that copy and normalise their outputs.  d_xfrag2 carries attention outputs and the GELU'd MLP rows.
+    const bool rows = frag && c->rows_ln_ready && c->rows_ln_enabled && c->ln_folded;
+    int ln_nblk = 1;
+    // bf16 only: the 16-bit copy of the residual rows keeps 8 mantissa bits of values that are NOT normalised yet; carried as
+    // hi + lo halves (two MFMAs per fragment) the LayerNorm GEMVs see 16 bits, more than the rounded LN(x) of the prepared path
+    const int lo_off = (c->rows_hilo && !c->f16) ? 64 * (D / 8) : 0;
+    auto rows_consume = [&](int epi, const void* W, int N, const EpiParams& ep, const float* wsum) -> int {
+        RowsParams rp;
+        memset(&rp, 0, sizeof(rp));
+        rp.xf = c->d_xfrag; rp.W = W; rp.Mb = nb; rp.K = D; rp.N = N; rp.wpk = c->wpacked ? 1 : 0; rp.ep = ep;
+        rp.ln_pstats = c->d_rstats; rp.ln_nblk = ln_nblk; rp.ln_wsum = wsum; rp.lo_off = lo_off;
+        return KD(c, cw_launch_gemv_rows, epi, false, rp, c->st);
+    };
+    auto rows_produce = [&](const void* W, int K, const float* bias) -> int {   // x += W a + b over the rows in d_xfrag2
+        RowsParams rp;
+        memset(&rp, 0, sizeof(rp));
+        rp.xf = c->d_xfrag2; rp.W = W; rp.Mb = nb; rp.K = K; rp.N = D; rp.wpk = c->wpacked ? 1 : 0;
+        rp.ep = epi0(); rp.ep.outf = c->dx; rp.ep.resid = c->dx; rp.ep.bias = bias; rp.ep.ldo = D;
+        rp.xf_out = c->d_xfrag; rp.pstats_out = c->d_rstats; rp.lo_off = lo_off;
+        ln_nblk = D / 16;
+        return KD(c, cw_launch_gemv_rows, (int)EPI_RESID_F32, true, rp, c->st);
+    };
+    if (rows) CWCHK(c, KD(c, cw_launch_rows_prep, c->dx, nb, D, c->d_xfrag, c->d_rstats, lo_off, c->st));
     for (int l = 0; l < c->d.dec_layers; ++l) {
         LayerW& L = c->dec[l];
         {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
             EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
             ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
-            CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, xin, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep));
+            if (rows) CWCHK(c, rows_consume(EPI_QKV_CACHE, L.wqkv, 3 * D, ep, L.qkv_wsum));
+            else CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, xin, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep));
         }
         {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
@@ -984,12 +1031,14 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
-            if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
+            if (rows) CWCHK(c, rows_produce(L.wo, D, L.bo));
+            else if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));
         }
         {   // cross-attention: LN + q projection, attention over the cached encoder K/V
             EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
-            CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep));
+            if (rows) CWCHK(c, rows_consume(EPI_STORE_F32, L.wq_c, D, ep, L.q_wsum));
+            else CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep));
         }
         if (c->bf16) {
             // keys split over ATT_NS blocks per (row, head); the out-projection GEMV combines the partials
@@ -1003,7 +1052,10 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             } else CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CombineParams cb{c->d_part_ml, H, nb * D};
-            CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag, c->wpacked));
+            if (rows) {
+                CWCHK(c, KD(c, cw_launch_rows_combine, c->d_part_o, nb, D, cb, c->d_xfrag2, c->st));
+                CWCHK(c, rows_produce(L.wo_c, D, L.bo_c));
+            } else CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag, c->wpacked));
         } else {
             DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn, nb, H);
             p.align_out = c->d.n_align > 0 ? c->d_align : nullptr; p.align_slot = c->d_align_slot + (size_t)l * H;
@@ -1015,11 +1067,13 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
-            CWCHK(c, gemv_ln(c, frag ? EPI_GELU_FRAG : EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, c->ln_folded ? nullptr : L.ln2_b, ep));
+            if (rows) CWCHK(c, rows_consume(EPI_GELU_FRAG, L.w1, F, ep, L.u1_wsum));
+            else CWCHK(c, gemv_ln(c, frag ? EPI_GELU_FRAG : EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, c->ln_folded ? nullptr : L.ln2_b, ep));
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.b2; ep.ldo = D;
-            if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
+            if (rows) CWCHK(c, rows_produce(L.w2, F, L.b2));
+            else if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
         }
     }
@@ -1791,6 +1845,11 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
         c->nb_encoded = 0;                                   // windows must be re-encoded
         return CW_OK;
     }
+    if (!strcmp(name, "rows_ln")) {   // 17..64-row decode: 0 = preparation launch in front of every GEMV (A/B, differential tests)
+        c->rows_ln_enabled = value != 0;
+        for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // graphs hold the kernel choice
+        return CW_OK;
+    }
     return fail(c, CW_ERR_INVALID, "unknown option %s", name);
 }
 
@@ -1799,6 +1858,7 @@ int32_t cw_test_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "beam_topk_1block")) { cw_bf16::cw_beam_topk_set_1block(value); cw_f16::cw_beam_topk_set_1block(value); return CW_OK; }
     if (!strcmp(name, "gemm_pp")) { cw_bf16::cw_gemm_set_pp(value); cw_f16::cw_gemm_set_pp(value); return CW_OK; }
     if (!strcmp(name, "gemm_8ph")) { cw_bf16::cw_gemm_set_8ph(value); cw_f16::cw_gemm_set_8ph(value); return CW_OK; }
+    if (!strcmp(name, "cross_valu")) { cw_bf16::cw_cross_set_valu(value); cw_f16::cw_cross_set_valu(value); return CW_OK; }
     return CW_ERR_INVALID;
 }
 
@@ -1928,6 +1988,54 @@ int32_t cw_test_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, const floa
     }
     if (r == CW_OK) r = download_T(c, dout, 0, out, (size_t)B * S * H * 64);
     hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout);
+    return r;
+}
+
+// One launch of the key-split cross-attention decode kernel on caller-supplied rows: q [B][H*64] (already scaled), k / v
+// [B / kv_div][H][S][64].  part_o [ATT_NS][B][H*64] and part_ml [B][H][ATT_NS][2] come back raw (the consumer's combine is the
+// test's); head `align_head` is captured as alignment slot 0: align [B][S] un-normalised + align_ml [B][ATT_NS][2].
+int32_t cw_test_cross_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, int32_t kv_div, const float* q, const float* k,
+                                const float* v, int32_t align_head, float* part_o, float* part_ml, float* align, float* align_ml) {
+    if (B < 1 || H < 1 || S < 1 || kv_div < 1 || B % kv_div || align_head < 0 || align_head >= H) return fail(c, CW_ERR_INVALID, "test_cross_attention: shape");
+    const int Bk = B / kv_div, D = H * 64;
+    const size_t nkv = (size_t)Bk * H * S * 64;
+    float *dq = nullptr, *dpo = nullptr, *dml = nullptr, *dal = nullptr, *daml = nullptr; void *dk = nullptr, *dv = nullptr;
+    int *dslot = nullptr, *dpos = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dq, (size_t)B * D * 4)); HIPCHK(c, hipMalloc(&dk, nkv * c->esz)); HIPCHK(c, hipMalloc(&dv, nkv * c->esz));
+    HIPCHK(c, hipMalloc((void**)&dpo, (size_t)ATT_NS * B * D * 4)); HIPCHK(c, hipMalloc((void**)&dml, (size_t)B * H * ATT_NS * 2 * 4));
+    HIPCHK(c, hipMalloc((void**)&dal, (size_t)B * S * 4)); HIPCHK(c, hipMalloc((void**)&daml, (size_t)B * ATT_NS * 2 * 4));
+    HIPCHK(c, hipMalloc((void**)&dslot, (size_t)H * 4)); HIPCHK(c, hipMalloc((void**)&dpos, (size_t)B * 4));
+    std::vector<int> slot(H, -1); slot[align_head] = 0;
+    HIPCHK(c, hipMemcpy(dslot, slot.data(), (size_t)H * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(dpos, 0, (size_t)B * 4)); HIPCHK(c, hipMemset(dal, 0, (size_t)B * S * 4));
+    HIPCHK(c, hipMemcpy(dq, q, (size_t)B * D * 4, hipMemcpyHostToDevice));
+    CWCHK(c, upload_T(c, dk, 0, k, nkv)); CWCHK(c, upload_T(c, dv, 0, v, nkv));
+    CrossSplitParams p{};
+    p.q = dq; p.K = dk; p.V = dv; p.n_keys = S; p.part_o = dpo; p.part_ml = dml; p.align_out = dal; p.align_ml = daml;
+    p.align_slot = dslot; p.pos = dpos; p.n_align = 1; p.align_rows = 1; p.B = B; p.H = H; p.kv_div = kv_div;
+    int r = KD(c, cw_launch_attn_cross_split, c->bf16, p, c->st);
+    if (r != CW_OK) fail(c, r, "test_cross_attention: launch rejected (B=%d H=%d S=%d kv_div=%d)", B, H, S, kv_div);
+    if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_cross_attention: %s", hipGetErrorString(er)); }
+    if (const char* reps_s = getenv("CW_TEST_ATTN_REPS")) {   // kernel A/B timing for the profiles (stderr only)
+        const int reps = atoi(reps_s);
+        hipEvent_t e0, e1;
+        if (r == CW_OK && reps > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            hipEventRecord(e0, c->st);
+            for (int i = 0; i < reps && r == CW_OK; ++i) r = KD(c, cw_launch_attn_cross_split, c->bf16, p, c->st);
+            hipEventRecord(e1, c->st);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            fprintf(stderr, "[cw_test_cross_attention] B=%d H=%d S=%d kv_div=%d: %.2f us/launch\n", B, H, S, kv_div, 1e3 * ms / reps);
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+    }
+    if (r == CW_OK && (hipMemcpy(part_o, dpo, (size_t)ATT_NS * B * D * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                       hipMemcpy(part_ml, dml, (size_t)B * H * ATT_NS * 2 * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                       hipMemcpy(align, dal, (size_t)B * S * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                       hipMemcpy(align_ml, daml, (size_t)B * ATT_NS * 2 * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        r = fail(c, CW_ERR_HIP, "test_cross_attention copy");
+    hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dpo); hipFree(dml); hipFree(dal); hipFree(daml); hipFree(dslot); hipFree(dpos);
     return r;
 }
 

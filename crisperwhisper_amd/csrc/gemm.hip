@@ -1871,6 +1871,14 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
     return CW_OK;
 }
 
+// 17..64 rows: combine the key-split cross-attention partials into 16-bit fragment-major rows (the consumer is a
+// gemv_rows_kernel producer launched separately, decfuse.hip)
+int cw_launch_rows_combine(const float* part_o, int Mb, int K, const CombineParams& cb, void* xf, hipStream_t st) {
+    if (Mb < 1 || Mb > GV_MAXM || K % 128 || K > 5120 || !cb.part_ml || !xf) return CW_ERR_INVALID;
+    hipLaunchKernelGGL((gemv_prep_kernel<true>), dim3(Mb), dim3(256), 0, st, part_o, K, (const float*)nullptr, (const float*)nullptr, cb, (bf16_t*)xf);
+    return CW_OK;
+}
+
 int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
                    const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch, bool wpacked) {
     const int wpk = wpacked ? 1 : 0;

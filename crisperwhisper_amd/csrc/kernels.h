@@ -166,6 +166,26 @@ struct MlpPairParams {
     int wpk;               // W1 / W2 are fragment-major
 };
 
+// decfuse.hip: decode GEMV for 17..64 rows (beam search: items x hypotheses) without the per-GEMV preparation launch.
+// Activations are 16-bit MFMA fragment-major rows (common.h: frag_index).  A *producer* (residual epilogue, whole K per block,
+// no atomics) leaves three things: the f32 residual stream, its 16-bit fragment-major copy (NOT normalised) and per-block
+// partial sums (sum, sum of squares) of every row over the block's 16 columns.  A *consumer* multiplies the un-normalised copy by
+// LayerNorm-folded weights W' and applies the LayerNorm through its linearity,  out = rstd (W' x - mean W'1) + b',  with the
+// statistics summed from the producer's partials.
+struct RowsParams {
+    const void* xf;          // fragment-major 16-bit activations [ceil(Mb/16)][K/32][64][8]
+    const void* W;           // [N][K] 16-bit weights, row-major or fragment-major (wpk)
+    int Mb, K, N, wpk;
+    EpiParams ep;            // consumer: any GEMV epilogue; producer: outf / resid / bias / ldo of the residual stream
+    const float* ln_pstats;  // consumer: [ln_nblk][64][2] partial (sum, sum of squares) of the rows of x; null = plain GEMV
+    int ln_nblk;
+    const float* ln_wsum;    // consumer: [N] row sums of W'
+    int lo_off;              // != 0: the residual copy is carried as two 16-bit halves, x = hi + lo, the low halves lo_off
+                             // 16-byte fragments behind the high ones (consumer: reads xf; producer: writes xf_out)
+    void* xf_out;            // producer: fragment-major 16-bit copy of the new residual rows (K' = N)
+    float* pstats_out;       // producer: [N/16][64][2]
+};
+
 // mel.hip
 struct MelTables {
     const double* cos_t;  // [400]
@@ -183,6 +203,7 @@ struct MelTables {
     void cw_gemm_set_256_min_tiles(int n); \
     void cw_gemm_set_pp(int on); \
     void cw_gemm_set_8ph(int on); \
+    void cw_cross_set_valu(int on); \
     int cw_launch_layernorm_fp8(const float* x, const float* g, const float* b, void* out8, float* scale, int rows, int d, hipStream_t st); \
     int cw_launch_quant_rows_fp8(const void* x, int rows, int K, void* out8, float* scale, hipStream_t st); \
     int cw_launch_gemm_fp8(int epi, const void* A8, int lda, const void* W8, int M, int N, int K, const float* sa, const float* sw, const EpiParams& ep, hipStream_t st); \
@@ -195,6 +216,9 @@ struct MelTables {
     int cw_launch_gemv_stack(const StackParams& p, int nt, hipStream_t st); \
     int cw_launch_gemv_fc2x(const Fc2xParams& p, hipStream_t st); \
     int cw_launch_mlp_pair(const MlpPairParams& p, hipStream_t st); \
+    int cw_launch_gemv_rows(int epi, bool produce, const RowsParams& p, hipStream_t st); \
+    int cw_launch_rows_combine(const float* part_o, int Mb, int K, const CombineParams& cb, void* xf, hipStream_t st); \
+    int cw_launch_rows_prep(const float* x, int Mb, int K, void* xf, float* pstats, int lo_off, hipStream_t st); \
     int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d, hipStream_t st); \
     int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d, hipStream_t st); \
     int cw_launch_sample(const SampleParams& p, hipStream_t st); \

@@ -351,6 +351,27 @@ class Engine:
         self._chk(self.lib.cw_test_attention(self.ctx, B, H, S, _ptr(q), _ptr(k), _ptr(v), _ptr(out)))
         return out
 
+    def test_cross_attention(self, q, k, v, kv_div=1, align_head=0):
+        """One launch of the key-split cross-attention decode kernel (cw_test_cross_attention): q [B][H][64] pre-scaled,
+        k / v [B / kv_div][H][S][64].  Returns (out [B][H*64], align [B][S]) with the six splits combined on the host."""
+        q, k, v = (np.ascontiguousarray(t, np.float32) for t in (q, k, v))
+        B, H, _ = q.shape
+        S = k.shape[2]
+        NS = 6
+        po = np.zeros((NS, B, H * 64), np.float32); ml = np.zeros((B, H, NS, 2), np.float32)
+        al = np.zeros((B, S), np.float32); aml = np.zeros((B, NS, 2), np.float32)
+        self._chk(self.lib.cw_test_cross_attention(self.ctx, B, H, S, int(kv_div), _ptr(q), _ptr(k), _ptr(v), int(align_head),
+                                                   _ptr(po), _ptr(ml), _ptr(al), _ptr(aml)))
+        m = ml[..., 0].astype(np.float64); l = ml[..., 1].astype(np.float64)
+        M = m.max(-1, keepdims=True)
+        w = np.exp(m - M)                                            # [B][H][NS]
+        o = (po.astype(np.float64).reshape(NS, B, H, 64) * w.transpose(2, 0, 1)[..., None]).sum(0) / (l * w).sum(-1)[..., None]
+        per = (S + NS - 1) // NS
+        am = aml[..., 0].astype(np.float64); a_l = aml[..., 1].astype(np.float64)
+        AM = am.max(-1, keepdims=True); aw = np.exp(am - AM)
+        scale = np.repeat(aw, per, axis=1)[:, :S] / (a_l * aw).sum(-1, keepdims=True)
+        return o.reshape(B, H * 64), al.astype(np.float64) * scale
+
     def test_sample(self, logits: np.ndarray, ids: np.ndarray, n_prompt: int, min_new_tokens: int = 0,
                     max_length: Optional[int] = None) -> np.ndarray:
         """One launch of the fused logits processors + greedy choice on caller rows (cw_test_sample)."""

@@ -242,6 +242,14 @@ int32_t cw_test_gemv(cw_ctx* ctx, int32_t Mb, int32_t N, int32_t K, const float*
                      const float* bias, const float* ln_g, const float* ln_b, int32_t gelu, float* out);
 int32_t cw_test_attention(cw_ctx* ctx, int32_t B, int32_t H, int32_t S, const float* q, const float* k,
                           const float* v, float* out /* [B][S][H*64] */);
+/* One launch of the key-split cross-attention decode kernel (CW_ATT_SPLITS = 6 key splits): q [B][H*64] pre-scaled, k / v
+ * [B / kv_div][H][S][64] (kv_div rows share one K/V: the hypotheses of an audio item under beam search).  Raw outputs:
+ * part_o [6][B][H*64], part_ml [B][H][6][2] = (max, sum) per split; head `align_head` captured as the only alignment head:
+ * align [B][S] = exp(s - max of its split), align_ml [B][6][2].                                                     */
+#define CW_ATT_SPLITS 6
+int32_t cw_test_cross_attention(cw_ctx* ctx, int32_t B, int32_t H, int32_t S, int32_t kv_div, const float* q, const float* k,
+                                const float* v, int32_t align_head, float* part_o, float* part_ml, float* align,
+                                float* align_ml);
 /* One launch of the fused logits processors + greedy choice (MinNewTokensLength, SuppressTokensAtBegin, SuppressTokens,
  * WhisperTimeStamp: TF/generation/logits_process.py:203-260, 1816-2047; argmax TF/generation/utils.py:2925) on
  * caller-supplied rows: logits [nb][vocab], ids [nb][t] = prompt + tokens generated so far; choice_out [nb] = token for

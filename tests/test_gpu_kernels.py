@@ -184,6 +184,41 @@ def test_encoder_attention(engines, dt, tol, B, H, S):
     assert rel_err(got, ref) < tol, (dt, B, H, S, rel_err(got, ref))
 
 
+@pytest.mark.parametrize("dt,tol", [("bf16", 3e-5), ("f16", 3e-5), ("f32", 2e-5)])
+@pytest.mark.parametrize("B,H,S,kv_div,path", [(10, 3, 1500, 5, "mfma"), (10, 3, 1500, 5, "valu"), (4, 2, 1500, 1, "valu"),
+                                                (6, 2, 1500, 2, "mfma"), (16, 1, 1500, 16, "mfma"), (9, 2, 750, 3, "mfma"),
+                                                (5, 2, 50, 5, "mfma"), (12, 2, 1499, 6, "mfma"), (12, 2, 1499, 6, "valu")])
+def test_cross_attention_decode_kernels(engines, dt, tol, B, H, S, kv_div, path):
+    """Key-split cross-attention of the decode step: the matrix-core kernel the 16-bit engines use for 2..16 hypotheses per
+    K/V and the 8-lane-group kernel (one row per K/V; f32 engine; CW_CROSS_VALU) against float64 softmax attention on the same
+    16-bit K/V.  The query stays f32: the matrix-core kernel carries it as hi + lo 16-bit halves (tolerance 3e-5 = the
+    f32 kernel's, not a 16-bit one).  S = 50: splits with 9 keys, seven of the eight waves of a block without a key."""
+    from crisperwhisper_amd import _native
+    if dt == "f32" and (path == "mfma" or kv_div > 6):
+        pytest.skip("the f32 engine has the 8-lane-group kernel only")
+    if path == "valu" and kv_div > 6:
+        pytest.skip("8-lane-group kernel: up to 6 rows per K/V")
+    rng = np.random.default_rng(B * 1000 + S + kv_div)
+    q = (rng.standard_normal((B, H, 64)) * 0.35).astype(np.float32)
+    k = rng.standard_normal((B // kv_div, H, S, 64)).astype(np.float32)
+    v = rng.standard_normal((B // kv_div, H, S, 64)).astype(np.float32)
+    k[0, 0, S // 3] *= 4.0                       # a dominant key in one split
+    v *= np.linspace(0.5, 2.0, 64, dtype=np.float32)    # column-dependent scale: a transposed V fragment cannot pass
+    k, v = _round16(dt, k, v)
+    kk = np.repeat(k, kv_div, axis=0).astype(np.float64); vv = np.repeat(v, kv_div, axis=0).astype(np.float64)
+    s = np.einsum("bhd,bhkd->bhk", q.astype(np.float64), kk)
+    p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bhk,bhkd->bhd", p, vv).reshape(B, H * 64)
+    lib = _native.load()
+    assert lib.cw_test_set_option(b"cross_valu", 1 if path == "valu" else 0) == 0
+    try:
+        got, al = engines[dt].test_cross_attention(q, k, v, kv_div=kv_div, align_head=H - 1)
+    finally:
+        lib.cw_test_set_option(b"cross_valu", 0)
+    assert rel_err(got, ref) < tol, (dt, path, rel_err(got, ref))
+    assert np.abs(al - p[:, H - 1]).max() < tol, (dt, path, np.abs(al - p[:, H - 1]).max())
+
+
 @pytest.mark.parametrize("kind,n", [("noise", 480000), ("mixed", 320000), ("chirp", 480000), ("noise_short", 12345)])
 def test_mel_vs_golden_and_oracle(engines, kind, n):
     g = Hh.gold_npz("mel_golden.npz")
