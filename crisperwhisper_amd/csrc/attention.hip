@@ -630,6 +630,13 @@ __device__ inline void attn_decode_anc(const DecAttnParams& p, int h, int b) {
 }
 
 template <typename T>
+__global__ __launch_bounds__(DEC_THREADS) void attn_decode_anc_kernel(DecAttnParams p) { attn_decode_anc<T>(p, blockIdx.x, blockIdx.y); }
+
+// ANC (beam search): the first 128 keys go through the same register-resident path as the plain kernel -- the ancestor table
+// entries of a lane's two keys are fetched first (clamped to valid cache rows: entries beyond the current position are
+// stale), then K AND V rows, nothing depends on the device-side position -- and only longer histories or alignment capture
+// fall back to attn_decode_anc above (serial table lookups, scores through LDS: 9.6 us per layer at 8 items x 5 hypotheses).
+template <typename T, bool ANC>
 __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams p) {
     extern __shared__ float dsm[];          // scores [cap rounded] | red [DEC_GROUPS][64] | scratch [64]
     const int h = blockIdx.x, b = blockIdx.y;
@@ -642,20 +649,34 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
     const int bk = p.kv_div > 1 ? b / p.kv_div : b;
     const T* Kh = (const T*)p.K + ((size_t)bk * p.H + h) * p.cap * 64;
     const T* Vh = (const T*)p.V + ((size_t)bk * p.H + h) * p.cap * 64;
-    if (p.anc) { attn_decode_anc<T>(p, h, b); return; }
     float qv[8];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
+    int arow[DEC_PRE];
+    if (ANC) {
+#pragma unroll
+        for (int u = 0; u < DEC_PRE; ++u) arow[u] = p.anc[(size_t)b * p.cap + min(grp + u * DEC_GROUPS, p.cap - 1)];
+    }
     // The first DEC_PRE keys of every 8-lane group (128 keys in all: the whole self-attention history of a typical
     // decode) are fetched before anything else, K AND V, with the row clamped to the cache capacity instead of to
     // n_keys: the loads then depend neither on the device-side position nor on the softmax, which takes two memory
     // round trips (pos -> K rows, softmax -> V rows) out of this latency-bound kernel.  Rows >= n_keys hold stale but
     // addressable data and are masked out below.
     Raw8<T> kpre[DEC_PRE], vpre[DEC_PRE];
+    if (ANC) {
 #pragma unroll
-    for (int u = 0; u < DEC_PRE; ++u) kpre[u].ld(Kh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
+        for (int u = 0; u < DEC_PRE; ++u) {
+            const size_t ro = (((size_t)min(max(arow[u], 0), p.B - 1) * p.H + h) * p.cap + min(grp + u * DEC_GROUPS, p.cap - 1)) * 64 + sub * 8;
+            kpre[u].ld((const T*)p.K + ro);
+            vpre[u].ld((const T*)p.V + ro);
+        }
+    } else {
 #pragma unroll
-    for (int u = 0; u < DEC_PRE; ++u) vpre[u].ld(Vh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
+        for (int u = 0; u < DEC_PRE; ++u) kpre[u].ld(Kh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
+#pragma unroll
+        for (int u = 0; u < DEC_PRE; ++u) vpre[u].ld(Vh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
+    }
     const int n_keys = p.pos ? (p.n_keys > 0 ? p.n_keys : p.pos[b] + 1) : p.n_keys;
+    if (ANC && (n_keys > DEC_PRE * DEC_GROUPS || p.align_out)) { attn_decode_anc<T>(p, h, b); return; }
 
     if (n_keys <= DEC_PRE * DEC_GROUPS && !p.align_out) {
         // Short history (<= 128 keys: every key row is already in registers): scores stay in registers, the only block-wide
@@ -809,10 +830,17 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
 
 int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
     size_t lds = ((size_t)((p.cap + 63) & ~63) + DEC_GROUPS * 64 + 64) * sizeof(float);
-    if (bf16)
-        hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+    static const bool anc_v1 = getenv("CW_ANC_ATTN_V1") != nullptr;   // A/B: beam self-attention through the serial kernel only
+    if (p.anc && (anc_v1 || p.n_keys > 0 || !p.pos)) {
+        if (bf16) hipLaunchKernelGGL((attn_decode_anc_kernel<bf16_t>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+        else hipLaunchKernelGGL((attn_decode_anc_kernel<float>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+    } else if (p.anc) {
+        if (bf16) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, true>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+        else hipLaunchKernelGGL((attn_decode_kernel<float, true>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+    } else if (bf16)
+        hipLaunchKernelGGL((attn_decode_kernel<bf16_t, false>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
     else
-        hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+        hipLaunchKernelGGL((attn_decode_kernel<float, false>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
     return CW_OK;
 }
 

@@ -731,11 +731,14 @@ __global__ __launch_bounds__(NW * 64) void gemv_rows_kernel(RowsParams p) {
     const bool ln = !PRODUCE && p.ln_pstats != nullptr;
     // consumer: this thread's share of the LayerNorm partial sums (row = lane, blocks wave, wave + NW, ..), requested first
     float s1 = 0.f, s2 = 0.f;
-    if (ln) {
-        for (int b = wave; b < p.ln_nblk; b += NW) {
-            const float2 t = *(const float2*)(p.ln_pstats + ((size_t)b * 64 + lane) * 2);
-            s1 += t.x; s2 += t.y;
-        }
+    if (ln) {                                                  // all requests out before the first use (a rolled loop serialises them)
+        constexpr int PER = 80 / NW;                           // <= 80 producer blocks (d_model <= 1280)
+        float2 t[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) t[i] = *(const float2*)(p.ln_pstats + ((size_t)min(wave + NW * i, p.ln_nblk - 1) * 64 + lane) * 2);
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (wave + NW * i < p.ln_nblk) { s1 += t[i].x; s2 += t[i].y; }
     }
     u32x4_t wq[NSLOT][4];
     const bf16_t* wrow = W + (size_t)nc * K + g * 8;
@@ -890,7 +893,7 @@ int cw_launch_gemv_rows(int epi, bool produce, const RowsParams& p, hipStream_t 
         if (epi != EPI_RESID_F32 || !p.xf_out || !p.pstats_out || !p.ep.outf || !p.ep.resid || p.N % 16) return CW_ERR_INVALID;
         return launch_rows<EPI_RESID_F32, true>(p, st);
     }
-    if (p.ln_pstats && (!p.ln_wsum || p.ln_nblk < 1)) return CW_ERR_INVALID;
+    if (p.ln_pstats && (!p.ln_wsum || p.ln_nblk < 1 || p.ln_nblk > 80)) return CW_ERR_INVALID;
     switch (epi) {
         case EPI_STORE_F32: return launch_rows<EPI_STORE_F32, false>(p, st);
         case EPI_QKV_CACHE: return launch_rows<EPI_QKV_CACHE, false>(p, st);

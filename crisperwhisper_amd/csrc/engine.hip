@@ -63,7 +63,7 @@ struct cw_ctx {
     std::vector<OutStage> out_stages;
     bool fuse6_ready = false;       // product matrices of the fused decoder stages are in place
     bool rows_ln_ready = false;     // row sums of the LayerNorm-folded q/k/v, cross-q and fc1 weights are in place (gemv_rows_kernel)
-    bool rows_ln_enabled = true;    // CW_NO_ROWS_LN=1: 17..64 rows keep the preparation launch in front of every GEMV
+    bool rows_ln_enabled = false;   // CW_ROWS_LN=1 (A/B, measured slower): 17..64 rows without the preparation launch in front of every GEMV
     bool rows_hilo = true;          // CW_NO_ROWS_HILO=1: single 16-bit copy of the residual rows (A/B)
     float* d_rstats = nullptr;      // [max(D, F) / 16][64][2] per-block LayerNorm partial sums of the 17..64-row producers
     bool fuse6_enabled = true;      // CW_NO_FUSE6=1: eight launches per layer (A/B)
@@ -276,7 +276,7 @@ static int create_impl(cw_ctx* c) {
     if (getenv("CW_NO_GRAPH")) c->use_graph = false;
     if (getenv("CW_NO_LN_FOLD")) c->fold_enabled = false;
     if (getenv("CW_NO_FUSE6")) c->fuse6_enabled = false;
-    if (getenv("CW_NO_ROWS_LN")) c->rows_ln_enabled = false;
+    if (getenv("CW_ROWS_LN")) c->rows_ln_enabled = true;
     if (getenv("CW_NO_ROWS_HILO")) c->rows_hilo = false;
     if (getenv("CW_FUSE_MLP")) c->fuse_mlp = true;
     if (getenv("CW_NO_WPACK")) c->wpack_enabled = false;
@@ -923,7 +923,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     // 17..64 rows without preparation launches (decfuse.hip: gemv_rows_kernel): the residual GEMVs own whole columns and leave
     // the stream in f32, its 16-bit fragment-major copy in d_xfrag and LayerNorm partial sums in d_rstats; the LayerNorm
     // GEMVs read that copy and normalise their outputs.  d_xfrag2 carries attention outputs and the GELU'd MLP rows.
-    const bool rows = frag && c->rows_ln_ready && c->rows_ln_enabled && c->ln_folded;
+    const bool rows = frag && c->rows_ln_ready && c->rows_ln_enabled && c->ln_folded && D <= 1280;
     int ln_nblk = 1;
     // bf16 only: the 16-bit copy of the residual rows keeps 8 mantissa bits of values that are NOT normalised yet; carried as
     // hi + lo halves (two MFMAs per fragment) the LayerNorm GEMVs see 16 bits, more than the rounded LN(x) of the prepared path

@@ -1769,6 +1769,17 @@ static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, co
         while (tiles * ksplit < 256 && steps % (ksplit * 2) == 0 && steps / (ksplit * 2) >= 4) ksplit *= 2;
     }
     while (K / ksplit > 1280) ksplit *= 2;
+    // combining GEMV (cross-attention out-projection): a block's activation bytes are the ATT_NS partial planes of its K slice
+    // (8 rows x 640 x 4 B x 6 = 123 KB at large-v3 against 20 KB of weights).  Two column tiles per block over 256-wide K
+    // slices -- grid (40, 5) instead of (80, 2) -- bring the same weights with 49 KB of partials.
+    static const bool comb_nt2 = getenv("CW_NO_COMB_NT2") == nullptr;
+    if (comb_nt2 && EPI == EPI_RESID_F32 && cb.part_ml && !ln_g && ep.outf == ep.resid && K % 256 == 0 && K >= 512 && N % 32 == 0) {
+        const int ks = K / 256;
+        const size_t lds2 = (size_t)16 * (256 + 8) * 2 + 2 * 4 * 4 * 64 * 4;
+        hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, RPW, true, true, 1, 1, 2>), dim3(N / 32, ks), dim3(256), lds2, st,
+                           x, Mb, K, 256, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
+        return;
+    }
     const int Kb = K / ksplit;
     const size_t lds = (size_t)16 * (Kb + 8) * 2 + 4 * 4 * 64 * 4;
     dim3 grid((N + 15) / 16, ksplit);
