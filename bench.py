@@ -504,12 +504,16 @@ def main():
                 steps_per_call = a.tokens + 2            # prompt positions 0,1 + one forward per generated token
                 by = 1.812e9 + B * 245.76e6               # weights (bf16) + cross-K/V per step; self-K/V omitted
                 per_step_ms = ms / calls / steps_per_call
+                if a.num_beams > 1:                       # beam search: the stage timer brackets every cw_beam_step (one forward of B x beams rows)
+                    per_step_ms = ms / calls
                 # streamed = what the kernels actually read: the fused out-projection / cross-query stage (csrc/decfuse.hip) adds a
                 # d x d product matrix per layer to the weight stream; the fraction is quoted on the ALGORITHMIC bytes
                 streamed = by + (g.dec_layers * g.d_model * g.d_model * 2.0 if (a.dtype in ("bf16", "f16") and B <= 16 and a.num_beams == 1 and not os.environ.get("CW_NO_FUSE6")) else 0.0)
                 sr["decode_step"] = {"bound": "hbm", "algorithmic_bytes": by, "streamed_bytes": streamed, "ms_per_step": per_step_ms,
                                      "achieved_GBps": by / per_step_ms / 1e6, "frac_of_8TBps": by / per_step_ms / 1e6 / 8000.0,
-                                     "launches_per_layer": 7 if streamed > by else 8}
+                                     "launches_per_layer": 12 if a.num_beams > 1 and B * a.num_beams > 16 else (7 if streamed > by else 8)}
+                if a.num_beams > 1:
+                    sr["decode_step"]["rows"] = B * a.num_beams
             t = per_call("timestamps")
             if t:
                 by = 4.0 * 15 * a.tokens * 1500 * B

@@ -1144,11 +1144,11 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_full_kernel(CrossSpl
 // exponentials and nq x 250 x 64 multiply-adds per block in 8-lane groups: at 5 hypotheses it is instruction-bound (2600
 // instructions per wave, 25.8 us per layer against 13 us at one row for the same 61 MB of K/V).  Here a wave owns 32 consecutive
 // keys of the block's slice and
-//   * S^T = K Q^T is four 16x16x32 MFMAs per 16-key tile (A = the K rows as loaded from HBM, B = the queries; the queries are
-//     split q = hi + lo into two 16-bit numbers so the product keeps ~16 mantissa bits of the f32 query the VALU kernel used;
+//   * S^T = K Q^T is six 16x16x32 MFMAs per 16-key tile (A = the K rows as loaded from HBM, B = the queries; the queries are
+//     split q = hi + mid + lo into three 16-bit numbers so the product is that of the f32 query the VALU kernel used;
 //     the contraction index is permuted, dim = g*16 + s*8 + j, so that a lane's two K loads are 32 contiguous bytes),
 //   * the C fragment of S^T (lane: query l&15, keys g*4 .. g*4+3 of each tile) IS the B fragment of the second product
-//     O^T = V^T P^T under the key order (g*4+j of tile 0, then of tile 1): no cross-lane movement for P (again hi + lo),
+//     O^T = V^T P^T under the key order (g*4+j of tile 0, then of tile 1): no cross-lane movement for P (again three halves),
 //   * V^T comes out of a wave-private LDS image of the wave's 32 V rows (row-major as loaded, 144-byte rows) through
 //     `ds_read_b64_tr_b16`, the gfx950 transposing read: each 16-lane group hands the hardware four rows x 16 columns and gets
 //     column l&15 of them.
@@ -1156,12 +1156,18 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_full_kernel(CrossSpl
 // VALU kernel, so the out-projection's combine and align_normalize_kernel do not change.
 // ---------------------------------------------------------------------------------------------------
 #define XM_VS 72                                                  // V image row stride (elements): 16-byte aligned rows
-__device__ inline void split_hi_lo(const float* x, bf16x8_t& hi, bf16x8_t& lo) {
+// x = hi + mid + lo in the 16-bit type: 3 x 8 mantissa bits (bf16) cover the 24 of an f32, so the MFMAs below multiply by the f32
+// value the 8-lane-group kernel multiplies by (two halves leave 2^-17: enough for the tolerance, but the synthetic bench model's
+// beam search then parts from the other kernel's at near-ties; three halves agree to f32 summation order)
+__device__ inline void split3(const float* x, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const bf16_t h = f32_to_bf16(x[e]);
+        const float r1 = x[e] - bf16_to_f32(h);
+        const bf16_t m = f32_to_bf16(r1);
         hi[e] = (short)h;
-        lo[e] = (short)f32_to_bf16(x[e] - bf16_to_f32(h));
+        mid[e] = (short)m;
+        lo[e] = (short)f32_to_bf16(r1 - bf16_to_f32(m));
     }
 }
 typedef short xm_v4s __attribute__((ext_vector_type(4)));
@@ -1200,9 +1206,9 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma_kernel(CrossSpl
         qf[1][0] = q2.x * z; qf[1][1] = q2.y * z; qf[1][2] = q2.z * z; qf[1][3] = q2.w * z;
         qf[1][4] = q3.x * z; qf[1][5] = q3.y * z; qf[1][6] = q3.z * z; qf[1][7] = q3.w * z;
     }
-    bf16x8_t qh[2], ql[2];
-    split_hi_lo(qf[0], qh[0], ql[0]);
-    split_hi_lo(qf[1], qh[1], ql[1]);
+    bf16x8_t qh[2], qm[2], ql[2];
+    split3(qf[0], qh[0], qm[0], ql[0]);
+    split3(qf[1], qh[1], qm[1], ql[1]);
     // S^T: lane holds query r, keys kb + t*16 + g*4 + i
     f32x4_t st[2];
     float mx = -INFINITY;
@@ -1210,8 +1216,10 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma_kernel(CrossSpl
     for (int t = 0; t < 2; ++t) {
         f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, kf[t][0]), a1 = __builtin_bit_cast(bf16x8_t, kf[t][1]);
-        c = cw_mfma_16x16x32(a0, ql[0], c);
+        c = cw_mfma_16x16x32(a0, ql[0], c);                     // small terms first
         c = cw_mfma_16x16x32(a1, ql[1], c);
+        c = cw_mfma_16x16x32(a0, qm[0], c);
+        c = cw_mfma_16x16x32(a1, qm[1], c);
         c = cw_mfma_16x16x32(a0, qh[0], c);
         c = cw_mfma_16x16x32(a1, qh[1], c);
 #pragma unroll
@@ -1261,8 +1269,8 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma_kernel(CrossSpl
     lsum += __shfl_xor(lsum, 32, 64);
     if (g == 0) red_l[wave * 16 + r] = lsum;
     // O^T = V^T P^T: B fragment = the probabilities this lane already holds (k index g*8 + j <-> key g*4 + j of tile j / 4)
-    bf16x8_t ph, pl;
-    split_hi_lo(pr, ph, pl);
+    bf16x8_t ph, pm, pl;
+    split3(pr, ph, pm, pl);
     f32x4_t oc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -1282,6 +1290,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma_kernel(CrossSpl
         }
         f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         c = cw_mfma_16x16x32(a, pl, c);
+        c = cw_mfma_16x16x32(a, pm, c);
         c = cw_mfma_16x16x32(a, ph, c);
         oc[dt] = c;                                               // query r, dims dt*16 + g*4 + i
     }

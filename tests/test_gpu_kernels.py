@@ -184,15 +184,15 @@ def test_encoder_attention(engines, dt, tol, B, H, S):
     assert rel_err(got, ref) < tol, (dt, B, H, S, rel_err(got, ref))
 
 
-@pytest.mark.parametrize("dt,tol", [("bf16", 3e-5), ("f16", 3e-5), ("f32", 2e-5)])
+@pytest.mark.parametrize("dt,tol", [("bf16", 5e-6), ("f16", 5e-6), ("f32", 5e-6)])
 @pytest.mark.parametrize("B,H,S,kv_div,path", [(10, 3, 1500, 5, "mfma"), (10, 3, 1500, 5, "valu"), (4, 2, 1500, 1, "valu"),
                                                 (6, 2, 1500, 2, "mfma"), (16, 1, 1500, 16, "mfma"), (9, 2, 750, 3, "mfma"),
                                                 (5, 2, 50, 5, "mfma"), (12, 2, 1499, 6, "mfma"), (12, 2, 1499, 6, "valu")])
 def test_cross_attention_decode_kernels(engines, dt, tol, B, H, S, kv_div, path):
     """Key-split cross-attention of the decode step: the matrix-core kernel the 16-bit engines use for 2..16 hypotheses per
     K/V and the 8-lane-group kernel (one row per K/V; f32 engine; CW_CROSS_VALU) against float64 softmax attention on the same
-    16-bit K/V.  The query stays f32: the matrix-core kernel carries it as hi + lo 16-bit halves (tolerance 3e-5 = the
-    f32 kernel's, not a 16-bit one).  S = 50: splits with 9 keys, seven of the eight waves of a block without a key."""
+    16-bit K/V.  The query stays f32: the matrix-core kernel carries it (and the probabilities) as three 16-bit halves, so
+    both kernels are held to an f32 tolerance (5e-6), not a 16-bit one.  S = 50: splits with 9 keys, seven of the eight waves of a block without a key."""
     from crisperwhisper_amd import _native
     if dt == "f32" and (path == "mfma" or kv_div > 6):
         pytest.skip("the f32 engine has the 8-lane-group kernel only")
