@@ -1494,7 +1494,10 @@ __global__ __launch_bounds__(256) void gemv_prep_kernel(const float* __restrict_
     }
 }
 
-template <int EPI, int MT, bool ATOMIC, int NSLOT>
+// PREA (round 3): the activation fragments of all of the wave's K steps are requested up front as well (NSLOT x 4 x MT
+// fragments = up to 192 VGPRs; one wave per SIMD, the register file is there).  Fetched on demand inside the MFMA loop they
+// arrive a few at a time at L2 latency, and a 16-column block takes in three times as many activation bytes as weight bytes.
+template <int EPI, int MT, bool ATOMIC, int NSLOT, bool PREA = false>
 __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__ xf, int Mb, int K, int Kb,
                                                       const bf16_t* __restrict__ W, int N, EpiParams ep, int wpk) {
     __shared__ float red[4 * MT * 4 * 64];
@@ -1524,6 +1527,19 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const u32x4_t* xq = (const u32x4_t*)xf;
+    u32x4_t aq[PREA ? NSLOT : 1][4][MT];
+    if (PREA) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int step = wave + 4 * s;
+            step = step < steps ? step : steps - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) aq[s][j][t] = xq[((size_t)t * KS + (kbase >> 5) + step * 4 + j) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // every request is out before the first MFMA (hipcc otherwise sinks the loads to their uses)
+    }
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         const int step_raw = wave + 4 * s;
@@ -1536,7 +1552,7 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
             const int ks = (kbase >> 5) + step * 4 + j;
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                const u32x4_t a = xq[((size_t)t * KS + ks) * 64 + lane];
+                const u32x4_t a = PREA ? aq[PREA ? s : 0][j][t] : xq[((size_t)t * KS + ks) * 64 + lane];
                 acc[t] = mfma16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, w), acc[t]);
             }
         }
@@ -1819,13 +1835,20 @@ static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N
     const int Kb = K / ksplit;
     dim3 grid((N + 15) / 16, ksplit);
     const bool atomic = EPI == EPI_RESID_F32 && ksplit > 1;
+    static const bool prea = getenv("CW_MT_NO_PREA") == nullptr;   // A/B: activation fragments fetched on demand
 #define CW_MT_LAUNCH(NS)                                                                                              \
     do {                                                                                                              \
-        if (atomic)                                                                                                   \
-            hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, MT, true, NS>), grid, dim3(256), 0, st, xf, Mb, K, Kb,   \
+        if (atomic && prea)                                                                                           \
+            hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, MT, true, NS, true>), grid, dim3(256), 0, st, xf, Mb, K, Kb, \
+                               (const bf16_t*)W, N, ep, wpk);                                                         \
+        else if (atomic)                                                                                              \
+            hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, MT, true, NS, false>), grid, dim3(256), 0, st, xf, Mb, K, Kb, \
+                               (const bf16_t*)W, N, ep, wpk);                                                         \
+        else if (prea)                                                                                                \
+            hipLaunchKernelGGL((gemv_mt_kernel<EPI, MT, false, NS, true>), grid, dim3(256), 0, st, xf, Mb, K, Kb,      \
                                (const bf16_t*)W, N, ep, wpk);                                                         \
         else                                                                                                          \
-            hipLaunchKernelGGL((gemv_mt_kernel<EPI, MT, false, NS>), grid, dim3(256), 0, st, xf, Mb, K, Kb,            \
+            hipLaunchKernelGGL((gemv_mt_kernel<EPI, MT, false, NS, false>), grid, dim3(256), 0, st, xf, Mb, K, Kb,     \
                                (const bf16_t*)W, N, ep, wpk);                                                         \
     } while (0)
     const int steps = Kb / 128;

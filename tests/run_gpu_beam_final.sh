@@ -11,5 +11,7 @@ print(sys.argv[1], "ms_per_step", round(d["ms_per_step"], 1), "passes", d.get("p
       "decode ms per beam step", round(d["stage_roofline"]["decode_step"]["ms_per_step"], 3))
 P
 }
-run r2 CW_CROSS_VALU=1 CW_ANC_ATTN_V1=1 CW_NO_COMB_NT2=1
+run r2 CW_CROSS_VALU=1 CW_ANC_ATTN_V1=1 CW_MT_NO_PREA=1
 run r3 A=1
+run r3_noprea CW_MT_NO_PREA=1
+run r3_again A=1
