@@ -1332,6 +1332,8 @@ static int g_cross_valu = 0;
 void cw_cross_set_valu(int on) { g_cross_valu = on; }
 int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > 4 * (CROSS_THREADS / 8) || CROSS_THREADS != 512) return CW_ERR_INVALID;
+    // every key split must own at least one key (the kernels clamp their loads to the split's last key)
+    if (p.n_keys < 1 || (ATT_NS - 1) * ((p.n_keys + ATT_NS - 1) / ATT_NS) >= p.n_keys) return CW_ERR_INVALID;
     if (p.xstat || p.pstats) {   // fused out-projection / query stage: the query is finished in the kernel; 16-bit caches
         if (!bf16 || p.kv_div > 1 || p.H > 20 || !p.qa || !p.qb || !p.qw || !p.qbias) return CW_ERR_INVALID;
         if (p.a_out) {

@@ -219,6 +219,16 @@ def test_cross_attention_decode_kernels(engines, dt, tol, B, H, S, kv_div, path)
     assert np.abs(al - p[:, H - 1]).max() < tol, (dt, path, np.abs(al - p[:, H - 1]).max())
 
 
+def test_cross_attention_rejects_key_counts_that_leave_a_split_empty(engines):
+    """7 keys over 6 splits of ceil(7 / 6) = 2: splits 4 and 5 would own no key (the kernels clamp loads to the split's last key);
+    the launcher refuses instead of reading in front of the cache."""
+    from crisperwhisper_amd.engine import EngineError
+    z = np.zeros((2, 1, 64), np.float32)
+    kv = np.zeros((2, 1, 7, 64), np.float32)
+    with pytest.raises(EngineError):
+        engines["bf16"].test_cross_attention(z, kv, kv)
+
+
 @pytest.mark.parametrize("kind,n", [("noise", 480000), ("mixed", 320000), ("chirp", 480000), ("noise_short", 12345)])
 def test_mel_vs_golden_and_oracle(engines, kind, n):
     g = Hh.gold_npz("mel_golden.npz")
