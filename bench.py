@@ -133,6 +133,9 @@ def cpu_reference(geometry, n_tok, threads, timeout_s, style="aligned"):
     st = r["stage_s"]
     return {"value": r["words"] / r["wall_s"], "unit": "aligned words/s", "cores": r["threads"], "host_cpus": r["host_cpus"],
             "cpu_model": r["cpu_model"], "kind": "reference", "rtf": r["wall_s"] / r["audio_s"],
+            # seconds per probe for every torch thread count tried on this host ("gemm" = encoder-shaped, "gemv" = one decoder
+            # forward's op chain); the reference leg runs each stage at its fastest count, not at os.cpu_count()
+            "thread_calibration": r.get("thread_calibration") or None,
             "sample": f"1 x 30 s clip (bench clip 0) through transformers.pipeline('automatic-speech-recognition', chunk_length_s=30, "
                       f"batch_size=1, return_timestamps='word', fp32, device='cpu') + adjust_pauses, greedy, {n_tok} tokens per generate "
                       f"call, torch threads {r.get('threads_encoder')} (encoder) / {r.get('threads_decoder')} (decoder), calibrated, of {r['host_cpus']} host CPUs: {r['wall_s']:.1f} s wall for {r['words']} words (encoder {st['encoder']:.1f} s in "

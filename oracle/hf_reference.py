@@ -67,7 +67,7 @@ def cpu_model_name() -> str:
     return "unknown"
 
 
-def calibrate_threads(d_model: int, ffn: int, candidates=(2, 4, 8, 16, 32, 64, 128, 256)):
+def calibrate_threads(d_model: int, ffn: int, candidates=(2, 4, 8, 16, 32, 64, 128, 256), table=None):
     """torch intra-op thread counts that serve the reference best on this host: one for GEMM-shaped work (the encoder:
     [1500 x d] @ [d x ffn]) and one for the M = 1 decoder steps (LayerNorm + GEMV chains streaming weights that do not fit
     the caches -- 16 distinct [ffn x d] matrices are cycled; such steps stop scaling, and on oversubscribed or
@@ -107,6 +107,8 @@ def calibrate_threads(d_model: int, ffn: int, candidates=(2, 4, 8, 16, 32, 64, 1
                 if len(res) >= 2 and dt > 3 * min(r[0] for r in res):     # past the knee: stop before the pathological counts
                     break
             best[kind] = min(res)[1]
+            if table is not None:                              # [[threads, seconds per probe], ...] as measured, for the bench line
+                table[kind] = [[c, round(dt, 4)] for dt, c in res]
     return best["gemm"], best["gemv"]
 
 
@@ -123,10 +125,11 @@ def time_reference_pipeline(geom, vocab, tensors, audio: np.ndarray, n_tok: int,
     from oracle import pauses as OP
     transformers.logging.set_verbosity_error()
     from tests.golden import hf_synth as H
+    calib = {}
     if threads:
         t_enc = t_dec = int(threads)
     else:
-        t_enc, t_dec = calibrate_threads(geom.d_model, geom.ffn)
+        t_enc, t_dec = calibrate_threads(geom.d_model, geom.ffn, table=calib)
     torch.set_num_threads(t_enc)
     t0 = time.perf_counter()
     model = build_model_fast(geom, vocab, tensors, n_align)
@@ -161,7 +164,7 @@ def time_reference_pipeline(geom, vocab, tensors, audio: np.ndarray, n_tok: int,
     res = OP.adjust_pauses_for_hf_pipeline_output(res)
     wall = time.perf_counter() - t0
     return {"wall_s": wall, "words": len(res["chunks"]), "audio_s": len(audio) / 16000.0, "threads": max(t_enc, t_dec),
-            "threads_encoder": t_enc, "threads_decoder": t_dec,
+            "threads_encoder": t_enc, "threads_decoder": t_dec, "thread_calibration": calib,
             "build_s": t_build, "stage_s": {k: round(v, 3) for k, v in stage.items()}, "stage_calls": calls,
             "text": res["text"], "chunks": res["chunks"]}
 
