@@ -491,8 +491,7 @@ __global__ __launch_bounds__(256) void beam_topk_partial_kernel(SampleParams p, 
     const int ts_floor = (last_tok >= 0) ? ((last_ts && !penult_ts) ? last_tok : last_tok + 1) : tb;
     const bool at_begin = (n_gen == 0);
     const int ts_cap = (at_begin && p.max_initial_timestamp_index >= 0) ? tb + p.max_initial_timestamp_index : 0x7fffffff;
-    auto dead = [&](int v) -> bool {
-        const unsigned char mk = p.mask[v];
+    auto dead = [&](int v, unsigned char mk) -> bool {
         bool d = (mk & 1) || (at_begin && (mk & 2));
         d |= (v == p.eos && n_gen < min_new_tokens);
         if (last_ts) d |= penult_ts ? (v >= tb) : (v < p.eos);
@@ -503,36 +502,64 @@ __global__ __launch_bounds__(256) void beam_topk_partial_kernel(SampleParams p, 
     const int per = (p.V + BT_NS - 1) / BT_NS;
     const int lo = sl * per, hi = min(p.V, lo + per);
     float x[BT_PER_LANE];        // allowed value, -inf when dead or out of range
+    float rawv[BT_PER_LANE];     // the logit itself (-inf out of range)
+    unsigned char mkv[BT_PER_LANE];
     float rmax = -INFINITY, btext = -INFINITY, bts = -INFINITY;
+    // every load of the block first, unconditional with a clamped index: behind `if (v < hi)` each logit and each mask byte was
+    // its own exec-masked block with its own wait -- 26 memory round trips in a row, 46 us for a 200 KB slice
+#pragma unroll
+    for (int i = 0; i < BT_PER_LANE; ++i) {
+        const int vc = min(lo + tid + i * 256, hi - 1);
+        rawv[i] = lg[vc];
+        mkv[i] = p.mask[vc];
+    }
 #pragma unroll
     for (int i = 0; i < BT_PER_LANE; ++i) {
         const int v = lo + tid + i * 256;
         float raw = -INFINITY;
         x[i] = -INFINITY;
         if (v < hi) {
-            raw = lg[v];
-            if (!dead(v)) x[i] = raw;
+            raw = rawv[i];
+            if (!dead(v, mkv[i])) x[i] = raw;
         }
+        rawv[i] = raw;
         rmax = fmaxf(rmax, raw);
         if (v < tb) btext = fmaxf(btext, x[i]); else bts = fmaxf(bts, x[i]);
     }
-    rmax = block_max(rmax, s_f); __syncthreads();
-    btext = block_max(btext, s_f); __syncthreads();
-    bts = block_max(bts, s_f); __syncthreads();
+    // the three maxima in one exchange, the two sums in another (each was its own block reduction: 15 barriers of this
+    // latency-bound kernel; the sums add the waves' partials in the same order as block_sum, so the records are unchanged)
+    __shared__ float s_mx[3][4], s_sm[2][4];
+    rmax = wave_max(rmax); btext = wave_max(btext); bts = wave_max(bts);
+    if (lane == 0) { s_mx[0][wave] = rmax; s_mx[1][wave] = btext; s_mx[2][wave] = bts; }
+    __syncthreads();
+    rmax = fmaxf(fmaxf(s_mx[0][0], s_mx[0][1]), fmaxf(s_mx[0][2], s_mx[0][3]));
+    btext = fmaxf(fmaxf(s_mx[1][0], s_mx[1][1]), fmaxf(s_mx[1][2], s_mx[1][3]));
+    bts = fmaxf(fmaxf(s_mx[2][0], s_mx[2][1]), fmaxf(s_mx[2][2], s_mx[2][3]));
     float rsum = 0.f, tsum = 0.f;
 #pragma unroll
     for (int i = 0; i < BT_PER_LANE; ++i) {
         const int v = lo + tid + i * 256;
         if (v < hi) {
-            rsum += expf(lg[v] - rmax);
+            rsum += expf(rawv[i] - rmax);
             if (v >= tb && x[i] > -INFINITY) tsum += expf(x[i] - bts);
         }
     }
-    rsum = block_sum(rsum, s_f); __syncthreads();
-    tsum = block_sum(tsum, s_f); __syncthreads();
+    rsum = wave_sum(rsum); tsum = wave_sum(tsum);
+    if (lane == 0) { s_sm[0][wave] = rsum; s_sm[1][wave] = tsum; }
+    __syncthreads();
+    rsum = 0.f; tsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { rsum += s_sm[0][w]; tsum += s_sm[1][w]; }
     float* rec = scratch + ((size_t)b * BT_NS + sl) * BT_REC;
     if (tid == 0) { rec[0] = rmax; rec[1] = rsum; rec[2] = btext; rec[3] = bts; rec[4] = tsum; }
     // two lists (text tokens, timestamp tokens), each n_cand rounds of block-wide selection in (value desc, token asc) order
+    __shared__ float s_sf[2][4];                                             // selection rounds alternate between two exchange
+    __shared__ int s_si[2][4];                                               // buffers: one barrier per round instead of two
+    // the winners of the rounds are collected in LDS and written out once per list: a global store inside the round made the
+    // round's barrier wait for it (vmcnt(0) in front of every s_barrier), a memory round trip per candidate
+    __shared__ float s_lv[2][64];
+    __shared__ int s_li[2][64];
+    int rr = 0;
     for (int list = 0; list < 2; ++list) {
         float* lv = rec + 8 + list * 128;
         int* li = (int*)(lv + 64);
@@ -540,6 +567,8 @@ __global__ __launch_bounds__(256) void beam_topk_partial_kernel(SampleParams p, 
             for (int r = tid; r < n_cand; r += 256) { lv[r] = -INFINITY; li[r] = -1; }
             continue;
         }
+        for (int r = tid; r < n_cand; r += 256) { s_lv[list][r] = -INFINITY; s_li[list][r] = -1; }   // rounds that never run: padding
+        __syncthreads();
         ArgPair prev = {INFINITY, -1};
         for (int r = 0; r < n_cand; ++r) {
             ArgPair best = {-INFINITY, 0x7fffffff};
@@ -551,20 +580,19 @@ __global__ __launch_bounds__(256) void beam_topk_partial_kernel(SampleParams p, 
                 if (kind && after && x[i] > -INFINITY) best = arg_better(best, ArgPair{x[i], v});
             }
             best = wave_argmax(best);
-            __syncthreads();
-            if (lane == 0) { s_f[wave] = best.v; s_i[wave] = best.i; }
+            const int bufI = rr & 1; ++rr;
+            if (lane == 0) { s_sf[bufI][wave] = best.v; s_si[bufI][wave] = best.i; }
             __syncthreads();
             best = {-INFINITY, 0x7fffffff};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) best = arg_better(best, ArgPair{s_f[w], s_i[w]});
+            for (int w = 0; w < 4; ++w) best = arg_better(best, ArgPair{s_sf[bufI][w], s_si[bufI][w]});
             const bool ok = best.v > -INFINITY;
-            if (tid == 0) { lv[r] = ok ? best.v : -INFINITY; li[r] = ok ? best.i : -1; }
+            if (tid == 0 && ok) { s_lv[list][r] = best.v; s_li[list][r] = best.i; }
             prev = best;
-            if (!ok) {                                                       // fewer allowed tokens than n_cand: pad the rest
-                for (int r2 = r + 1 + tid; r2 < n_cand; r2 += 256) { lv[r2] = -INFINITY; li[r2] = -1; }
-                break;
-            }
+            if (!ok) break;                                                  // fewer allowed tokens than n_cand: the rest stays padded
         }
+        __syncthreads();
+        for (int r = tid; r < n_cand; r += 256) { lv[r] = s_lv[list][r]; li[r] = s_li[list][r]; }
     }
 }
 
