@@ -82,6 +82,10 @@ _SIGS = {
     "cw_vocab_create": (_P, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "cw_vocab_destroy": (None, [_P]),
     "cw_collate_begin": (_P, [_P, C.c_double]),
+    "cw_beam_host_new": (_P, [_I, _I, _I, _I, _I, _I, _I, C.c_double, _I, _P]),
+    "cw_beam_host_step": (_I, [_P, _P, _P, _P, _P]),
+    "cw_beam_host_result": (_I, [_P, _P, _P, _P]),
+    "cw_beam_host_free": (None, [_P]),
     "cw_collate_set_mode": (_I, [_P, _I]),
     "cw_collate_feed": (_I, [_P, _P, _I, _P, _I, _I, C.c_double, C.c_double, C.c_double]),
     "cw_collate_finish": (_I, [_P, _P, _P, _P, _P]),

@@ -189,6 +189,20 @@ int32_t cw_beam_step(cw_ctx* ctx, int32_t n_cand, float* cand_logprob, int32_t* 
 int32_t cw_beam_advance(cw_ctx* ctx, const int32_t* parent, const int32_t* token);
 int32_t cw_beam_finish(cw_ctx* ctx, int32_t n_items, int32_t L, const int32_t* row_of_pos);
 
+/* Host half of the same search (running / finished hypotheses, length penalty, early-stopping heuristic:
+ * TF/generation/utils.py:3147, 3173-3245, 3009-3053; float32 like HF), host-only C++: no cw_ctx, no GPU.  Per decoder step:
+ *   cw_beam_step -> cw_beam_host_step (candidates in, parent / token out; 1 = go on, 0 = search over) -> cw_beam_advance.
+ * cw_beam_host_result: best hypothesis per item -- sequences [n_items][max_length] (pad / eos filled), beam_indices
+ * [n_items][max_length - n_prompt] (flat row of every generated position, -1 behind the end), its score.               */
+typedef struct cw_beam_host cw_beam_host;
+cw_beam_host* cw_beam_host_new(int32_t n_items, int32_t num_beams, int32_t n_prompt, int32_t max_length, int32_t vocab_size,
+                               int32_t eos_token_id, int32_t pad_token_id, double length_penalty, int32_t early_stopping,
+                               const int32_t* prompt /* [n_items][n_prompt] */);
+int32_t cw_beam_host_step(cw_beam_host* s, const float* cand_logprob, const int32_t* cand_token /* [rows][2 * num_beams] */,
+                          int32_t* parent, int32_t* token /* [rows] */);
+int32_t cw_beam_host_result(const cw_beam_host* s, int64_t* sequences, int32_t* beam_indices, float* score);
+void cw_beam_host_free(cw_beam_host* s);
+
 /* cw_token_timestamps: _extract_token_timestamps (generation_whisper.py:241-381) on the retained rows:
  * crop to num_frames[b]//2 encoder frames, drop the n_prompt prompt rows, z-score over tokens, median
  * filter, head mean, DTW, jump times.  L = rows retained = max(lengths) - 1.  ts_out [nb][L+1] seconds. */

@@ -143,6 +143,55 @@ static void fuzz_collate(const Vocab& V, int iters) {
     }
 }
 
+// host half of beam search (csrc/beamhost.cpp): random geometries and candidate streams, now and then a token past the
+// vocabulary or a NaN (must be refused with the state untouched), results read back after every outcome
+static long g_beam_runs = 0, g_beam_rejects = 0;
+static void fuzz_beam_host(int iters) {
+    for (int it = 0; it < iters; ++it) {
+        const int B = 1 + (int)below(4), K = 1 + (int)below(6), n_prompt = 1 + (int)below(4), V = 2 + (int)below(200);
+        const int max_length = n_prompt + 1 + (int)below(20), keep = 2 * K, rows = B * K;
+        const int eos = (int)below((uint32_t)V), pad = below(3) ? (int)below((uint32_t)V) : 0;
+        std::vector<int32_t> prompt((size_t)B * n_prompt);
+        for (auto& p : prompt) p = (int32_t)below((uint32_t)V);
+        if (below(20) == 0) {   // invalid geometry must give no object
+            if (cw_beam_host_new(B, K, n_prompt, n_prompt, V, eos, pad, 1.0, 0, prompt.data())) { fprintf(stderr, "bad geometry accepted\n"); exit(7); }
+            continue;
+        }
+        cw_beam_host* s = cw_beam_host_new(B, K, n_prompt, max_length, V, eos, pad, below(2) ? 1.0 : 0.1 * (double)below(30), (int32_t)below(2), prompt.data());
+        if (!s) { fprintf(stderr, "cw_beam_host_new failed\n"); exit(7); }
+        std::vector<float> val((size_t)rows * keep);
+        std::vector<int32_t> tok((size_t)rows * keep), parent((size_t)rows), token((size_t)rows);
+        ++g_beam_runs;
+        for (int step = 0; step < max_length + 2; ++step) {     // two calls past the end: CW_ERR_STATE, not a write past max_length
+            bool hostile = false;
+            for (int r = 0; r < rows; ++r) {
+                float v = -(float)below(8) * 0.25f;
+                const int npad = below(6) ? 0 : (int)below((uint32_t)keep + 1);
+                for (int j = 0; j < keep; ++j) {
+                    v -= (float)below(4) * 0.25f;
+                    const size_t i = (size_t)r * keep + j;
+                    val[i] = v; tok[i] = below(8) == 0 ? eos : (int32_t)below((uint32_t)V);
+                    if (j >= keep - npad) { val[i] = -INFINITY; tok[i] = -1; }
+                    if (below(2000) == 0) { val[i] = NAN; hostile = true; }
+                    if (below(2000) == 0) { tok[i] = V + (int32_t)below(1000); hostile = true; }
+                }
+            }
+            const int32_t rc = cw_beam_host_step(s, val.data(), tok.data(), parent.data(), token.data());
+            if (hostile) { if (rc >= 0) { fprintf(stderr, "hostile candidates accepted (%d)\n", rc); exit(7); } ++g_beam_rejects; continue; }
+            if (rc < 0 && step < max_length - n_prompt) { fprintf(stderr, "cw_beam_host_step failed early (%d)\n", rc); exit(7); }
+            if (rc == 1)
+                for (int r = 0; r < rows; ++r)
+                    if (parent[r] / K != r / K || token[r] < 0 || token[r] >= V) { fprintf(stderr, "parent / token out of range\n"); exit(7); }
+            if (rc == 0 && below(2)) break;                      // sometimes keep calling after the search is over
+        }
+        std::vector<int64_t> seq((size_t)B * max_length);
+        std::vector<int32_t> bi((size_t)B * (max_length - n_prompt));
+        std::vector<float> score((size_t)B);
+        if (cw_beam_host_result(s, seq.data(), bi.data(), score.data()) != 0) { fprintf(stderr, "cw_beam_host_result failed\n"); exit(7); }
+        cw_beam_host_free(s);
+    }
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 2000;
     g_state = argc > 2 ? (uint64_t)atoll(argv[2]) : 1;
@@ -153,6 +202,8 @@ int main(int argc, char** argv) {
     if (!V.v) { fprintf(stderr, "cw_vocab_create failed\n"); return 6; }
     fuzz_collate(V, iters / 4 + 1);
     cw_vocab_destroy(V.v);
-    printf("fuzz_host: %ld FLAC streams decoded, %ld rejected, %d collator runs, no sanitizer report\n", g_flac_ok, g_flac_err, iters / 4 + 1);
+    fuzz_beam_host(iters / 4 + 1);
+    printf("fuzz_host: %ld FLAC streams decoded, %ld rejected, %d collator runs, %ld beam searches (%ld hostile steps refused), no sanitizer report\n",
+           g_flac_ok, g_flac_err, iters / 4 + 1, g_beam_runs, g_beam_rejects);
     return 0;
 }

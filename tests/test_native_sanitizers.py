@@ -1,6 +1,7 @@
-"""Host-only half of the C ABI (word collator, FLAC decoder) under AddressSanitizer + UndefinedBehaviorSanitizer:
-tests/native/fuzz_host.cpp is compiled together with csrc/collate.cpp and csrc/flac.cpp (plain g++, no HIP) and fed mutated
-FLAC streams, noise and random token streams.  SURVEY.md section 5 lists a sanitizer build of the C ABI among the reference-side
+"""Host-only half of the C ABI (word collator, FLAC decoder, beam-search bookkeeping) under AddressSanitizer +
+UndefinedBehaviorSanitizer: tests/native/fuzz_host.cpp is compiled together with csrc/collate.cpp, csrc/flac.cpp and
+csrc/beamhost.cpp (plain g++, no HIP) and fed mutated FLAC streams, noise, random token streams and random / hostile beam
+candidates.  SURVEY.md section 5 lists a sanitizer build of the C ABI among the reference-side
 auxiliaries; the container parsers are the part of this library that reads untrusted bytes."""
 import os
 import shutil
@@ -36,7 +37,7 @@ def _valid_flac_streams():
 def test_host_c_abi_under_asan_ubsan(tmp_path):
     exe = tmp_path / "fuzz_host"
     src = [os.path.join(ROOT, "tests", "native", "fuzz_host.cpp"), os.path.join(ROOT, "crisperwhisper_amd", "csrc", "collate.cpp"),
-           os.path.join(ROOT, "crisperwhisper_amd", "csrc", "flac.cpp")]
+           os.path.join(ROOT, "crisperwhisper_amd", "csrc", "flac.cpp"), os.path.join(ROOT, "crisperwhisper_amd", "csrc", "beamhost.cpp")]
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
            *src, "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True)
