@@ -1041,20 +1041,25 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_full_kernel(CrossSpl
     constexpr int G = CROSS_THREADS / 8;                       // 64 key groups
     float4 xrow[5];
     float qa1 = 0.f, qb1 = 0.f, qw1 = 0.f, qc1 = 0.f;
-    if (wave == 0) {                                            // wave-uniform
+    if (wave == 0 && p.xstat) {                                 // wave-uniform
         const float* xr = p.xstat + (size_t)b * Dm;
 #pragma unroll
         for (int c = 0; c < 5; ++c) xrow[c] = *(const float4*)(xr + (size_t)min(lane + 64 * c, nvec - 1) * 4);
         const size_t col = (size_t)h * 64 + lane;
-        qa1 = p.qa[(size_t)b * Dm + col]; qb1 = p.qb[(size_t)b * Dm + col];
+        qa1 = p.qa[(size_t)b * Dm + col];
+        for (int sI = 1; sI < p.q_planes; ++sI) qa1 += p.qa[(size_t)sI * p.q_plane_stride + (size_t)b * Dm + col];   // K-split planes (skinny.hip), slice order
+        qb1 = p.qb ? p.qb[(size_t)b * Dm + col] : 0.f;
         qw1 = p.qw[col]; qc1 = p.qbias[col];
+    } else if (wave == 0) {
+        qa1 = p.q[(size_t)b * Dm + h * 64 + lane];              // finished query
     }
     Raw8<T> kr[CROSSF_U], vr[CROSSF_U];
 #pragma unroll
     for (int u = 0; u < CROSSF_U; ++u) kr[u].ld(Kh + (size_t)min(grp + u * G, nk - 1) * 64);   // unconditional, clamped
 #pragma unroll
     for (int u = 0; u < CROSSF_U; ++u) vr[u].ld(Vh + (size_t)min(grp + u * G, nk - 1) * 64);
-    if (wave == 0) {
+    if (wave == 0 && !p.xstat) s_q[lane] = qa1;
+    if (wave == 0 && p.xstat) {
         float sx = 0.f;
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
@@ -1130,7 +1135,8 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_full_kernel(CrossSpl
         float r = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) r += red[w * 64 + tid];
-        p.a_out[(size_t)b * Dm + h * 64 + tid] = r * (1.0f / l);
+        if (p.a_frag) ((bf16_t*)p.a_frag)[frag_index(b, h * 64 + tid, Dm)] = f32_to_bf16(r * (1.0f / l));   // the out-projection's MFMA rows
+        else p.a_out[(size_t)b * Dm + h * 64 + tid] = r * (1.0f / l);
     } else if (slot >= 0 && tid < 64 + ATT_NS) {
         const int sI = tid - 64;
         p.align_ml[(rowi * ATT_NS + sI) * 2] = mx;
@@ -1334,8 +1340,14 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > 4 * (CROSS_THREADS / 8) || CROSS_THREADS != 512) return CW_ERR_INVALID;
     // every key split must own at least one key (the kernels clamp their loads to the split's last key)
     if (p.n_keys < 1 || (ATT_NS - 1) * ((p.n_keys + ATT_NS - 1) / ATT_NS) >= p.n_keys) return CW_ERR_INVALID;
+    if (p.a_frag) {   // 17..64 greedy rows: one block per (row, head) writes the out-projection's 16-bit rows -- no partials, no combine
+        if (!bf16 || p.kv_div > 1 || p.H > 20 || p.n_keys > CROSSF_U * (CROSS_THREADS / 8)) return CW_ERR_INVALID;
+        if (p.xstat ? (!p.qa || !p.qw || !p.qbias || p.q_planes < 1) : !p.q) return CW_ERR_INVALID;
+        hipLaunchKernelGGL((attn_cross_full_kernel<bf16_t>), dim3(p.H, p.B), dim3(CROSS_THREADS), 0, st, p);
+        return CW_OK;
+    }
     if (p.xstat || p.pstats) {   // fused out-projection / query stage: the query is finished in the kernel; 16-bit caches
-        if (!bf16 || p.kv_div > 1 || p.H > 20 || !p.qa || !p.qb || !p.qw || !p.qbias) return CW_ERR_INVALID;
+        if (!bf16 || p.kv_div > 1 || p.H > 20 || !p.qa || !p.qb || !p.qw || !p.qbias || p.q_planes > 1) return CW_ERR_INVALID;
         if (p.a_out) {
             if (!p.xstat) return CW_ERR_INVALID;   // one block per (row, head), finished output (A/B: 17 us per launch against 12 with six key splits)
             if (p.n_keys > CROSSF_U * (CROSS_THREADS / 8)) return CW_ERR_INVALID;

@@ -8,6 +8,7 @@
 #include <set>
 #include <string>
 #include <vector>
+#include <functional>
 
 #include "../../include/crisperwhisper.h"
 #include "kernels.h"
@@ -65,6 +66,13 @@ struct cw_ctx {
     bool rows_ln_ready = false;     // row sums of the LayerNorm-folded q/k/v, cross-q and fc1 weights are in place (gemv_rows_kernel)
     bool rows_ln_enabled = false;   // CW_ROWS_LN=1 (A/B, measured slower): 17..64 rows without the preparation launch in front of every GEMV
     bool rows_hilo = true;          // CW_NO_ROWS_HILO=1: single 16-bit copy of the residual rows (A/B)
+    int skinny_mode = 0;            // 17..64 rows (skinny.hip / attention.hip: attn_cross_full_kernel); option "skinny" / CW_SKINNY=n:
+                                    //   0 (default) round-3 path; 1 greedy rows: cross-attention query as a K-split skinny GEMM whose
+                                    //   planes the one-block-per-(row, head) cross-attention finishes, which also writes the
+                                    //   out-projection's rows (no LayerNorm preparation, no finish, no combine launch); 2 = 1 + q/k/v and
+                                    //   fc1 through planes + finish launch.  Both measured slower in the step (profiles/r04_b64_*_rejected_*): A/B only
+    float* d_planes = nullptr;      // [S][rows][N] K-split partial products of the LayerNorm projections (skinny.hip)
+    size_t planes_cap = 0;          // floats
     float* d_rstats = nullptr;      // [max(D, F) / 16][64][2] per-block LayerNorm partial sums of the 17..64-row producers
     bool fuse6_enabled = true;      // CW_NO_FUSE6=1: eight launches per layer (A/B)
     bool fuse_mlp = false;          // CW_FUSE_MLP=1: also fuse cross out-projection + fc1 (six launches; measured slower, A/B)
@@ -278,6 +286,7 @@ static int create_impl(cw_ctx* c) {
     if (getenv("CW_NO_FUSE6")) c->fuse6_enabled = false;
     if (getenv("CW_ROWS_LN")) c->rows_ln_enabled = true;
     if (getenv("CW_NO_ROWS_HILO")) c->rows_hilo = false;
+    if (getenv("CW_SKINNY")) c->skinny_mode = atoi(getenv("CW_SKINNY"));
     if (getenv("CW_FUSE_MLP")) c->fuse_mlp = true;
     if (getenv("CW_NO_WPACK")) c->wpack_enabled = false;
     if (getenv("CW_MLP_PAIR")) c->mlp_pair = true;
@@ -414,6 +423,10 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_rstats, (size_t)((D > F ? D : F) / 16 + 1) * 64 * 2 * 4));
     CWCHK(c, dmalloc(c, &c->d_bar, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_err, 4));
     CWCHK(c, dmalloc(c, &c->d_xfrag, (size_t)64 * 5120 * 2));
+    if (Bm > 16) {   // four K slices of the widest LayerNorm projection for 64 rows (5.2 MB at large-v3)
+        c->planes_cap = (size_t)4 * 64 * (3 * D > F ? 3 * D : F);
+        CWCHK(c, dmalloc(c, &c->d_planes, c->planes_cap * 4, false));
+    }
     CWCHK(c, dmalloc(c, &c->d_xfrag2, (size_t)64 * 5120 * 2));
     c->Vpad = (V + 3) & ~3;
     CWCHK(c, dmalloc(c, &c->dlogits, (size_t)Bm * c->Vpad * 4));
@@ -923,7 +936,29 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     // 17..64 rows without preparation launches (decfuse.hip: gemv_rows_kernel): the residual GEMVs own whole columns and leave
     // the stream in f32, its 16-bit fragment-major copy in d_xfrag and LayerNorm partial sums in d_rstats; the LayerNorm
     // GEMVs read that copy and normalise their outputs.  d_xfrag2 carries attention outputs and the GELU'd MLP rows.
-    const bool rows = frag && c->rows_ln_ready && c->rows_ln_enabled && c->ln_folded && D <= 1280;
+    // 17..64 rows, default: the LayerNorm projections (q/k/v, cross-attention query, fc1) as skinny-M GEMMs (skinny.hip): f32 rows
+    // -> K-split partial planes, finished (statistics, bias, cache / GELU epilogue) by one light launch -- no preparation launch.
+    // The residual projections stay on the 16-column K-split GEMV: their cost is the f32 atomics (7 ps each, measured), which
+    // a wider tile with more K slices multiplies (profiles/r04_skinny_ablation.txt).
+    const bool sk_ok = frag && c->wpacked && c->ln_folded && c->rows_ln_ready && c->d_planes;
+    const bool skinny = sk_ok && c->skinny_mode >= 2;
+    // greedy rows over the 16-bit cache: one cross-attention block per (row, head) over all keys writes the out-projection's
+    // 16-bit rows itself (1280 blocks at 64 rows: the chip is full without key splits)
+    const bool xfull = frag && c->skinny_mode >= 1 && c->beam_K == 0 && !c->kv8 && !c->rows_ln_enabled && H <= 20 && CW_N_CTX <= 24 * 64;
+    auto sk_ln = [&](int epi, const void* W, int N, const float* wsum, const EpiParams& ep) -> int {
+        SkinnyParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.x = c->dx; sp.W = W; sp.Mb = nb; sp.K = D; sp.N = N; sp.planes = c->d_planes;
+        const int nks = KD(c, cw_skinny_pick_nks, N, D, (int)(c->planes_cap / ((size_t)nb * N)));
+        if (nks < 1) return CW_ERR_INVALID;
+        int r = KD(c, cw_launch_skinny, 0, sp, nks, c->st);
+        if (r != CW_OK) return r;
+        SkinnyFinishParams fp;
+        memset(&fp, 0, sizeof(fp));
+        fp.planes = c->d_planes; fp.S = (D / 32) / nks; fp.Mb = nb; fp.N = N; fp.x = c->dx; fp.K = D; fp.wsum = wsum; fp.ep = ep;
+        return KD(c, cw_launch_skinny_finish, epi, fp, c->st);
+    };
+    const bool rows = !skinny && frag && c->rows_ln_ready && c->rows_ln_enabled && c->ln_folded && D <= 1280;
     int ln_nblk = 1;
     // bf16 only: the 16-bit copy of the residual rows keeps 8 mantissa bits of values that are NOT normalised yet; carried as
     // hi + lo halves (two MFMAs per fragment) the LayerNorm GEMVs see 16 bits, more than the rounded LN(x) of the prepared path
@@ -950,7 +985,8 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
             EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
             ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
-            if (rows) CWCHK(c, rows_consume(EPI_QKV_CACHE, L.wqkv, 3 * D, ep, L.qkv_wsum));
+            if (skinny) CWCHK(c, sk_ln(EPI_QKV_CACHE, L.wqkv, 3 * D, L.qkv_wsum, ep));
+            else if (rows) CWCHK(c, rows_consume(EPI_QKV_CACHE, L.wqkv, 3 * D, ep, L.qkv_wsum));
             else CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, xin, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep));
         }
         {
@@ -1035,9 +1071,32 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             else if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));
         }
+        if (xfull) {
+            CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml,
+                               c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_ml, c->d_align_slot + (size_t)l * H,
+                               c->d_pos, c->d.n_align, TGT, nb, H};
+            p.kv_div = 1; p.a_frag = c->d_xfrag;
+            if (sk_ok) {   // W'q_c (x - c) over K slices -> planes; the attention blocks apply rstd (sum - mean W'q_c 1) + b'q_c
+                SkinnyParams sp;
+                memset(&sp, 0, sizeof(sp));
+                sp.x = c->dx; sp.W = L.wq_c; sp.Mb = nb; sp.K = D; sp.N = D; sp.planes = c->d_planes;
+                const int nks = KD(c, cw_skinny_pick_nks, D, D, (int)(c->planes_cap / ((size_t)nb * D)));
+                if (nks < 1) return fail(c, CW_ERR_INVALID, "no K split for the cross-attention query GEMM");
+                CWCHK(c, KD(c, cw_launch_skinny, 0, sp, nks, c->st));
+                p.q = nullptr; p.xstat = c->dx; p.qa = c->d_planes; p.q_planes = (D / 32) / nks; p.q_plane_stride = nb * D;
+                p.qw = L.q_wsum; p.qbias = L.bq_c;
+            } else {
+                EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
+                CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep));
+            }
+            CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
+            EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
+            CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag, c->wpacked));
+        } else {
         {   // cross-attention: LN + q projection, attention over the cached encoder K/V
             EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
-            if (rows) CWCHK(c, rows_consume(EPI_STORE_F32, L.wq_c, D, ep, L.q_wsum));
+            if (skinny) CWCHK(c, sk_ln(EPI_STORE_F32, L.wq_c, D, L.q_wsum, ep));
+            else if (rows) CWCHK(c, rows_consume(EPI_STORE_F32, L.wq_c, D, ep, L.q_wsum));
             else CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep));
         }
         if (c->bf16) {
@@ -1065,9 +1124,11 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo_c, D, nullptr, nullptr, ep));
         }
+        }
         {
             EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
-            if (rows) CWCHK(c, rows_consume(EPI_GELU_FRAG, L.w1, F, ep, L.u1_wsum));
+            if (skinny) CWCHK(c, sk_ln(EPI_GELU_FRAG, L.w1, F, L.u1_wsum, ep));
+            else if (rows) CWCHK(c, rows_consume(EPI_GELU_FRAG, L.w1, F, ep, L.u1_wsum));
             else CWCHK(c, gemv_ln(c, frag ? EPI_GELU_FRAG : EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, c->ln_folded ? nullptr : L.ln2_b, ep));
         }
         {
@@ -1850,6 +1911,11 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
         for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // graphs hold the kernel choice
         return CW_OK;
     }
+    if (!strcmp(name, "skinny")) {    // 17..64-row decode: cw_ctx::skinny_mode (0 = round-3 path, for A/B and differential tests)
+        c->skinny_mode = value;
+        for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }
+        return CW_OK;
+    }
     return fail(c, CW_ERR_INVALID, "unknown option %s", name);
 }
 
@@ -1954,6 +2020,105 @@ int32_t cw_test_gemv(cw_ctx* c, int32_t Mb, int32_t N, int32_t K, const float* x
     else fail(c, r, "test_gemv: launch rejected (Mb=%d N=%d K=%d)", Mb, N, K);
     if (r == CW_OK) { hipError_t er = hipMemcpy(out, dO, (size_t)Mb * N * 4, hipMemcpyDeviceToHost); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemv copy"); }
     hipFree(dx); hipFree(dW); hipFree(dO); hipFree(dB); hipFree(dg); hipFree(db); hipFree(dxn);
+    return r;
+}
+
+// One skinny-M decoder projection (skinny.hip) on caller-supplied rows, 16-bit engines only.
+//   mode 0: out[Mb][N] = n(x) W^T + bias, n = LayerNorm without affine part (folded weights), through K-split planes + finish
+//   mode 1: the same through the GELU epilogue (16-bit fragment-major on the device, returned row-major as f32)
+//   mode 2: out[Mb][N] (in/out, on the 2^-12 grid) += x16 W^T + bias, x16 = x rounded to the engine's 16-bit type
+// nks: k-steps of 32 per block (0: the launcher's own choice).  reps > 0: the launches are also timed over `reps` rounds on
+// rotating weight copies larger than the Infinity Cache (cold weights, as in a decoder pass); us[0] = GEMM, us[1] = finish.
+int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K, const float* x, const float* W, const float* bias,
+                       int32_t nks, int32_t reps, float* out, float* us) {
+    if (!c->bf16) return fail(c, CW_ERR_INVALID, "cw_test_skinny: 16-bit engines only");
+    if (Mb < 1 || Mb > 64 || K % 32 || N % 16 || mode < 0 || mode > 2 || (mode == 1 && N % 32)) return fail(c, CW_ERR_INVALID, "cw_test_skinny: bad shape");
+    const int MT = (Mb + 15) / 16;
+    if (nks <= 0) nks = KD(c, cw_skinny_pick_nks, N, K, mode == 2 ? 0 : 16);
+    if (nks < 1 || (K / 32) % nks) return fail(c, CW_ERR_INVALID, "cw_test_skinny: nks %d does not divide K / 32", nks);
+    const int S = (K / 32) / nks;
+    const size_t wbytes = (size_t)N * K * 2;
+    int ncopy = 1;
+    if (reps > 0) { ncopy = (int)((size_t)320 * 1024 * 1024 / wbytes) + 1; if (ncopy > 64) ncopy = 64; }
+    float *dx = nullptr, *dB = nullptr, *dO = nullptr, *dws = nullptr, *dP = nullptr; void *dW = nullptr, *dWp = nullptr, *dxf = nullptr, *dfr = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dx, (size_t)Mb * K * 4)); HIPCHK(c, hipMalloc(&dW, wbytes)); HIPCHK(c, hipMalloc(&dWp, wbytes * ncopy));
+    HIPCHK(c, hipMalloc((void**)&dO, (size_t)Mb * N * 4)); HIPCHK(c, hipMalloc((void**)&dB, (size_t)N * 4)); HIPCHK(c, hipMalloc((void**)&dws, (size_t)N * 4));
+    HIPCHK(c, hipMalloc((void**)&dP, (size_t)S * Mb * N * 4)); HIPCHK(c, hipMalloc(&dxf, (size_t)MT * 16 * K * 2)); HIPCHK(c, hipMalloc(&dfr, (size_t)MT * 16 * N * 2));
+    HIPCHK(c, hipMemcpy(dx, x, (size_t)Mb * K * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(dB, 0, (size_t)N * 4));
+    if (bias) HIPCHK(c, hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    CWCHK(c, upload_T(c, dW, 0, W, (size_t)N * K));
+    CWCHK(c, KD(c, cw_launch_fold_rowvec, nullptr, nullptr, 1.0f, nullptr, dW, N, K, nullptr, dws, c->st));
+    for (int i = 0; i < ncopy; ++i) CWCHK(c, KD(c, cw_launch_wfrag_pack, dW, N, K, (char*)dWp + wbytes * i, c->st));
+    if (mode == 2) {
+        std::vector<bf16_t> xf((size_t)MT * 16 * K, 0);
+        for (int m = 0; m < Mb; ++m)
+            for (int k = 0; k < K; ++k) xf[frag_index(m, k, K)] = c->f16 ? cw_host_f32_to_f16(x[(size_t)m * K + k]) : cw_host_f32_to_bf16(x[(size_t)m * K + k]);
+        HIPCHK(c, hipMemcpy(dxf, xf.data(), xf.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(dO, out, (size_t)Mb * N * 4, hipMemcpyHostToDevice));
+    }
+    SkinnyParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.x = dx; sp.xf = dxf; sp.W = dWp; sp.Mb = Mb; sp.K = K; sp.N = N; sp.planes = dP; sp.outf = dO; sp.bias = dB; sp.ldo = N;
+    if (reps > 0 && getenv("CW_SK_DBG")) sp.dbg = atoi(getenv("CW_SK_DBG"));   // ablation of the timed launches (-DCW_SK_DEBUG builds)
+    const int sk_dbg = sp.dbg;
+    sp.dbg = 0;
+    SkinnyFinishParams fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.planes = dP; fp.S = S; fp.Mb = Mb; fp.N = N; fp.x = dx; fp.K = K; fp.wsum = dws; fp.ep = epi0();
+    fp.ep.bias = dB; fp.ep.outf = dO; fp.ep.out = dfr; fp.ep.ldo = N;
+    const int epi = mode == 1 ? EPI_GELU_FRAG : EPI_STORE_F32;
+    int r = KD(c, cw_launch_skinny, mode == 2 ? 1 : 0, sp, nks, c->st);
+    if (r == CW_OK && mode != 2) r = KD(c, cw_launch_skinny_finish, epi, fp, c->st);
+    if (r != CW_OK) fail(c, r, "cw_test_skinny: launch rejected (mode=%d Mb=%d N=%d K=%d nks=%d)", mode, Mb, N, K, nks);
+    if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "cw_test_skinny: %s", hipGetErrorString(er)); }
+    if (r == CW_OK) { hipError_t er = hipGetLastError(); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "cw_test_skinny: %s", hipGetErrorString(er)); }
+    if (r == CW_OK && mode == 1) {
+        std::vector<bf16_t> fr((size_t)MT * 16 * N);
+        if (hipMemcpy(fr.data(), dfr, fr.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, CW_ERR_HIP, "cw_test_skinny copy");
+        else for (int m = 0; m < Mb; ++m)
+            for (int n = 0; n < N; ++n) { const bf16_t v = fr[frag_index(m, n, N)]; out[(size_t)m * N + n] = c->f16 ? cw_host_f16_to_f32(v) : cw_host_bf16_to_f32(v); }
+    } else if (r == CW_OK) {
+        if (hipMemcpy(out, dO, (size_t)Mb * N * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, CW_ERR_HIP, "cw_test_skinny copy");
+    }
+    if (r == CW_OK && reps > 0 && us) {
+        // `reps` dependent launches captured as one hipGraph (how the decode step runs them) and replayed; the last replay is timed
+        sp.dbg = sk_dbg;
+        auto time_graph = [&](const std::function<int(int)>& launch, float* us_out) -> int {
+            hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+            if (hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal) != hipSuccess) return CW_ERR_HIP;
+            int rr = CW_OK;
+            for (int i = 0; i < reps && rr == CW_OK; ++i) rr = launch(i);
+            hipError_t e = hipStreamEndCapture(c->st, &g);
+            if (rr == CW_OK && e != hipSuccess) rr = CW_ERR_HIP;
+            if (rr == CW_OK && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) rr = CW_ERR_HIP;
+            if (g) hipGraphDestroy(g);
+            if (rr != CW_OK) return rr;
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            float best = 1e30f;
+            for (int k = 0; k < 4; ++k) {
+                hipEventRecord(e0, c->st);
+                hipGraphLaunch(ge, c->st);
+                hipEventRecord(e1, c->st);
+                hipEventSynchronize(e1);
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (k > 0 && ms < best) best = ms;
+            }
+            hipEventDestroy(e0); hipEventDestroy(e1); hipGraphExecDestroy(ge);
+            *us_out = 1e3f * best / reps;
+            return CW_OK;
+        };
+        r = time_graph([&](int i) { sp.W = (char*)dWp + wbytes * (i % ncopy); return KD(c, cw_launch_skinny, mode == 2 ? 1 : 0, sp, nks, c->st); }, &us[0]);
+        if (r == CW_OK && mode != 2) r = time_graph([&](int) { return KD(c, cw_launch_skinny_finish, epi, fp, c->st); }, &us[1]);
+        if (r == CW_OK && mode == 2) {                       // no finish launch: the floor of an empty launch instead (negative)
+            r = time_graph([&](int) { KD(c, cw_launch_skinny_empty, c->st); return (int)CW_OK; }, &us[1]);
+            us[1] = -us[1];
+        }
+        if (r != CW_OK) fail(c, r, "cw_test_skinny: timing graph failed");
+    }
+    hipFree(dx); hipFree(dW); hipFree(dWp); hipFree(dO); hipFree(dB); hipFree(dws); hipFree(dP); hipFree(dxf); hipFree(dfr);
     return r;
 }
 

@@ -106,6 +106,10 @@ struct CrossSplitParams {
     const float* qw;       // [H*64]    W'q 1
     const float* qbias;    // [H*64]    b'q
     float* a_out;          // [B][H*64] non-null: one block per (row, head) over all keys writes the finished output (no splits)
+    void* a_frag;          // non-null: the same launch shape, output as 16-bit MFMA fragment-major rows (frag_index, K = H*64) for the
+                           // out-projection of the 17..64-row path; q finished from `xstat` + q_planes planes at qa, or plain `q`
+    int q_planes;          // a_frag + xstat: qa holds this many K-split planes (skinny.hip), q_plane_stride floats apart; qb may be null
+    int q_plane_stride;
 };
 // opt-in fp8 (OCP e4m3) cross-attention cache: quantise one layer's bf16 K/V [B][H][S][64] with a scale per (b, h, K|V)
 struct CombineParams {     // activations of a GEMV = combination of ATT_NS attention partials
@@ -186,6 +190,30 @@ struct RowsParams {
     float* pstats_out;       // producer: [N/16][64][2]
 };
 
+// skinny.hip: decoder linear layers for 17..64 rows -- 64-column x Kb blocks for ALL rows, activations staged once per block in
+// LDS, K split over grid.y.  mode 0: f32 residual rows (LayerNorm by linearity, finished by skinny_finish_kernel) -> partial
+// planes; mode 1: 16-bit fragment-major rows -> f32 atomics into the residual stream (2^-12 grid).
+struct SkinnyParams {
+    const float* x;        // mode 0: [Mb][K] f32 rows
+    const void* xf;        // mode 1: 16-bit fragment-major rows [ceil(Mb/16)][K/32][64][8] (common.h: frag_index)
+    const void* W;         // [N][K] 16-bit, fragment-major (gemm.hip: wfrag_pack_kernel)
+    int Mb, K, N;
+    int Kb;                // filled in by the launcher: K columns per block
+    float* planes;         // mode 0: [S][Mb][N] f32 partial products, S = K / Kb
+    float* outf;           // mode 1: [Mb][ldo] f32, accumulated in place
+    const float* bias;     // mode 1: [N] or null (added by slice 0)
+    int ldo;
+    int dbg;               // -DCW_SK_DEBUG builds only: ablation switches of tools/skinny_bench.py
+};
+struct SkinnyFinishParams {
+    const float* planes;   // [S][Mb][N]
+    int S, Mb, N;
+    const float* x;        // [Mb][K] rows whose LayerNorm statistics apply (null: none)
+    int K;
+    const float* wsum;     // [N] row sums of the folded 16-bit weights (W' 1); null with x == null
+    EpiParams ep;          // destination + folded bias; EPI_STORE_F32 / EPI_QKV_CACHE / EPI_GELU_FRAG
+};
+
 // mel.hip
 struct MelTables {
     const double* cos_t;  // [400]
@@ -219,6 +247,10 @@ struct MelTables {
     int cw_launch_gemv_rows(int epi, bool produce, const RowsParams& p, hipStream_t st); \
     int cw_launch_rows_combine(const float* part_o, int Mb, int K, const CombineParams& cb, void* xf, hipStream_t st); \
     int cw_launch_rows_prep(const float* x, int Mb, int K, void* xf, float* pstats, int lo_off, hipStream_t st); \
+    int cw_skinny_pick_nks(int N, int K, int s_max); \
+    int cw_launch_skinny(int mode, const SkinnyParams& p, int nks, hipStream_t st); \
+    int cw_launch_skinny_finish(int epi, const SkinnyFinishParams& p, hipStream_t st); \
+    void cw_launch_skinny_empty(hipStream_t st); \
     int cw_launch_layernorm(bool bf16_out, const float* x, const float* g, const float* b, void* out, int rows, int d, hipStream_t st); \
     int cw_launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int rows, int d, hipStream_t st); \
     int cw_launch_sample(const SampleParams& p, hipStream_t st); \

@@ -344,6 +344,17 @@ class Engine:
                                         _ptr(g), _ptr(be), int(gelu), _ptr(out)))
         return out
 
+    def test_skinny(self, mode, x, W, bias=None, out0=None, nks=0, reps=0):
+        """One skinny-M decoder projection (cw_test_skinny, 17..64 rows).  mode 0: LayerNorm (no affine) + projection, 1: + GELU
+        (16-bit result), 2: out0 + x16 W^T + bias on the residual grid.  Returns (out, (gemm_us, finish_us))."""
+        x = np.ascontiguousarray(x, np.float32); W = np.ascontiguousarray(W, np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+        out = np.zeros((x.shape[0], W.shape[0]), np.float32) if out0 is None else np.ascontiguousarray(out0, np.float32).copy()
+        us = np.zeros(2, np.float32)
+        self._chk(self.lib.cw_test_skinny(self.ctx, int(mode), x.shape[0], W.shape[0], x.shape[1], _ptr(x), _ptr(W), _ptr(b),
+                                          int(nks), int(reps), _ptr(out), _ptr(us)))
+        return out, (float(us[0]), float(us[1]))
+
     def test_attention(self, q, k, v):
         q, k, v = (np.ascontiguousarray(t, np.float32) for t in (q, k, v))
         B, H, S, _ = q.shape

@@ -254,6 +254,12 @@ int32_t cw_test_gemm_fp8(cw_ctx* ctx, int32_t M, int32_t N, int32_t K, const flo
                          int32_t gelu, float* out);
 int32_t cw_test_gemv(cw_ctx* ctx, int32_t Mb, int32_t N, int32_t K, const float* x, const float* W,
                      const float* bias, const float* ln_g, const float* ln_b, int32_t gelu, float* out);
+/* One skinny-M decoder projection (17..64 rows; csrc/skinny.hip) on caller-supplied rows, 16-bit engines.  mode 0: LayerNorm
+ * (no affine part) + projection through K-split planes and the finish launch; 1: the same through GELU; 2: residual rows
+ * out += x16 W^T + bias by grid atomics.  nks = k-steps of 32 per block (0 = default), reps > 0 also times the launches on cold
+ * weights: us[0] GEMM, us[1] finish (microseconds per launch). */
+int32_t cw_test_skinny(cw_ctx* ctx, int32_t mode, int32_t Mb, int32_t N, int32_t K, const float* x, const float* W,
+                       const float* bias, int32_t nks, int32_t reps, float* out, float* us);
 int32_t cw_test_attention(cw_ctx* ctx, int32_t B, int32_t H, int32_t S, const float* q, const float* k,
                           const float* v, float* out /* [B][S][H*64] */);
 /* One launch of the key-split cross-attention decode kernel (CW_ATT_SPLITS = 6 key splits): q [B][H*64] pre-scaled, k / v

@@ -328,10 +328,14 @@ def test_native_seek_loop_equals_host_loop(tiny, eng_f32, language, task, kw):
         assert x.dtype == np.float32 and np.array_equal(x, y)
 
 
-def test_large_batch_decode_matches_small_batch_path():
+@pytest.mark.parametrize("skinny_mode", [1, 0, 2])
+def test_large_batch_decode_matches_small_batch_path(skinny_mode):
     """Decode batches of 17..64 rows take the one-weight-pass GEMV (prep + multi-tile kernel, gemm.hip); batches of
     <= 16 rows the latency kernel.  Same engine, same 20 windows, large-v3 shapes (K-split atomics, combine, 51866
-    logits): teacher-forced logits of the two paths agree to bf16 rounding and pick the same tokens."""
+    logits): teacher-forced logits of the two paths agree to bf16 rounding and pick the same tokens.
+    skinny_mode 1 (default): cross-attention query through K-split planes finished inside the one-block-per-(row, head)
+    cross-attention, which writes the out-projection's rows; 0: the round-3 path; 2: every LayerNorm projection through
+    csrc/skinny.hip planes + finish launch."""
     g, v = syn.large_v3_geometry()
     g.enc_layers = g.dec_layers = 2
     spec = syn.model_spec(g, v, n_align=15)
@@ -346,6 +350,7 @@ def test_large_batch_decode_matches_small_batch_path():
     eng = Engine(spec, dtype="bf16", max_batch=B)
     eng.load_state_dict(W)
     try:
+        eng._chk(eng.lib.cw_set_option(eng.ctx, b"skinny", skinny_mode))
         eng.mel(clips)
         eng.encode(list(range(B)), [0] * B, [3000] * B)
         cap = eng.capture_logits(B, T)

@@ -167,6 +167,46 @@ def test_gemv_with_layernorm(engines, dt, tol, Mb, N, K):
             got = engines[dt].test_gemv(x, W, b, ln, gelu)
             assert rel_err(got, ref) < tol, (dt, Mb, N, K, ln is not None, gelu, rel_err(got, ref))
 
+def _ln_plain(x):
+    x = x.astype(np.float64)
+    mu = x.mean(-1, keepdims=True)
+    return (x - mu) / np.sqrt(((x - mu) ** 2).mean(-1, keepdims=True) + 1e-5)
+
+
+@pytest.mark.parametrize("dt,tol", [("bf16", 2e-2), ("f16", 2.5e-3)])
+@pytest.mark.parametrize("Mb,N,K,nks", [(17, 384, 128, 0), (20, 128, 512, 4), (33, 256, 256, 2), (40, 1280, 1280, 0), (48, 3840, 1280, 10),
+                                         (64, 5120, 1280, 0), (64, 1280, 5120, 16), (64, 1280, 1280, 5), (25, 80, 64, 1), (64, 176, 1280, 8)])
+def test_skinny_projections_17_to_64_rows(engines, dt, tol, Mb, N, K, nks):
+    """Decoder projections of the 17..64-row path (csrc/skinny.hip) against float64: LayerNorm by linearity through K-split
+    planes + finish (plain and GELU epilogues) and the residual projection by grid atomics, every supported K split shape,
+    ragged row counts, column counts that leave waves / lanes without a tile.  The rows carry a mean 40x their spread (a
+    kernel that rounded x to 16 bits before removing the mean loses those 5 bits) and every other row an outlier channel."""
+    rng = np.random.default_rng(Mb * 13 + N + K)
+    x = (rng.standard_normal((Mb, K)) * 0.5 + rng.uniform(-20, 20, (Mb, 1))).astype(np.float32)
+    x[1::2, 7] *= 30.0
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    (W,) = _round16(dt, W)
+    eng = engines[dt]
+    ref = _ln_plain(x) @ W.astype(np.float64).T + b
+    got, _ = eng.test_skinny(0, x, W, b, nks=nks)
+    assert rel_err(got, ref) < tol, (dt, Mb, N, K, "ln", rel_err(got, ref))
+    if N % 32 == 0:                                         # the GELU epilogue writes MFMA fragments of the next projection (K' = N)
+        got, _ = eng.test_skinny(1, x, W, b, nks=nks)
+        refg = OMOD.gelu(ref.astype(np.float32)).astype(np.float64)
+        assert rel_err(got, refg) < tol, (dt, Mb, N, K, "gelu", rel_err(got, refg))
+    # residual projection: activations are 16-bit rows, result on the 2^-12 grid, bit-reproducible
+    a = (rng.standard_normal((Mb, K)) * 2).astype(np.float32)
+    (a16,) = _round16(dt, a)
+    r0 = (np.round(rng.standard_normal((Mb, N)) * 3 * 4096) / 4096).astype(np.float32)
+    ref2 = r0 + a16.astype(np.float64) @ W.astype(np.float64).T + b
+    got2, _ = eng.test_skinny(2, a16, W, b, out0=r0, nks=nks)
+    S = (K // 32) // (nks if nks else 1)
+    assert np.abs(got2 - ref2).max() < 2.0 ** -13 * (S + 2) + 1e-5 * np.abs(ref2).max(), (dt, Mb, N, K, np.abs(got2 - ref2).max())
+    assert np.all(got2 * 4096 == np.round(got2 * 4096))
+    again, _ = eng.test_skinny(2, a16, W, b, out0=r0, nks=nks)
+    assert np.array_equal(got2, again)
+
 
 @pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
 @pytest.mark.parametrize("B,H,S", [(1, 1, 64), (2, 2, 200), (1, 2, 1500), (2, 3, 257), (1, 1, 1), (3, 5, 511)])
