@@ -77,7 +77,9 @@ def parse_wav(data: bytes):
     return code, ch, sr, n_frames, payload[: n_frames * ch * (bits // 8)]
 
 
-MAX_DECODED_SECONDS = 24 * 3600          # upper bound on what a single compressed file may expand to
+import os as _os
+# upper bound on what a single compressed file may expand to (enforced inside the decoder's frame loop); CW_MAX_AUDIO_SECONDS
+MAX_DECODED_SECONDS = int(_os.environ.get("CW_MAX_AUDIO_SECONDS", 2 * 3600))
 
 
 def decode_flac(data: bytes):
@@ -100,7 +102,7 @@ def decode_flac(data: bytes):
         raise ValueError(f"FLAC stream declares {total.value} sample frames: more than the {MAX_DECODED_SECONDS} s this path accepts")
     cap = int(total.value)
     if cap <= 0:
-        if lib.cw_flac_decode(ptr, len(buf), None, 0, C.byref(n)) != 0:
+        if lib.cw_flac_decode(ptr, len(buf), None, max_frames, C.byref(n)) != 0:
             raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
         cap = int(n.value)
         if cap > max_frames:

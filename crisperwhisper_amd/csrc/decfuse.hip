@@ -130,8 +130,10 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
         const int zi = bid * 256 + tid;
         if (zi < p.zero_n4) ((float4*)p.zero)[zi] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const float* __restrict__ wsum = SEG_PICK(wsum);
+    float* smean = red + 4 * NT * 4 * 64;                       // [16] row means (segments with wsum)
     int nloc[NT];                                                // this lane's output column inside the segment (or -1)
-    float bias_v[NT];
+    float bias_v[NT], wsum_v[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tl = tl0 + t;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
         nloc[t] = ok ? tl * 16 + l15 : -1;
         const int ncl = (ok ? tl : n_tiles - 1) * 16 + l15;
         bias_v[t] = bias ? bias[ncl] : 0.f;
+        wsum_v[t] = wsum ? wsum[ncl] : 0.f;
     }
     // activation rows -> registers
     float4 xv[RPW][PER_LANE];
@@ -180,6 +183,23 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
     // every load above is in flight before the first one is waited for: without the fence hipcc interleaves the weight loads
     // with the conversion of the activation rows as those return, which delays the weight stream by one L2 round trip
     __builtin_amdgcn_sched_barrier(0);
+    // Rows that feed a LayerNorm consumer (W' x, the consumer applies rstd (. - mean W'1) + b'): rounding x itself to 16 bits
+    // would spend the significand on the row's mean, which the consumer subtracts again -- |mean| / std of precision lost on
+    // rows with an offset.  The row lives in this wave, so its mean is six DPP steps away: round x - mean and add
+    // mean * (W' 1) back in f32 in the epilogue.
+    if (wsum) {                                                  // block-uniform
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            float sx = 0.f;
+#pragma unroll
+            for (int c = 0; c < PER_LANE; ++c)
+                if (lane + 64 * c < nvec) sx += (xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w);
+            const float mu = wave_sum(sx) / (float)K;
+#pragma unroll
+            for (int c = 0; c < PER_LANE; ++c) { xv[i][c].x -= mu; xv[i][c].y -= mu; xv[i][c].z -= mu; xv[i][c].w -= mu; }
+            if (lane == 0) smean[wave + 4 * i] = mu;
+        }
+    }
     // rows -> 16 bit -> LDS
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -231,10 +251,11 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
         const int m = g * 4 + r, n = nloc[t];
         if (m < Mb && n >= 0) {
             const size_t o = (size_t)m * ldo + n;
+            const float back = wsum ? smean[m] * wsum_v[t] : 0.f;
             if (epi == 0) {
-                out[o] = v + bias_v[t];
+                out[o] = v + bias_v[t] + back;
             } else if (epi == 2) {
-                atomicAdd(out + o, v + bias_v[t]);
+                atomicAdd(out + o, v + bias_v[t] + back);
             } else {
                 const float rv = resid[o] + resid_grid(v + bias_v[t]);
                 out[o] = rv;
@@ -265,7 +286,7 @@ static int launch_stack_nt(StackParams& p, hipStream_t st) {
         blocks += (p.seg[s].n_tiles + p.seg[s].nt - 1) / p.seg[s].nt;
     }
     if (p.zero && (long long)blocks * 256 < p.zero_n4) return CW_ERR_INVALID;
-    const size_t lds = (size_t)16 * (p.K + 8) * 2 + (size_t)4 * NT * 4 * 64 * 4;
+    const size_t lds = (size_t)16 * (p.K + 8) * 2 + (size_t)4 * NT * 4 * 64 * 4 + 16 * 4;
     if (p.K <= 256) hipLaunchKernelGGL((gemv_stack_kernel<RPW, 1, 1, NT>), dim3(blocks), dim3(256), lds, st, p);
     else if (p.K <= 768) hipLaunchKernelGGL((gemv_stack_kernel<RPW, 2, 3, NT>), dim3(blocks), dim3(256), lds, st, p);
     else hipLaunchKernelGGL((gemv_stack_kernel<RPW, 3, 5, NT>), dim3(blocks), dim3(256), lds, st, p);

@@ -615,7 +615,13 @@ static int apply_folds(cw_ctx* c) {
 static int pack_decoder_weights(cw_ctx* c) {
     if (!c->bf16 || !c->wpack_enabled || c->wpacked) return CW_OK;
     const int D = c->d.d_model, F = c->d.ffn_dim, V = c->d.vocab_size;
-    if (D % 32 || F % 32) return CW_OK;
+    // packed weights are read by gemv2_bf16_kernel / gemv_mt_kernel / gemv_stack_kernel only (the first-generation GEMV reads
+    // row-major): pack exactly when those kernels take every decoder shape -- K = d_model in one K slice (<= 1280), fc2's
+    // K = ffn_dim in power-of-two slices of <= 1280 that are multiples of 128 (gemm.hip: gemv2_ok).  Wider geometries
+    // (d_model up to 2048 is accepted by cw_create) keep row-major weights and the fallback kernel.
+    int fks = 1;
+    while (F / fks > 1280) fks *= 2;
+    if (D % 128 || D > 1280 || F % 128 || F > 5120 || F % fks || (F / fks) % 128) return CW_OK;
     const size_t emb_elems = KD(c, cw_wfrag_elems, V, D);
     size_t tmp_elems = (size_t)(2 * F + D) * D;
     if ((size_t)3 * D * D > tmp_elems) tmp_elems = (size_t)3 * D * D;
@@ -1003,6 +1009,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 memset(&sp, 0, sizeof(sp));
                 sp.W = L.ws3; sp.wpk = c->wpacked ? 1 : 0; sp.K = D; sp.Mb = nb; sp.nseg = 3;
                 sp.seg[0].x = xin;      sp.seg[0].bias = L.qa_bias; sp.seg[0].out = c->d_qa; sp.seg[0].tile0 = 0;      sp.seg[0].n_tiles = TD; sp.seg[0].epi = 0;
+                sp.seg[0].wsum = L.q_wsum;   // x is rounded as x - mean(x): the operand the cross-attention LayerNorm is sensitive to
                 sp.seg[1].x = c->dattn; sp.seg[1].bias = nullptr;   sp.seg[1].out = c->d_qb; sp.seg[1].tile0 = TD;     sp.seg[1].n_tiles = TD; sp.seg[1].epi = 0;
                 sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo;      sp.seg[2].out = xalt;    sp.seg[2].tile0 = 2 * TD; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
                 sp.seg[2].resid = xin; sp.seg[2].pstats = c->d_pstats;   // LayerNorm partial sums of x1 for the cross-attention
@@ -1054,6 +1061,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 memset(&sp, 0, sizeof(sp));
                 sp.W = L.ws5; sp.wpk = c->wpacked ? 1 : 0; sp.K = D; sp.Mb = nb; sp.nseg = 3;
                 sp.seg[0].x = xalt;     sp.seg[0].bias = L.u1_bias; sp.seg[0].out = c->d_u1; sp.seg[0].tile0 = 0;      sp.seg[0].n_tiles = TF; sp.seg[0].epi = 2;
+                sp.seg[0].wsum = L.u1_wsum;
                 sp.seg[1].x = c->dattn; sp.seg[1].bias = nullptr;   sp.seg[1].out = c->d_u1; sp.seg[1].tile0 = TF;     sp.seg[1].n_tiles = TF; sp.seg[1].epi = 2;
                 sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo_c;    sp.seg[2].out = xin;     sp.seg[2].tile0 = 2 * TF; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
                 sp.seg[2].resid = xalt; sp.seg[2].out2 = c->dx2c;

@@ -336,9 +336,12 @@ int64_t read_frame(const uint8_t* d, size_t n, size_t off, const StreamInfo& si,
     return (int64_t)(body_len + 2);
 }
 
-int decode_all(const uint8_t* d, size_t n, StreamInfo& si, std::vector<std::vector<int64_t>>& ch) {
+// max_frames > 0: give up INSIDE the frame loop once more than that many sample frames are decoded -- a few hundred bytes of
+// CONSTANT subframes expand without bound, and the caller's size check would only run after everything was materialised
+int decode_all(const uint8_t* d, size_t n, StreamInfo& si, std::vector<std::vector<int64_t>>& ch, int64_t max_frames) {
     int r = parse_metadata(d, n, si);
     if (r) return r;
+    if (max_frames > 0 && si.total > max_frames) return flac_fail("FLAC stream declares more sample frames than the caller accepts");
     ch.assign(si.channels, {});
     size_t off = si.audio_off;
     Md5 md5;
@@ -352,6 +355,7 @@ int decode_all(const uint8_t* d, size_t n, StreamInfo& si, std::vector<std::vect
         if (used < 0) return (int)used;
         if (bps != si.bps) return flac_fail("FLAC frame sample size differs from STREAMINFO");
         off += (size_t)used;
+        if (max_frames > 0 && (int64_t)ch[0].size() > max_frames) return flac_fail("FLAC stream decodes to more sample frames than the caller accepts");
         raw.resize((size_t)bs * si.channels * bytes_ps);     // MD5 is over interleaved little-endian samples
         size_t w = 0;
         for (int i = 0; i < bs; ++i)
@@ -396,7 +400,8 @@ int32_t cw_flac_decode(const uint8_t* data, int64_t n, int32_t* pcm_s32, int64_t
     if (!data || n < 0 || !n_frames) return flac_fail("null FLAC buffer");
     StreamInfo si;
     std::vector<std::vector<int64_t>> ch;
-    const int r = decode_all(data, (size_t)n, si, ch);
+    // cap_frames bounds the decoding itself (size query: the most the caller would accept; 0 = no bound)
+    const int r = decode_all(data, (size_t)n, si, ch, cap_frames > 0 ? cap_frames : 0);
     if (r) return r;
     const int64_t frames = (int64_t)ch[0].size();
     *n_frames = frames;

@@ -122,6 +122,8 @@ struct CombineParams {     // activations of a GEMV = combination of ATT_NS atte
 struct StackSeg {
     const float* x;        // [Mb][K] f32 input rows of this segment (rounded to 16 bit, no LayerNorm)
     const float* bias;     // [n_tiles*16] or null
+    const float* wsum;     // epi 0 / 2, non-null: [n_tiles*16] row sums of this segment's weights -- the rows are rounded as x - mean(x)
+                           // (the operand a LayerNorm consumer is sensitive to) and mean(x) * wsum[n] is added back in f32
     const float* resid;    // epi 1: [Mb][n_tiles*16]
     float* out;            // [Mb][n_tiles*16]
     float* out2;           // epi 1: optional second copy of the result

@@ -217,6 +217,10 @@ def beam_search(engine: Engine, prompt: np.ndarray, max_length: int, min_new_tok
     ``native_host`` (default True): the bookkeeping of every step runs in ``csrc/beamhost.cpp`` (one C call per step instead
     of ~45 numpy calls, 0.23 ms per step at 8 items x 5 beams); ``False`` keeps the numpy statement below, which
     ``tests/test_beam_host.py`` holds bit-equal to the native one on random candidate streams."""
+    if early_stopping is not True and early_stopping is not False:
+        # transformers also knows "never" (a third stopping heuristic, generation/utils.py:3042-3053); it is not implemented
+        # here and must not be mistaken for False
+        raise ValueError(f"early_stopping={early_stopping!r}: only True / False are implemented")
     spec = engine.spec
     f32 = np.float32
     prompt = np.asarray(prompt, dtype=np.int64)
@@ -329,19 +333,20 @@ def generate(engine: Engine, n_items: int, num_frames, *, language: Optional[str
     spec = engine.spec
     if no_speech_threshold is not None and logprob_threshold is None:
         raise ValueError("no_speech_threshold needs logprob_threshold as well (generation_whisper.py:1275-1285 compares both)")
-    if hasattr(engine, "set_thresholds"):
-        engine.set_thresholds(logprob_threshold, no_speech_threshold)
-    elif logprob_threshold is not None:
-        raise ValueError("this engine does not implement logprob_threshold / no_speech_threshold")
+    # every argument is checked before any engine state changes (a refused call must not leave its thresholds behind)
     skip_on = logprob_threshold is not None and no_speech_threshold is not None
     if skip_on and num_beams is not None and int(num_beams) > 1:
-        raise ValueError("logprob_threshold / no_speech_threshold are implemented for greedy decoding only (num_beams=1)")
+        raise ValueError("logprob_threshold / no_speech_threshold are implemented for greedy decoding only: pass num_beams=1")
     num_beams = 1 if num_beams is None else int(num_beams)
     if num_beams < 1:
         raise ValueError(f"`num_beams` has to be an integer strictly greater than 0, but is {num_beams}")
     if num_beams * n_items > engine.max_batch:
         raise ValueError(f"beam search decodes items x beams = {num_beams * n_items} rows; the engine was created with "
                          f"max_batch = {engine.max_batch}")
+    if hasattr(engine, "set_thresholds"):
+        engine.set_thresholds(logprob_threshold, no_speech_threshold)
+    elif logprob_threshold is not None:
+        raise ValueError("this engine does not implement logprob_threshold / no_speech_threshold")
     num_frames = np.asarray(num_frames, dtype=np.int64)
     if native is None:
         native = hasattr(engine, "transcribe") and num_beams == 1

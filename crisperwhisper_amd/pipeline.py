@@ -213,7 +213,9 @@ _GENERATE_KWARGS = ("language", "task", "max_new_tokens", "min_new_tokens", "num
                     "logprob_threshold", "no_speech_threshold", "compression_ratio_threshold", "return_timestamps")
 
 
-def _check_generate_kwargs(gk: Dict[str, Any]) -> None:
+def _check_generate_kwargs(gk: Dict[str, Any], default_num_beams: Optional[int] = None) -> None:
+    """``default_num_beams``: the width a call without ``num_beams`` decodes with (the pipeline default): the refusals that
+    depend on the beam width are then raised here, before any audio is loaded."""
     unknown = sorted(k for k in gk if k not in _GENERATE_KWARGS)
     if unknown:
         raise ValueError(f"generate_kwargs {unknown} are not implemented on the native path (implemented: "
@@ -229,9 +231,12 @@ def _check_generate_kwargs(gk: Dict[str, Any]) -> None:
             raise ValueError("temperature fallback with sampling is not implemented on the native path "
                              "(stochastic decoding cannot be made bit-comparable with torch's generator)")
         temp = temp[0]
-    if temp is not None and not (isinstance(temp, (int, float)) and not isinstance(temp, bool) and float(temp) in (0.0, 1.0)):
-        raise ValueError(f"generate_kwargs['temperature']={gk['temperature']!r} is not supported on the native path "
-                         "(deterministic greedy / beam search only)")
+    # do_sample = temperature > 0.0 (generation_whisper.py:1002): any positive temperature, 1.0 included, makes transformers
+    # SAMPLE (with num_beams forced to 1) -- only 0 is the deterministic decoding this path implements
+    if temp is not None and not (isinstance(temp, (int, float)) and not isinstance(temp, bool) and float(temp) == 0.0):
+        raise ValueError(f"generate_kwargs['temperature']={gk['temperature']!r} is not supported on the native path: transformers "
+                         "samples at every temperature > 0 (stochastic decoding cannot be made bit-comparable with torch's "
+                         "generator); pass temperature=0.0 or leave it out")
     if gk.get("num_return_sequences") not in (None, 1):
         raise ValueError("generate_kwargs['num_return_sequences'] > 1 is not supported on the native path")
     for k in ("prompt_ids", "assistant_model"):
@@ -241,9 +246,12 @@ def _check_generate_kwargs(gk: Dict[str, Any]) -> None:
         raise ValueError("generate_kwargs['return_timestamps'] must be left to the pipeline argument of the same name")
     if gk.get("no_speech_threshold") is not None and gk.get("logprob_threshold") is None:
         raise ValueError("no_speech_threshold needs logprob_threshold as well (generation_whisper.py:1275-1285 compares both)")
-    if thresholds and gk.get("num_beams") not in (None, 1) and any(k in thresholds for k in ("logprob_threshold", "no_speech_threshold")):
-        raise ValueError("logprob_threshold / no_speech_threshold are implemented for greedy decoding only (num_beams=1): "
-                         "transformers scores beam hypotheses differently again and that path is not reproduced")
+    beams = gk.get("num_beams") if gk.get("num_beams") is not None else default_num_beams
+    if thresholds and beams not in (None, 1) and any(k in thresholds for k in ("logprob_threshold", "no_speech_threshold")):
+        raise ValueError(f"logprob_threshold / no_speech_threshold are implemented for greedy decoding only and this call decodes "
+                         f"with {beams} beams" + ("" if gk.get("num_beams") is not None else " (the pipeline default)") +
+                         ": pass generate_kwargs={'num_beams': 1, ...} -- transformers scores beam hypotheses differently again "
+                         "and that path is not reproduced")
     if gk.get("logprob_threshold") is not None and gk.get("temperature") is None:
         raise ValueError("logprob_threshold needs an explicit temperature (pass temperature=0.0): transformers itself fails with "
                          "a TypeError in _retrieve_avg_logprobs otherwise (generation_whisper.py:1959)")
@@ -353,7 +361,7 @@ class CrisperWhisperPipeline:
         if return_language:
             raise ValueError("return_language is not supported on the native path")
         gk = dict(generate_kwargs or {})
-        _check_generate_kwargs(gk)
+        _check_generate_kwargs(gk, self.default_num_beams)
         if "num_beams" not in gk:
             _warn_once("beams", f"no num_beams given: decoding with {self.default_num_beams} beams like the installed transformers "
                                 "ASR pipeline default; pass generate_kwargs={'num_beams': 1} for the greedy decoding of the 2024 reference")

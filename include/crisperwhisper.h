@@ -101,7 +101,9 @@ int32_t cw_resample_taps(int32_t sr_in, int32_t sr_out, float* taps, int32_t cap
 /* FLAC container (host, no GPU): the part of `ffmpeg_read` (TF/pipelines/audio_utils.py:9-45) that turns a .flac file into
  * integer samples -- RFC 9639 decoder with CRC-8 / CRC-16 / STREAMINFO-MD5 verification (csrc/flac.cpp).  cw_flac_decode writes
  * interleaved samples left-justified to 32 bits ([frames][channels] int32: exactly what cw_ingest(CW_PCM_S32) scales by
- * 2^-31, i.e. ffmpeg's s16 / s32 -> f32 conversion); pcm_s32 == NULL only reports the frame count.  Errors: negative
+ * 2^-31, i.e. ffmpeg's s16 / s32 -> f32 conversion); pcm_s32 == NULL only reports the frame count.  cap_frames > 0 also
+ * bounds the decoding: the frame loop stops with an error as soon as more frames than that were produced (a decompression
+ * bomb never materialises); with pcm_s32 == NULL it is the most the caller would accept, 0 = unbounded.  Errors: negative
  * code, text in cw_flac_last_error().                                                                                 */
 int32_t cw_flac_info(const uint8_t* data, int64_t n_bytes, int32_t* sample_rate, int32_t* channels,
                      int32_t* bits_per_sample, int64_t* total_frames);

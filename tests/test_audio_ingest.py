@@ -324,6 +324,33 @@ def test_flac_decoder_fails_loudly_on_corruption():
         with pytest.raises(ValueError, match=msg):
             _decode(mutate(good))
 
+def test_flac_decompression_bomb_is_stopped_inside_the_frame_loop(monkeypatch):
+    """A stream of CONSTANT subframes (14 bytes per 4096-sample block) of unknown total length: the decoder gives up as soon as
+    the caller's bound is passed -- inside the frame loop, not after everything was materialised -- for the size query and for
+    the decoding call alike; the same stream under a bound it fits in decodes."""
+    import ctypes as C
+    from crisperwhisper_amd import _native as N, audio
+    from tests import flac_writer as FW
+    n_blocks, bs = 40, 4096
+    chans = [np.full(n_blocks * bs, 321, dtype=np.int64)]
+    frames = [dict(n=bs, plans=[dict(kind="constant")]) for _ in range(n_blocks)]
+    data = FW.write_stream(chans, 16, 16000, frames, with_md5=False, total_known=False)
+    assert len(data) < 1000                                    # 160 k samples from < 1 kB
+    lib = N.load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n = C.c_int64(0)
+    assert lib.cw_flac_decode(buf.ctypes.data_as(C.c_void_p), len(buf), None, 3 * bs, C.byref(n)) != 0
+    assert b"more sample frames" in lib.cw_flac_last_error()
+    out = np.empty((3 * bs, 1), np.int32)
+    assert lib.cw_flac_decode(buf.ctypes.data_as(C.c_void_p), len(buf), out.ctypes.data_as(C.c_void_p), 3 * bs, C.byref(n)) != 0
+    assert lib.cw_flac_decode(buf.ctypes.data_as(C.c_void_p), len(buf), None, n_blocks * bs, C.byref(n)) == 0 and n.value == n_blocks * bs
+    monkeypatch.setattr(audio, "MAX_DECODED_SECONDS", 5)       # 80 k frames at 16 kHz < 160 k
+    with pytest.raises(ValueError, match="more sample frames"):
+        audio.decode_flac(data)
+    monkeypatch.setattr(audio, "MAX_DECODED_SECONDS", 60)
+    pcm, sr = audio.decode_flac(data)
+    assert pcm.shape == (n_blocks * bs, 1) and sr == 16000 and int(pcm[0, 0]) == 321 << 16
+
 
 @pytest.mark.gpu
 def test_gpu_flac_path_equals_wav_path(eng, tmp_path):

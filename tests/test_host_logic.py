@@ -408,11 +408,12 @@ def test_generate_kwargs_are_honoured_or_refused():
     to slip through a `val not in (None, False, 0, 0.0, 1, 1.0)` test because True == 1)."""
     from crisperwhisper_amd.pipeline import _check_generate_kwargs as chk
     for ok in ({}, {"num_beams": 5, "language": "<|de|>", "task": "translate", "max_new_tokens": 7, "min_new_tokens": 0},
-               {"do_sample": False, "temperature": 0.0}, {"temperature": 1}, {"temperature": (0.0, 0.2, 0.4)},
+               {"do_sample": False, "temperature": 0.0}, {"temperature": 0}, {"temperature": (0.0, 0.2, 0.4)},
                {"temperature": 0.0, "logprob_threshold": -1.0, "no_speech_threshold": 0.6, "compression_ratio_threshold": 1.35},
                {"num_return_sequences": 1, "prompt_ids": None, "return_timestamps": True}):
         chk(dict(ok))
-    for bad in ({"do_sample": True}, {"do_sample": 1}, {"temperature": 0.5}, {"temperature": True}, {"temperature": ()},
+    for bad in ({"do_sample": True}, {"do_sample": 1}, {"temperature": 0.5}, {"temperature": 1}, {"temperature": 1.0}, {"temperature": (1.0,)},
+                {"temperature": True}, {"temperature": ()},
                 {"temperature": (0.0, 0.2), "no_speech_threshold": 0.6, "logprob_threshold": -1.0},
                 {"temperature": (0.0, 0.2), "compression_ratio_threshold": 1.35}, {"num_return_sequences": 2},
                 {"prompt_ids": np.array([1, 2, 3])}, {"assistant_model": object()}, {"repetition_penalty": 1.1},
