@@ -184,17 +184,24 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
     // with the conversion of the activation rows as those return, which delays the weight stream by one L2 round trip
     __builtin_amdgcn_sched_barrier(0);
     // Rows that feed a LayerNorm consumer (W' x, the consumer applies rstd (. - mean W'1) + b'): rounding x itself to 16 bits
-    // would spend the significand on the row's mean, which the consumer subtracts again -- |mean| / std of precision lost on
-    // rows with an offset.  The row lives in this wave, so its mean is six DPP steps away: round x - mean and add
-    // mean * (W' 1) back in f32 in the epilogue.
+    // spends the significand on the row's mean, which the consumer subtracts again -- a factor sqrt(1 + mean^2 / var) on the
+    // rounding noise of rows with an offset (outlier channels / drifting residual streams of trained checkpoints).  The row
+    // lives in this wave, so its moments are a few DPP steps away: rows with |mean| >= std are rounded as x - mean and
+    // mean * (W' 1) is added back in f32 in the epilogue.  Below that the factor is < 1.41 (half a bit) and the row is rounded
+    // as it is: bit-identical to the uncentred stage, whose parity record the goldens hold (the rows of the synthetic models
+    // sit at |mean| / std ~ 0.3-0.9, where the two roundings differ by noise only -- and that noise moves near-tie argmaxes).
     if (wsum) {                                                  // block-uniform
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            float sx = 0.f;
+            float sx = 0.f, sq = 0.f;
 #pragma unroll
             for (int c = 0; c < PER_LANE; ++c)
-                if (lane + 64 * c < nvec) sx += (xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w);
-            const float mu = wave_sum(sx) / (float)K;
+                if (lane + 64 * c < nvec) {
+                    sx += (xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w);
+                    sq += (xv[i][c].x * xv[i][c].x + xv[i][c].y * xv[i][c].y) + (xv[i][c].z * xv[i][c].z + xv[i][c].w * xv[i][c].w);
+                }
+            float mu = wave_sum(sx) / (float)K;
+            if (2.f * mu * mu < wave_sum(sq) / (float)K) mu = 0.f;    // |mean| < std  <=>  2 mean^2 < E[x^2]
 #pragma unroll
             for (int c = 0; c < PER_LANE; ++c) { xv[i][c].x -= mu; xv[i][c].y -= mu; xv[i][c].z -= mu; xv[i][c].w -= mu; }
             if (lane == 0) smean[wave + 4 * i] = mu;

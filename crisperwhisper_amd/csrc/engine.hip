@@ -66,6 +66,7 @@ struct cw_ctx {
     bool rows_ln_ready = false;     // row sums of the LayerNorm-folded q/k/v, cross-q and fc1 weights are in place (gemv_rows_kernel)
     bool rows_ln_enabled = false;   // CW_ROWS_LN=1 (A/B, measured slower): 17..64 rows without the preparation launch in front of every GEMV
     bool rows_hilo = true;          // CW_NO_ROWS_HILO=1: single 16-bit copy of the residual rows (A/B)
+    bool stack_center = true;       // fused out-projection / cross-query stage rounds x - mean(x) (CW_NO_STACK_CENTER=1: x itself, round-3 behaviour; A/B)
     int skinny_mode = 0;            // 17..64 rows (skinny.hip / attention.hip: attn_cross_full_kernel); option "skinny" / CW_SKINNY=n:
                                     //   0 (default) round-3 path; 1 greedy rows: cross-attention query as a K-split skinny GEMM whose
                                     //   planes the one-block-per-(row, head) cross-attention finishes, which also writes the
@@ -287,6 +288,7 @@ static int create_impl(cw_ctx* c) {
     if (getenv("CW_ROWS_LN")) c->rows_ln_enabled = true;
     if (getenv("CW_NO_ROWS_HILO")) c->rows_hilo = false;
     if (getenv("CW_SKINNY")) c->skinny_mode = atoi(getenv("CW_SKINNY"));
+    if (getenv("CW_NO_STACK_CENTER")) c->stack_center = false;
     if (getenv("CW_FUSE_MLP")) c->fuse_mlp = true;
     if (getenv("CW_NO_WPACK")) c->wpack_enabled = false;
     if (getenv("CW_MLP_PAIR")) c->mlp_pair = true;
@@ -386,6 +388,35 @@ static int create_impl(cw_ctx* c) {
         CWCHK(c, dmalloc(c, &dfb, fb.size() * 4));
         HIPCHK(c, hipMemcpy(dfb, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
         c->mel.cos_t = dct; c->mel.sin_t = dsn; c->mel.window = dwin; c->mel.filters = dfb;
+        // basis of the f64 matrix-core DFT (mel.hip: mel_mfma_kernel) and the non-zero bin range of every mel filter
+        {
+            const int KS = 26, NT = 7;
+            std::vector<double> bas((size_t)4 * KS * NT * 64, 0.0);
+            const double PI = 3.14159265358979323846;
+            for (int q = 0; q < 4; ++q)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int nt = 0; nt < NT; ++nt)
+                        for (int l = 0; l < 64; ++l) {
+                            const int j = ks * 4 + l / 16, k = nt * 16 + l % 16;     // sample column, bin
+                            const int n = (q & 1) ? 2 * j + 1 : 2 * j;
+                            const bool ok = k <= 100 && ((q & 1) ? j <= 99 : j <= 100);
+                            const long long ph = ((long long)k * n) % 400;             // exact phase reduction, like the table of the VALU kernel
+                            const double ang = 2.0 * PI * (double)ph / 400.0;
+                            bas[(((size_t)q * KS + ks) * NT + nt) * 64 + l] = ok ? ((q & 2) ? sin(ang) : cos(ang)) : 0.0;
+                        }
+            double* dbas;
+            CWCHK(c, dmalloc(c, &dbas, bas.size() * 8));
+            HIPCHK(c, hipMemcpy(dbas, bas.data(), bas.size() * 8, hipMemcpyHostToDevice));
+            std::vector<int> lo(nm, nb), hi(nm, -1);
+            for (int m = 0; m < nm; ++m)
+                for (int k = 0; k < nb; ++k)
+                    if (fb[(size_t)k * nm + m] != 0.f) { if (k < lo[m]) lo[m] = k; if (k > hi[m]) hi[m] = k; }
+            int *dlo, *dhi;
+            CWCHK(c, dmalloc(c, &dlo, nm * 4)); CWCHK(c, dmalloc(c, &dhi, nm * 4));
+            HIPCHK(c, hipMemcpy(dlo, lo.data(), nm * 4, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(dhi, hi.data(), nm * 4, hipMemcpyHostToDevice));
+            c->mel.basis = dbas; c->mel.fb_lo = dlo; c->mel.fb_hi = dhi;
+        }
     }
     CWCHK(c, dmalloc(c, &c->d_pcm, (size_t)Bm * CW_N_SAMPLES * 4));
     CWCHK(c, dmalloc(c, &c->d_logspec, (size_t)Bm * CW_N_FRAMES * d.n_mels * 4));
@@ -1009,7 +1040,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 memset(&sp, 0, sizeof(sp));
                 sp.W = L.ws3; sp.wpk = c->wpacked ? 1 : 0; sp.K = D; sp.Mb = nb; sp.nseg = 3;
                 sp.seg[0].x = xin;      sp.seg[0].bias = L.qa_bias; sp.seg[0].out = c->d_qa; sp.seg[0].tile0 = 0;      sp.seg[0].n_tiles = TD; sp.seg[0].epi = 0;
-                sp.seg[0].wsum = L.q_wsum;   // x is rounded as x - mean(x): the operand the cross-attention LayerNorm is sensitive to
+                sp.seg[0].wsum = c->stack_center ? L.q_wsum : nullptr;   // x is rounded as x - mean(x): the operand the cross-attention LayerNorm is sensitive to
                 sp.seg[1].x = c->dattn; sp.seg[1].bias = nullptr;   sp.seg[1].out = c->d_qb; sp.seg[1].tile0 = TD;     sp.seg[1].n_tiles = TD; sp.seg[1].epi = 0;
                 sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo;      sp.seg[2].out = xalt;    sp.seg[2].tile0 = 2 * TD; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
                 sp.seg[2].resid = xin; sp.seg[2].pstats = c->d_pstats;   // LayerNorm partial sums of x1 for the cross-attention
@@ -1061,7 +1092,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 memset(&sp, 0, sizeof(sp));
                 sp.W = L.ws5; sp.wpk = c->wpacked ? 1 : 0; sp.K = D; sp.Mb = nb; sp.nseg = 3;
                 sp.seg[0].x = xalt;     sp.seg[0].bias = L.u1_bias; sp.seg[0].out = c->d_u1; sp.seg[0].tile0 = 0;      sp.seg[0].n_tiles = TF; sp.seg[0].epi = 2;
-                sp.seg[0].wsum = L.u1_wsum;
+                sp.seg[0].wsum = c->stack_center ? L.u1_wsum : nullptr;
                 sp.seg[1].x = c->dattn; sp.seg[1].bias = nullptr;   sp.seg[1].out = c->d_u1; sp.seg[1].tile0 = TF;     sp.seg[1].n_tiles = TF; sp.seg[1].epi = 2;
                 sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo_c;    sp.seg[2].out = xin;     sp.seg[2].tile0 = 2 * TF; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
                 sp.seg[2].resid = xalt; sp.seg[2].out2 = c->dx2c;

@@ -11,6 +11,7 @@
 // [B][n_mels][3000] f32 layout for host inspection.
 #include "common.h"
 #include "kernels.h"
+#include <mutex>
 
 namespace CW_NS {
 
@@ -137,6 +138,144 @@ __global__ __launch_bounds__(256) void mel_kernel(MelTables tb, const float* __r
     if (tid == 0) atomicMax(gmax + b, float_to_ordered(lmax));
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the same folded DFT as a matrix product on the f64 matrix cores (v_mfma_f64_16x16x4_f64).
+// With the n-fold (a[n] = x[n] + x[400-n], b[n] = x[n] - x[400-n]) and the k-fold (bin 200-k from the even-n / odd-n partial
+// sums of bin k) a block of 32 frames is four products  [32 frames x ~101 samples] x [~101 x 101 bins]:
+//     Ce = A_even C_even,  Co = A_odd C_odd,  Se = B_even S_even,  So = B_odd S_odd        (one per wave)
+//     Re X[k] = Ce + Co,  Im X[k] = -(Se + So),  Re X[200-k] = Ce - Co,  Im X[200-k] = So - Se
+// 1.95 GFLOP per 8 clips in f64 -- the arithmetic of the VALU kernel above (which reaches 6 % of the f64 rate: every FMA of
+// its inner loop waits for two LDS operands), fed from LDS (frames) and L2 (the basis, fragment-major: 373 KB shared by every
+// block) at one 512-byte fragment per 64-clock MFMA.  f64 keeps the spectrum exact to 1e-13; an f32 product would sit 7-9e-5
+// from the reference on pure tones (bins 80 dB below the peak see the f32 rounding floor), too close to the 1e-4 bar.
+// LDS: frames a/b even/odd [4][32][105] f64 (later the four products [4][32][112]) | raw samples 5360 f32 (later the power
+// spectrum [32][204] f32) | Hann window [400] f64.
+// ---------------------------------------------------------------------------------------------------
+#define MM_FR 32                       // frames per block
+#define MM_KP 105                      // row stride of the frame arrays (doubles)
+#define MM_NB 112                      // bins 0..100 padded to 7 tiles of 16
+#define MM_KS 26                       // k-steps of 4 (even n: 101 -> 104; odd n: 100)
+typedef __attribute__((ext_vector_type(4))) double f64x4_t;
+
+__global__ __launch_bounds__(256) void mel_mfma_kernel(MelTables tb, const float* __restrict__ pcm, int n_mels,
+                                                       float* __restrict__ logspec_tm, unsigned int* __restrict__ gmax) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_smem[];
+    double* s_ab = (double*)mm_smem;                                    // [4][32][105] -> [4][32][112]
+    float* s_raw = (float*)(mm_smem + (size_t)4 * MM_FR * MM_NB * 8);   // 5360 floats -> power [32][204]
+    double* s_win = (double*)(mm_smem + (size_t)4 * MM_FR * MM_NB * 8 + (size_t)MM_FR * 204 * 4);
+    __shared__ float s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, f0 = blockIdx.x * MM_FR;
+    const float* x = pcm + (size_t)b * N_SAMPLES;
+
+    // ---- raw samples of the block's frames (reflect-padded at the clip edges), window
+    const int s0 = f0 * HOP - N_FFT / 2, n_raw = (MM_FR - 1) * HOP + N_FFT;
+    for (int i = tid; i < n_raw; i += 256) {
+        int k = s0 + i;
+        if (k < 0) k = -k;
+        if (k >= N_SAMPLES) k = 2 * (N_SAMPLES - 1) - k;
+        s_raw[i] = (k >= 0 && k < N_SAMPLES) ? x[k] : 0.f;
+    }
+    for (int i = tid; i < N_FFT; i += 256) s_win[i] = tb.window[i];
+    __syncthreads();
+    // ---- folded frames: q = 0 a even n, 1 a odd n, 2 b even n, 3 b odd n; column j <-> n = 2 j (+ 1)
+    for (int i = tid; i < MM_FR * MM_KP; i += 256) {
+        const int f = i / MM_KP, j = i - f * MM_KP;
+        const bool live = f0 + f < N_FRAMES;
+        double ae = 0.0, ao = 0.0, be = 0.0, bo = 0.0;
+        if (live && j <= 100) {
+            const int n = 2 * j;
+            const double xn = (double)s_raw[f * HOP + n] * s_win[n];
+            if (n == 0 || n == 200) ae = xn;
+            else { const double xm = (double)s_raw[f * HOP + N_FFT - n] * s_win[N_FFT - n]; ae = xn + xm; be = xn - xm; }
+        }
+        if (live && j <= 99) {
+            const int n = 2 * j + 1;
+            const double xn = (double)s_raw[f * HOP + n] * s_win[n], xm = (double)s_raw[f * HOP + N_FFT - n] * s_win[N_FFT - n];
+            ao = xn + xm; bo = xn - xm;
+        }
+        s_ab[(0 * MM_FR + f) * MM_KP + j] = ae; s_ab[(1 * MM_FR + f) * MM_KP + j] = ao;
+        s_ab[(2 * MM_FR + f) * MM_KP + j] = be; s_ab[(3 * MM_FR + f) * MM_KP + j] = bo;
+    }
+    __syncthreads();
+
+    // ---- wave q: product q.  A fragment: lane -> frame lane % 16, sample 4 ks + lane / 16; basis fragment (ks, nt): 64 doubles
+    f64x4_t acc[2][7];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 7; ++nt) acc[mt][nt] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+    const double* basis = tb.basis + (size_t)wave * MM_KS * 7 * 64 + lane;
+    const double* arow = s_ab + ((size_t)wave * MM_FR + (lane & 15)) * MM_KP + (lane >> 4);
+    double bn[7];
+#pragma unroll
+    for (int nt = 0; nt < 7; ++nt) bn[nt] = basis[nt * 64];
+    for (int ks = 0; ks < MM_KS; ++ks) {
+        double bc[7];
+#pragma unroll
+        for (int nt = 0; nt < 7; ++nt) bc[nt] = bn[nt];
+        const int kn = ks + 1 < MM_KS ? ks + 1 : ks;                     // next step's basis is requested under this step's MFMAs
+#pragma unroll
+        for (int nt = 0; nt < 7; ++nt) bn[nt] = basis[((size_t)kn * 7 + nt) * 64];
+        const double a0 = arow[ks * 4], a1 = arow[16 * MM_KP + ks * 4];
+#pragma unroll
+        for (int nt = 0; nt < 7; ++nt) {
+            acc[0][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bc[nt], acc[0][nt], 0, 0, 0);
+            acc[1][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bc[nt], acc[1][nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                                     // every wave is done with the frames
+    // D[frame = mt*16 + lane / 16 + 4 i][bin = nt*16 + lane % 16]   (f64 layout; tools/probe/mfma_f64_layout.hip)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 7; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                s_ab[((size_t)wave * MM_FR + mt * 16 + (lane >> 4) + 4 * i) * MM_NB + nt * 16 + (lane & 15)] = acc[mt][nt][i];
+    __syncthreads();
+    float* s_pw = s_raw;                                                 // [32][204]
+    for (int i = tid; i < MM_FR * 101; i += 256) {
+        const int f = i / 101, k = i - f * 101;
+        const double ce = s_ab[(0 * MM_FR + f) * MM_NB + k], co = s_ab[(1 * MM_FR + f) * MM_NB + k];
+        const double se = s_ab[(2 * MM_FR + f) * MM_NB + k], so = s_ab[(3 * MM_FR + f) * MM_NB + k];
+        const double re1 = ce + co, im1 = se + so, re2 = ce - co, im2 = so - se;
+        s_pw[f * 204 + k] = (float)(re1 * re1 + im1 * im1);
+        s_pw[f * 204 + 200 - k] = (float)(re2 * re2 + im2 * im2);       // k = 100 writes the same bin twice (same value)
+    }
+    __syncthreads();
+
+    // ---- slaney mel bank (sparse triangles: zero weights are skipped, the non-zero terms keep their order), log10, clip maximum
+    float lmax = -INFINITY;
+    const int m = tid & 127, fh = tid >> 7;                              // filter, frame half
+    if (m < n_mels) {
+        double macc[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) macc[f] = 0.0;
+        const int lo = tb.fb_lo[m], hi = tb.fb_hi[m];                    // bins with a non-zero weight: lo .. hi
+        for (int kk = lo; kk <= hi; ++kk) {
+            const float w = tb.filters[kk * n_mels + m];
+            if (w != 0.f) {
+                const double wd = (double)w;
+#pragma unroll
+                for (int f = 0; f < 16; ++f) macc[f] = fma(wd, (double)s_pw[(fh * 16 + f) * 204 + kk], macc[f]);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            const int frame = f0 + fh * 16 + f;
+            if (frame < N_FRAMES) {
+                const float lv = log10f(fmaxf((float)macc[f], 1e-10f));
+                logspec_tm[((size_t)b * N_FRAMES + frame) * n_mels + m] = lv;
+                lmax = fmaxf(lmax, lv);
+            }
+        }
+    }
+    lmax = block_max(lmax, s_red);
+    if (tid == 0) atomicMax(gmax + b, float_to_ordered(lmax));
+}
+
 template <typename T>
 __global__ void mel_finish_kernel(const float* __restrict__ logspec_tm, const unsigned int* __restrict__ gmax,
                                   int n_mels, T* __restrict__ feats_tm, float* __restrict__ feats_hf) {
@@ -157,7 +296,15 @@ __global__ void mel_finish_kernel(const float* __restrict__ logspec_tm, const un
 int cw_launch_mel(const MelTables& t, const float* pcm, int B, int n_mels, float* logspec_tm, unsigned int* gmax,
                   hipStream_t st) {
     if (n_mels > 256 || B <= 0) return CW_ERR_INVALID;
-    hipMemsetAsync(gmax, 0, sizeof(unsigned int) * B, st);   // ordered encoding: 0 is below every float
+    (void)hipMemsetAsync(gmax, 0, sizeof(unsigned int) * B, st);   // ordered encoding: 0 is below every float
+    static const bool valu = getenv("CW_MEL_VALU") != nullptr;   // A/B: round-1 VALU kernel
+    if (t.basis && t.fb_lo && n_mels <= 128 && !valu) {
+        const size_t lds = (size_t)4 * MM_FR * MM_NB * 8 + (size_t)MM_FR * 204 * 4 + (size_t)N_FFT * 8;
+        static std::once_flag attr;
+        std::call_once(attr, [lds] { (void)hipFuncSetAttribute((const void*)mel_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+        hipLaunchKernelGGL(mel_mfma_kernel, dim3((N_FRAMES + MM_FR - 1) / MM_FR, B), dim3(256), lds, st, t, pcm, n_mels, logspec_tm, gmax);
+        return CW_OK;
+    }
     hipLaunchKernelGGL(mel_kernel, dim3((N_FRAMES + MEL_FR - 1) / MEL_FR, B), dim3(256), 0, st, t, pcm, n_mels,
                        logspec_tm, gmax);
     return CW_OK;

@@ -1089,6 +1089,51 @@ def test_fused_decoder_stage_tracks_eight_launch_layer(rows):
     assert (lf.argmax(-1) == le.argmax(-1)).mean() > 0.95
     assert np.abs(af - ae).max() < 2e-2
 
+def test_fused_decoder_stage_on_rows_with_a_large_mean():
+    """The fused out-projection / cross-query stage multiplies the UN-normalised residual row by W'q and lets the consumer
+    apply the LayerNorm (csrc/decfuse.hip).  A row whose mean is far from zero (outlier channels, drifting residual streams:
+    here every decoder position carries an offset of 40 against a spread of ~1) must not lose that factor of precision: rows
+    with |mean| >= std are rounded as x - mean.  Teacher-forced logits of the bf16 engine against the f32 engine: the fused
+    stage is as close as the eight-launch layer (which rounds LN(x)); with the centring switched off (CW_NO_STACK_CENTER=1,
+    the round-3 arithmetic) it is several times further away."""
+    import os
+    g, v = syn.large_v3_geometry()
+    g.enc_layers = g.dec_layers = 2
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19)]
+    W = dict(syn.random_weights(g, seed=9))
+    W["model.decoder.embed_positions.weight"] = (W["model.decoder.embed_positions.weight"] + 40.0).astype(np.float32)
+    rows, T = 8, 10
+    clips = [syn.synth_audio(300 + i, 480000 - 15000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
+    rng = np.random.default_rng(2)
+    ids = np.concatenate([[v.sot, v.lang_id("en"), v.transcribe], [v.timestamp_begin], rng.integers(300, 50000, T - 4)])
+    forced = np.full((rows, T), -1, np.int32); forced[:, 3:] = ids[3:]
+    prompt = np.tile(ids[None, :3], (rows, 1))
+    res = {}
+    for mode, dt, env in (("f32", "f32", None), ("fused", "bf16", None), ("eight", "bf16", "CW_NO_FUSE6"), ("uncentred", "bf16", "CW_NO_STACK_CENTER")):
+        if env:
+            os.environ[env] = "1"
+        try:
+            eng = Engine(spec, dtype=dt, max_batch=rows)
+        finally:
+            if env:
+                os.environ.pop(env, None)
+        try:
+            eng.load_state_dict(W)
+            eng.mel(clips)
+            eng.encode(list(range(rows)), [0] * rows, [3000] * rows)
+            cap = eng.capture_logits(rows, T)
+            eng.decode(prompt, max_length=T, forced=forced)
+            res[mode] = cap[:T - 3].copy()
+            eng.stop_capture()
+        finally:
+            eng.close()
+    ref = res["f32"]
+    err = {m: float(np.sqrt(((res[m] - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())) for m in ("fused", "eight", "uncentred")}
+    assert err["fused"] < 1.3 * err["eight"] + 1e-4, err
+    assert err["uncentred"] > 1.5 * err["fused"], err          # the guard is doing something on these rows
+
+
 
 @pytest.mark.parametrize("rows", [17, 40, 64])
 def test_rows_path_without_preparation_launches_tracks_prepared_path(rows):
