@@ -388,25 +388,8 @@ static int create_impl(cw_ctx* c) {
         CWCHK(c, dmalloc(c, &dfb, fb.size() * 4));
         HIPCHK(c, hipMemcpy(dfb, fb.data(), fb.size() * 4, hipMemcpyHostToDevice));
         c->mel.cos_t = dct; c->mel.sin_t = dsn; c->mel.window = dwin; c->mel.filters = dfb;
-        // basis of the f64 matrix-core DFT (mel.hip: mel_mfma_kernel) and the non-zero bin range of every mel filter
+        // non-zero bin range of every mel filter (mel.hip: mel_mfma_kernel walks only those)
         {
-            const int KS = 26, NT = 7;
-            std::vector<double> bas((size_t)4 * KS * NT * 64, 0.0);
-            const double PI = 3.14159265358979323846;
-            for (int q = 0; q < 4; ++q)
-                for (int ks = 0; ks < KS; ++ks)
-                    for (int nt = 0; nt < NT; ++nt)
-                        for (int l = 0; l < 64; ++l) {
-                            const int j = ks * 4 + l / 16, k = nt * 16 + l % 16;     // sample column, bin
-                            const int n = (q & 1) ? 2 * j + 1 : 2 * j;
-                            const bool ok = k <= 100 && ((q & 1) ? j <= 99 : j <= 100);
-                            const long long ph = ((long long)k * n) % 400;             // exact phase reduction, like the table of the VALU kernel
-                            const double ang = 2.0 * PI * (double)ph / 400.0;
-                            bas[(((size_t)q * KS + ks) * NT + nt) * 64 + l] = ok ? ((q & 2) ? sin(ang) : cos(ang)) : 0.0;
-                        }
-            double* dbas;
-            CWCHK(c, dmalloc(c, &dbas, bas.size() * 8));
-            HIPCHK(c, hipMemcpy(dbas, bas.data(), bas.size() * 8, hipMemcpyHostToDevice));
             std::vector<int> lo(nm, nb), hi(nm, -1);
             for (int m = 0; m < nm; ++m)
                 for (int k = 0; k < nb; ++k)
@@ -415,7 +398,7 @@ static int create_impl(cw_ctx* c) {
             CWCHK(c, dmalloc(c, &dlo, nm * 4)); CWCHK(c, dmalloc(c, &dhi, nm * 4));
             HIPCHK(c, hipMemcpy(dlo, lo.data(), nm * 4, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(dhi, hi.data(), nm * 4, hipMemcpyHostToDevice));
-            c->mel.basis = dbas; c->mel.fb_lo = dlo; c->mel.fb_hi = dhi;
+            c->mel.fb_lo = dlo; c->mel.fb_hi = dhi;
         }
     }
     CWCHK(c, dmalloc(c, &c->d_pcm, (size_t)Bm * CW_N_SAMPLES * 4));

@@ -222,11 +222,10 @@ struct MelTables {
     const double* sin_t;  // [400]
     const double* window; // [400]
     const float* filters; // [201][n_mels]
-    // f64 matrix-core kernel (mel.hip: mel_mfma_kernel): DFT basis in MFMA B-fragment order [4 products][26 k-steps][7 bin
-    // tiles][64 lanes] (products: cos even n, cos odd n, sin even n, sin odd n; lane -> sample 4 ks + lane / 16, bin 16 nt + lane % 16)
-    const double* basis;
+    // f64 matrix-core kernel (mel.hip: mel_mfma_kernel)
     const int* fb_lo;     // [n_mels] first / last FFT bin with a non-zero filter weight
     const int* fb_hi;
+    int dbg;              // -DCW_SK_DEBUG builds: ablation switches
 };
 
 

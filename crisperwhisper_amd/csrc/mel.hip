@@ -145,27 +145,35 @@ __global__ __launch_bounds__(256) void mel_kernel(MelTables tb, const float* __r
 //     Ce = A_even C_even,  Co = A_odd C_odd,  Se = B_even S_even,  So = B_odd S_odd        (one per wave)
 //     Re X[k] = Ce + Co,  Im X[k] = -(Se + So),  Re X[200-k] = Ce - Co,  Im X[200-k] = So - Se
 // 1.95 GFLOP per 8 clips in f64 -- the arithmetic of the VALU kernel above (which reaches 6 % of the f64 rate: every FMA of
-// its inner loop waits for two LDS operands), fed from LDS (frames) and L2 (the basis, fragment-major: 373 KB shared by every
-// block) at one 512-byte fragment per 64-clock MFMA.  f64 keeps the spectrum exact to 1e-13; an f32 product would sit 7-9e-5
+// its inner loop waits for two LDS operands).  A wave owns two 16-bin tiles of ALL FOUR products, so Ce, Co, Se, So of a
+// (frame, bin) end up in one lane; the basis fragments are gathered from the 400-entry cos / sin tables in LDS by phase
+// (k n mod 400) -- a fragment-major basis in memory (373 KB per block from L2, 280 MB per 8 clips) was the first version's
+// limiter.  f64 keeps the spectrum exact to 1e-13; an f32 product would sit 7-9e-5
 // from the reference on pure tones (bins 80 dB below the peak see the f32 rounding floor), too close to the 1e-4 bar.
-// LDS: frames a/b even/odd [4][32][105] f64 (later the four products [4][32][112]) | raw samples 5360 f32 (later the power
-// spectrum [32][204] f32) | Hann window [400] f64.
+// LDS: frames a/b even/odd [4][32][105] f64 | raw samples 5360 f32 (later the power spectrum [32][204] f32) | Hann window,
+// cos, sin tables [400] f64 each.
 // ---------------------------------------------------------------------------------------------------
 #define MM_FR 32                       // frames per block
 #define MM_KP 105                      // row stride of the frame arrays (doubles)
-#define MM_NB 112                      // bins 0..100 padded to 7 tiles of 16
 #define MM_KS 26                       // k-steps of 4 (even n: 101 -> 104; odd n: 100)
 typedef __attribute__((ext_vector_type(4))) double f64x4_t;
 
 __global__ __launch_bounds__(256) void mel_mfma_kernel(MelTables tb, const float* __restrict__ pcm, int n_mels,
                                                        float* __restrict__ logspec_tm, unsigned int* __restrict__ gmax) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mm_smem[];
-    double* s_ab = (double*)mm_smem;                                    // [4][32][105] -> [4][32][112]
-    float* s_raw = (float*)(mm_smem + (size_t)4 * MM_FR * MM_NB * 8);   // 5360 floats -> power [32][204]
-    double* s_win = (double*)(mm_smem + (size_t)4 * MM_FR * MM_NB * 8 + (size_t)MM_FR * 204 * 4);
+    double* s_ab = (double*)mm_smem;                                    // [4][32][105]
+    float* s_raw = (float*)(mm_smem + (size_t)4 * MM_FR * MM_KP * 8);   // 5360 floats -> power [32][204]
+    double* s_win = (double*)(mm_smem + (size_t)4 * MM_FR * MM_KP * 8 + (size_t)MM_FR * 204 * 4);
+    double* s_cos = s_win + N_FFT;
+    double* s_sin = s_cos + N_FFT;
     __shared__ float s_red[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CW_SK_DEBUG
+    const int dbg = tb.dbg;
+#else
+    const int dbg = 0;
+#endif
     const int b = blockIdx.y, f0 = blockIdx.x * MM_FR;
     const float* x = pcm + (size_t)b * N_SAMPLES;
 
@@ -177,11 +185,10 @@ __global__ __launch_bounds__(256) void mel_mfma_kernel(MelTables tb, const float
         if (k >= N_SAMPLES) k = 2 * (N_SAMPLES - 1) - k;
         s_raw[i] = (k >= 0 && k < N_SAMPLES) ? x[k] : 0.f;
     }
-    for (int i = tid; i < N_FFT; i += 256) s_win[i] = tb.window[i];
+    for (int i = tid; i < N_FFT; i += 256) { s_win[i] = tb.window[i]; s_cos[i] = tb.cos_t[i]; s_sin[i] = tb.sin_t[i]; }
     __syncthreads();
     // ---- folded frames: q = 0 a even n, 1 a odd n, 2 b even n, 3 b odd n; column j <-> n = 2 j (+ 1)
-    for (int i = tid; i < MM_FR * MM_KP; i += 256) {
-        const int f = i / MM_KP, j = i - f * MM_KP;
+    for (int j = tid & 7, f = tid >> 3; j < ((dbg & 2) ? 8 : MM_KP); j += 8) {            // 8 threads per frame
         const bool live = f0 + f < N_FRAMES;
         double ae = 0.0, ao = 0.0, be = 0.0, bo = 0.0;
         if (live && j <= 100) {
@@ -200,49 +207,78 @@ __global__ __launch_bounds__(256) void mel_mfma_kernel(MelTables tb, const float
     }
     __syncthreads();
 
-    // ---- wave q: product q.  A fragment: lane -> frame lane % 16, sample 4 ks + lane / 16; basis fragment (ks, nt): 64 doubles
-    f64x4_t acc[2][7];
+    // ---- wave w: bin tiles 2 w, 2 w + 1 (wave 3: tile 6 only) of all four products, both frame tiles.  A fragment: lane ->
+    // frame lane % 16, sample column 4 ks + lane / 16.  The basis never leaves the CU: cos / sin of the 400 phases sit in LDS and
+    // a lane gathers entry (bin * n) mod 400 of its (sample, bin), advancing the phase by 8 bin per k-step (n grows by 8).
+    const int ntl = wave < 3 ? 2 : 1;                                    // wave-uniform
+    f64x4_t acc[4][2][2];                                                // [product][frame tile][bin tile]
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int nt = 0; nt < 7; ++nt) acc[mt][nt] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
-    const double* basis = tb.basis + (size_t)wave * MM_KS * 7 * 64 + lane;
-    const double* arow = s_ab + ((size_t)wave * MM_FR + (lane & 15)) * MM_KP + (lane >> 4);
-    double bn[7];
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 7; ++nt) bn[nt] = basis[nt * 64];
-    for (int ks = 0; ks < MM_KS; ++ks) {
-        double bc[7];
+            for (int t = 0; t < 2; ++t) acc[q][mt][t] = (f64x4_t){0.0, 0.0, 0.0, 0.0};
+    int ph_e[2], ph_o[2], dph[2];                                        // phases (k n mod 400) of the even / odd sample, step 8 k mod 400
 #pragma unroll
-        for (int nt = 0; nt < 7; ++nt) bc[nt] = bn[nt];
-        const int kn = ks + 1 < MM_KS ? ks + 1 : ks;                     // next step's basis is requested under this step's MFMAs
+    for (int t = 0; t < 2; ++t) {
+        const int bin = (wave * 2 + t) * 16 + (lane & 15), j = lane >> 4;
+        ph_e[t] = (bin * (2 * j)) % N_FFT; ph_o[t] = (bin * (2 * j + 1)) % N_FFT; dph[t] = (bin * 8) % N_FFT;
+    }
+    const double* arow = s_ab + (size_t)(lane & 15) * MM_KP + (lane >> 4);
+    // operands of k-step ks + 1 are read from LDS under the MFMAs of k-step ks
+    double an[4][2], bn[2][4];
+    auto fetch = [&](int ks) {
 #pragma unroll
-        for (int nt = 0; nt < 7; ++nt) bn[nt] = basis[((size_t)kn * 7 + nt) * 64];
-        const double a0 = arow[ks * 4], a1 = arow[16 * MM_KP + ks * 4];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int nt = 0; nt < 7; ++nt) {
-            acc[0][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bc[nt], acc[0][nt], 0, 0, 0);
-            acc[1][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bc[nt], acc[1][nt], 0, 0, 0);
+            for (int mt = 0; mt < 2; ++mt) an[q][mt] = arow[((size_t)q * MM_FR + mt * 16) * MM_KP + ks * 4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bn[t][0] = s_cos[ph_e[t]]; bn[t][1] = s_cos[ph_o[t]]; bn[t][2] = s_sin[ph_e[t]]; bn[t][3] = s_sin[ph_o[t]];
+            ph_e[t] += dph[t]; ph_e[t] -= ph_e[t] >= N_FFT ? N_FFT : 0;
+            ph_o[t] += dph[t]; ph_o[t] -= ph_o[t] >= N_FFT ? N_FFT : 0;
+        }
+    };
+    fetch(0);
+    const int n_ks = (dbg & 1) ? 1 : MM_KS;
+    for (int ks = 0; ks < n_ks; ++ks) {
+        double a[4][2], bc[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q][0] = an[q][0]; a[q][1] = an[q][1]; }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bc[t][q] = bn[t][q];
+        if (ks + 1 < n_ks) fetch(ks + 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < ntl) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[q][mt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][mt], bc[t][q], acc[q][mt][t], 0, 0, 0);
+            }
         }
     }
-    __syncthreads();                                                     // every wave is done with the frames
-    // D[frame = mt*16 + lane / 16 + 4 i][bin = nt*16 + lane % 16]   (f64 layout; tools/probe/mfma_f64_layout.hip)
+    // D[frame = mt*16 + lane / 16 + 4 i][bin = nt*16 + lane % 16]   (f64 layout; tools/probe/mfma_f64_layout.hip): the four
+    // products of a (frame, bin) sit in the same lane, so the power spectrum needs no exchange
+    float* s_pw = s_raw;                                                 // [32][204]; the raw samples were consumed by the fold
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int t = 0; t < 2; ++t) {
+        const int k = (wave * 2 + t) * 16 + (lane & 15);
+        if (t < ntl && k <= 100) {
 #pragma unroll
-        for (int nt = 0; nt < 7; ++nt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                s_ab[((size_t)wave * MM_FR + mt * 16 + (lane >> 4) + 4 * i) * MM_NB + nt * 16 + (lane & 15)] = acc[mt][nt][i];
-    __syncthreads();
-    float* s_pw = s_raw;                                                 // [32][204]
-    for (int i = tid; i < MM_FR * 101; i += 256) {
-        const int f = i / 101, k = i - f * 101;
-        const double ce = s_ab[(0 * MM_FR + f) * MM_NB + k], co = s_ab[(1 * MM_FR + f) * MM_NB + k];
-        const double se = s_ab[(2 * MM_FR + f) * MM_NB + k], so = s_ab[(3 * MM_FR + f) * MM_NB + k];
-        const double re1 = ce + co, im1 = se + so, re2 = ce - co, im2 = so - se;
-        s_pw[f * 204 + k] = (float)(re1 * re1 + im1 * im1);
-        s_pw[f * 204 + 200 - k] = (float)(re2 * re2 + im2 * im2);       // k = 100 writes the same bin twice (same value)
+                for (int i = 0; i < 4; ++i) {
+                    const int f = mt * 16 + (lane >> 4) + 4 * i;
+                    const double ce = acc[0][mt][t][i], co = acc[1][mt][t][i], se = acc[2][mt][t][i], so = acc[3][mt][t][i];
+                    const double re1 = ce + co, im1 = se + so, re2 = ce - co, im2 = so - se;
+                    if (k < 100) s_pw[f * 204 + 200 - k] = (float)(re2 * re2 + im2 * im2);
+                    s_pw[f * 204 + k] = k == 100 ? (float)(re2 * re2 + im2 * im2) : (float)(re1 * re1 + im1 * im1);   // bin 100: the value the VALU kernel's second write leaves
+                }
+        }
     }
     __syncthreads();
 
@@ -253,13 +289,24 @@ __global__ __launch_bounds__(256) void mel_mfma_kernel(MelTables tb, const float
         double macc[16];
 #pragma unroll
         for (int f = 0; f < 16; ++f) macc[f] = 0.0;
-        const int lo = tb.fb_lo[m], hi = tb.fb_hi[m];                    // bins with a non-zero weight: lo .. hi
-        for (int kk = lo; kk <= hi; ++kk) {
-            const float w = tb.filters[kk * n_mels + m];
-            if (w != 0.f) {
-                const double wd = (double)w;
+        const int lo = tb.fb_lo[m], hi = tb.fb_hi[m];                    // bins with a non-zero weight: lo .. hi (<= 14 wide up to 80 mels)
+        float wv[16];
 #pragma unroll
-                for (int f = 0; f < 16; ++f) macc[f] = fma(wd, (double)s_pw[(fh * 16 + f) * 204 + kk], macc[f]);
+        for (int u = 0; u < 16; ++u) wv[u] = tb.filters[min(lo + u, N_BINS - 1) * n_mels + m];   // all requests out at once
+        for (int u0 = 0; lo + u0 <= hi && !(dbg & 4); u0 += 16) {
+            if (u0 > 0) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = tb.filters[min(lo + u0 + u, N_BINS - 1) * n_mels + m];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int kk = lo + u0 + u;
+                const float w = wv[u];
+                if (kk <= hi && w != 0.f) {
+                    const double wd = (double)w;
+#pragma unroll
+                    for (int f = 0; f < 16; ++f) macc[f] = fma(wd, (double)s_pw[(fh * 16 + f) * 204 + kk], macc[f]);
+                }
             }
         }
 #pragma unroll
@@ -298,11 +345,16 @@ int cw_launch_mel(const MelTables& t, const float* pcm, int B, int n_mels, float
     if (n_mels > 256 || B <= 0) return CW_ERR_INVALID;
     (void)hipMemsetAsync(gmax, 0, sizeof(unsigned int) * B, st);   // ordered encoding: 0 is below every float
     static const bool valu = getenv("CW_MEL_VALU") != nullptr;   // A/B: round-1 VALU kernel
-    if (t.basis && t.fb_lo && n_mels <= 128 && !valu) {
-        const size_t lds = (size_t)4 * MM_FR * MM_NB * 8 + (size_t)MM_FR * 204 * 4 + (size_t)N_FFT * 8;
+#ifdef CW_SK_DEBUG
+    MelTables t2 = t; t2.dbg = getenv("CW_MEL_DBG") ? atoi(getenv("CW_MEL_DBG")) : 0;
+#else
+    const MelTables& t2 = t;
+#endif
+    if (t.fb_lo && n_mels <= 128 && !valu) {
+        const size_t lds = (size_t)4 * MM_FR * MM_KP * 8 + (size_t)MM_FR * 204 * 4 + (size_t)3 * N_FFT * 8;
         static std::once_flag attr;
         std::call_once(attr, [lds] { (void)hipFuncSetAttribute((const void*)mel_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-        hipLaunchKernelGGL(mel_mfma_kernel, dim3((N_FRAMES + MM_FR - 1) / MM_FR, B), dim3(256), lds, st, t, pcm, n_mels, logspec_tm, gmax);
+        hipLaunchKernelGGL(mel_mfma_kernel, dim3((N_FRAMES + MM_FR - 1) / MM_FR, B), dim3(256), lds, st, t2, pcm, n_mels, logspec_tm, gmax);
         return CW_OK;
     }
     hipLaunchKernelGGL(mel_kernel, dim3((N_FRAMES + MEL_FR - 1) / MEL_FR, B), dim3(256), 0, st, t, pcm, n_mels,
