@@ -514,7 +514,7 @@ def main():
             if t:
                 by = 3456000.0 * B
                 sr["mel"] = {"bound": "hbm", "algorithmic_bytes": by, "ms_per_call": t, "achieved_GBps": by / t / 1e6,
-                             "frac_of_8TBps": by / t / 1e6 / 8000.0, "note": "f64 direct-DFT: VALU-bound by design, off the critical path"}
+                             "frac_of_8TBps": by / t / 1e6 / 8000.0, "note": "folded 400-point DFT on the f64 matrix cores (v_mfma_f64_16x16x4_f64: issue-bound, ~29 TFLOP/s f64 measured); an f32 product would sit 7-9e-5 from the reference on pure tones (bar 1e-4)"}
             t = per_call("encoder")
             if t:
                 fl = 2.274e12 * B
