@@ -14,6 +14,7 @@ seeded random tensors of the large-v3 geometry (no checkpoint is available offli
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -447,6 +448,9 @@ def main():
                                 f"contiguous chunk shards over {world} rank(s) = {[h - l for l, h in dist.shard_bounds(n_chunks, world)]}, "
                                 f"batch {B}, {a.tokens} tokens/pass, one all-gather of {dist.REC_WORDS * 4}-byte chunk records, seam merge + pause split",
                     "wall_s": lw, "rtf": lw / a.longform_seconds, "aligned_words_per_s": len(res["chunks"]) / lw, "words": len(res["chunks"]),
+                    "chunk_shards": [h - l for l, h in dist.shard_bounds(n_chunks, world)],
+                    # digest of the merged output (text + every word with its timestamps): the same at every rank count
+                    "output_sha1": hashlib.sha1(json.dumps([res["text"], [[c["text"], list(c["timestamp"])] for c in res["chunks"]]]).encode()).hexdigest(),
                     "scaling": "strong", "n_gpus": world}
     # roofline of the decode-step kernels, HIP events on the engine's own stream
     roof = {}

@@ -103,3 +103,31 @@ def test_bench_gpus2_spawns_two_ranks_and_reports_them():
     assert rec["n_gpus"] == 2 and rec["collective"]["ranks_seen"] == 2
     assert rec["collective"]["chunks_per_rank"] == [2, 2] and rec["config"]["parallelism"] == "chunk-dp2"
     assert rec["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus8_large_geometry_shards_the_long_recording_like_one_rank():
+    """What the driver's 8-GPU run does, on the one device of the box: `bench.py --gpus 8` at the large-v3 geometry spawns eight
+    ranks (sharing the GPU: 8 x 3.1 GB of weights; collectives over gloo because eight RCCL ranks cannot share a device).  The
+    line must report 8 ranks seen by the communicator, the BASELINE configs[2] recording (600 s -> 30 chunks) sharded
+    (4,4,4,4,4,4,3,3), and the merged word list -- every word and timestamp, by digest -- must be the one a single rank
+    produces from the same recording (chunks are independent)."""
+    env = dict(os.environ, CW_DIST_BACKEND="gloo", PYTHONUNBUFFERED="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--geometry", "large-v3", "--batch", "4", "--tokens", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+              "--no-config3", "--kernel-iters", "3"]
+    recs = {}
+    for n in (1, 8):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + common + (["--no-rccl"] if n == 1 else []),
+                           env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        recs[n] = json.loads(lines[0])
+    r8, r1 = recs[8], recs[1]
+    assert r8["n_gpus"] == 8 and r8["collective"]["ranks_seen"] == 8 and r8["config"]["parallelism"] == "chunk-dp8"
+    assert r8["collective"]["chunks_per_rank"] == [4] * 8
+    assert r8["longform"]["chunk_shards"] == [4, 4, 4, 4, 4, 4, 3, 3] and r1["longform"]["chunk_shards"] == [30]
+    assert r8["longform"]["words"] == r1["longform"]["words"] > 0
+    assert r8["longform"]["output_sha1"] == r1["longform"]["output_sha1"]
