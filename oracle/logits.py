@@ -40,9 +40,8 @@ class ProcessorSpec:
         self.min_new_tokens = min_new_tokens or 0
 
 
-def process(spec: ProcessorSpec, input_ids: np.ndarray, scores: np.ndarray, begin_index: int,
-            prompt_len: int) -> np.ndarray:
-    """input_ids [B,t] (prompt + generated so far), scores [B,V] f32 -> processed [B,V]."""
+def _masked(spec: ProcessorSpec, input_ids: np.ndarray, scores: np.ndarray, begin_index: int, prompt_len: int) -> np.ndarray:
+    """Every processor up to (not including) the timestamp-mass rule of WhisperTimeStampLogitsProcessor (:2041-2045)."""
     s = scores.astype(np.float32).copy()
     B, t = input_ids.shape
     # MinNewTokensLengthLogitsProcessor :250-260
@@ -74,8 +73,25 @@ def process(spec: ProcessorSpec, input_ids: np.ndarray, scores: np.ndarray, begi
         s[:, :tb] = NEG_INF
         if spec.max_initial_timestamp_index is not None:
             s[:, tb + spec.max_initial_timestamp_index + 1:] = NEG_INF
+    return s
+
+
+def process(spec: ProcessorSpec, input_ids: np.ndarray, scores: np.ndarray, begin_index: int,
+            prompt_len: int) -> np.ndarray:
+    """input_ids [B,t] (prompt + generated so far), scores [B,V] f32 -> processed [B,V]."""
+    s = _masked(spec, input_ids, scores, begin_index, prompt_len)
+    tb = spec.timestamp_begin
     lp = log_softmax(s)
-    for k in range(B):
+    for k in range(s.shape[0]):
         if logsumexp(lp[k, tb:]) > lp[k, :tb].max():
             s[k, :tb] = NEG_INF
     return s
+
+
+def timestamp_mass_margin(spec: ProcessorSpec, input_ids: np.ndarray, scores: np.ndarray, begin_index: int, prompt_len: int) -> np.ndarray:
+    """[B] logsumexp(log p[timestamps]) - max(log p[text]) of the masked scores: the quantity the timestamp-mass rule
+    (:2041-2045) compares with zero -- how far a row is from switching between "a timestamp is forced" and "text allowed"."""
+    s = _masked(spec, input_ids, scores, begin_index, prompt_len)
+    tb = spec.timestamp_begin
+    lp = log_softmax(s)
+    return np.asarray([logsumexp(lp[k, tb:]) - lp[k, :tb].max() for k in range(s.shape[0])], dtype=np.float32)

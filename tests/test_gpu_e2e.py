@@ -928,13 +928,16 @@ def test_bench_geometry_second_weight_seed_other_audio(dtype):
         pipe.engine.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_longform_600s_at_bench_geometry_vs_transformers(dtype):
     """BASELINE configs[2] at full geometry against the reference: the 600 s recording of bench.py's longform leg through
     transformers.pipeline(chunk_length_s=30, batch_size=4) on the CPU (tests/golden/gen_golden_bench2.py longform: 30 chunks, 5 s
     strides, 29 seams merged by _decode_asr) and through the drop-in pipeline with the same arguments.  f32 engine: word for
-    word; bf16 engine (free-running over 30 chunks): >= 97 % of the reference words reproduced within one frame, measured by the
-    longest common word subsequence so that a single divergent chunk cannot shift everything after it."""
+    word; 16-bit engines (free-running over 30 chunks; f16 is the reference's own GPU dtype, REF/transcribe.py:10): >= 98.5 % of
+    the reference words reproduced within one frame (measured: bf16 1098, f16 1100 of 1113), measured by the longest common word subsequence so
+    that a single divergent chunk cannot shift everything after it.  Why not 100 %: profiles/r04_longform_divergence.txt lists
+    every decoder row that parts from the reference with the f32 engine's logit margin at that token -- 0.0009-0.039 on a logit
+    range of 17, inside the 16-bit engines' own rounding noise (rms 0.011 / 0.003): ties, broken differently."""
     import os, difflib
     path = os.path.join(os.path.dirname(__file__), "golden", "e2e_bench_longform_golden.json")
     if not os.path.exists(path):
@@ -947,7 +950,7 @@ def test_longform_600s_at_bench_geometry_vs_transformers(dtype):
     pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, dict(_aligned_weights(g, gold["weight_seed"]).items())),
                        tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=gold["pipeline"]["chunk_length_s"],
                        batch_size=gold["pipeline"]["batch_size"], return_timestamps="word",
-                       torch_dtype={"bf16": "bfloat16", "f32": "float32"}[dtype], device="cuda:0")
+                       torch_dtype={"bf16": "bfloat16", "f32": "float32", "f16": "float16"}[dtype], device="cuda:0")
     try:
         out = pipe(x, generate_kwargs=dict(gold["generate_kwargs"]))
         ref = gold["chunks"]
@@ -972,7 +975,7 @@ def test_longform_600s_at_bench_geometry_vs_transformers(dtype):
             ok, why = Hh.words_equal(out["chunks"], ref, tol=0.02)
             assert ok, why
         else:
-            assert close >= 0.97 * len(ref), (close, matched, len(ref))
+            assert close >= 0.985 * len(ref), (close, matched, len(ref))
     finally:
         pipe.engine.close()
 
