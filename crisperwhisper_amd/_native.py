@@ -96,6 +96,7 @@ _SIGS = {
     "cw_test_gemm": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "cw_test_gemm_fp8": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "cw_test_gemv": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "cw_has_experiments": (_I, []),
     "cw_test_skinny": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P]),
     "cw_test_attention": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "cw_test_cross_attention": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P]),

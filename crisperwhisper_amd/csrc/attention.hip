@@ -30,6 +30,7 @@ __device__ inline f32x4_t mfma16a(bf16x8_t a, bf16x8_t b, f32x4_t c) { return cw
 #define KS_STRIDE 72   // bf16 per K row in LDS (64 + 8)
 #define VS_STRIDE 66   // bf16 per V^T row in LDS (64 keys + 2): 33 dwords -> spreads the transposing writes
 
+#ifdef CW_EXPERIMENTS   // round-1 encoder attention (32 queries per wave), A/B only (CW_ATTN_V1=1)
 // grid: (ceil(S/128), H, B), 256 threads; wave w owns queries q0 + w*32 .. +31 (two 16-query tiles).
 __global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __restrict__ Q,
                                                                 const bf16_t* __restrict__ K,
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void attn_encoder_bf16_kernel(const bf16_t* __
         }
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Second-generation encoder attention (the default): same S^T = K Q^T / O^T = V^T P^T register scheme as the kernel above, but
@@ -525,11 +527,13 @@ int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* 
                            int S_pad, hipStream_t st) {
     if (bf16) {
         if (S_pad % KT != 0 || S_pad < S) return CW_ERR_INVALID;
+#ifdef CW_EXPERIMENTS
         static const bool v1 = getenv("CW_ATTN_V1") != nullptr;   // the round-1 32-queries-per-wave kernel (A/B comparisons)
         if (v1)
             hipLaunchKernelGGL(attn_encoder_bf16_kernel, dim3(((S + 127) / 128) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
                                (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
         else
+#endif
             hipLaunchKernelGGL(attn_encoder_q64_kernel<4>, dim3(((S + 255) / 256) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
                                (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
     } else {
@@ -1013,6 +1017,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
     }
 }
 
+#ifdef CW_EXPERIMENTS   // measured slower than the key-split kernel at every batch size (17.1 vs 11.7 us at B = 8, 103 vs 76 us at B = 64)
 // ---------------------------------------------------------------------------------------------------
 // Cross-attention decode, ONE block per (row, head) over all keys (six-launch layer, decfuse.hip).  grid (H, B), 512 threads:
 // an 8-lane group owns keys grp, grp+64, ... (24 rows of 128 B at 1500 frames) and every K and V row of the block is
@@ -1143,6 +1148,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_full_kernel(CrossSpl
         p.align_ml[(rowi * ATT_NS + sI) * 2 + 1] = sI == 0 ? l : 0.f;
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Cross-attention decode for nq = 2..16 rows that share one K/V (the hypotheses of one audio item under beam search), on the
@@ -1340,20 +1346,26 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > 4 * (CROSS_THREADS / 8) || CROSS_THREADS != 512) return CW_ERR_INVALID;
     // every key split must own at least one key (the kernels clamp their loads to the split's last key)
     if (p.n_keys < 1 || (ATT_NS - 1) * ((p.n_keys + ATT_NS - 1) / ATT_NS) >= p.n_keys) return CW_ERR_INVALID;
+#ifndef CW_EXPERIMENTS
+    if (p.a_frag || p.a_out) return CW_ERR_INVALID;   // the full-key kernel is an A/B build (-DCW_EXPERIMENTS)
+#else
     if (p.a_frag) {   // 17..64 greedy rows: one block per (row, head) writes the out-projection's 16-bit rows -- no partials, no combine
         if (!bf16 || p.kv_div > 1 || p.H > 20 || p.n_keys > CROSSF_U * (CROSS_THREADS / 8)) return CW_ERR_INVALID;
         if (p.xstat ? (!p.qa || !p.qw || !p.qbias || p.q_planes < 1) : !p.q) return CW_ERR_INVALID;
         hipLaunchKernelGGL((attn_cross_full_kernel<bf16_t>), dim3(p.H, p.B), dim3(CROSS_THREADS), 0, st, p);
         return CW_OK;
     }
+#endif
     if (p.xstat || p.pstats) {   // fused out-projection / query stage: the query is finished in the kernel; 16-bit caches
         if (!bf16 || p.kv_div > 1 || p.H > 20 || !p.qa || !p.qb || !p.qw || !p.qbias || p.q_planes > 1) return CW_ERR_INVALID;
+#ifdef CW_EXPERIMENTS
         if (p.a_out) {
             if (!p.xstat) return CW_ERR_INVALID;   // one block per (row, head), finished output (A/B: 17 us per launch against 12 with six key splits)
             if (p.n_keys > CROSSF_U * (CROSS_THREADS / 8)) return CW_ERR_INVALID;
             hipLaunchKernelGGL((attn_cross_full_kernel<bf16_t>), dim3(p.H, p.B), dim3(CROSS_THREADS), 0, st, p);
             return CW_OK;
         }
+#endif
         if (!p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.B > 16) return CW_ERR_INVALID;
         hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, 1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
         return CW_OK;

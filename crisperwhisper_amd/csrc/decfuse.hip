@@ -327,6 +327,10 @@ int cw_launch_gemv_stack(const StackParams& p_in, int nt, hipStream_t st) {
     return launch_stack_nt<2, 3>(p, st);
 }
 
+// ===================================================================================================
+// Measured and rejected: kept as published A/Bs behind -DCW_EXPERIMENTS, not part of the default library.
+// ===================================================================================================
+#ifdef CW_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------
 // gemv_fc2x_kernel: x3 = x2 + W2 gelu(fc1) + b2 with fc1 finished on load,
 //     mid[m][k] = gelu(rstd_m (u[m][k] - mean_m w1sum[k]) + b1[k]),
@@ -929,5 +933,12 @@ int cw_launch_gemv_rows(int epi, bool produce, const RowsParams& p, hipStream_t 
         default: return CW_ERR_INVALID;
     }
 }
+
+#else   // !CW_EXPERIMENTS: the measured-and-rejected stages are not in the library (make EXTRA=-DCW_EXPERIMENTS builds them)
+int cw_launch_gemv_fc2x(const Fc2xParams&, hipStream_t) { return CW_ERR_INVALID; }
+int cw_launch_mlp_pair(const MlpPairParams&, hipStream_t) { return CW_ERR_INVALID; }
+int cw_launch_rows_prep(const float*, int, int, void*, float*, int, hipStream_t) { return CW_ERR_INVALID; }
+int cw_launch_gemv_rows(int, bool, const RowsParams&, hipStream_t) { return CW_ERR_INVALID; }
+#endif
 
 }  // namespace CW_NS

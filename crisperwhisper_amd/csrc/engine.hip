@@ -66,6 +66,8 @@ struct cw_ctx {
     bool rows_ln_ready = false;     // row sums of the LayerNorm-folded q/k/v, cross-q and fc1 weights are in place (gemv_rows_kernel)
     bool rows_ln_enabled = false;   // CW_ROWS_LN=1 (A/B, measured slower): 17..64 rows without the preparation launch in front of every GEMV
     bool rows_hilo = true;          // CW_NO_ROWS_HILO=1: single 16-bit copy of the residual rows (A/B)
+    bool mid16 = true;              // fc1 hands gelu(.) to fc2 in 16 bits (CW_NO_MID16=1: f32; A/B)
+    bool dtw_block = false;         // CW_DTW_BLOCK=1: round-1 block-per-sequence DTW (A/B)
     bool stack_center = true;       // fused out-projection / cross-query stage rounds x - mean(x) (CW_NO_STACK_CENTER=1: x itself, round-3 behaviour; A/B)
     int skinny_mode = 0;            // 17..64 rows (skinny.hip / attention.hip: attn_cross_full_kernel); option "skinny" / CW_SKINNY=n:
                                     //   0 (default) round-3 path; 1 greedy rows: cross-attention query as a K-split skinny GEMM whose
@@ -289,6 +291,13 @@ static int create_impl(cw_ctx* c) {
     if (getenv("CW_NO_ROWS_HILO")) c->rows_hilo = false;
     if (getenv("CW_SKINNY")) c->skinny_mode = atoi(getenv("CW_SKINNY"));
     if (getenv("CW_NO_STACK_CENTER")) c->stack_center = false;
+    if (getenv("CW_NO_MID16")) c->mid16 = false;
+    if (getenv("CW_DTW_BLOCK")) c->dtw_block = true;
+#ifndef CW_EXPERIMENTS
+    for (const char* sw : {"CW_ROWS_LN", "CW_FUSE_MLP", "CW_MLP_PAIR", "CW_SKINNY"})
+        if (getenv(sw) && atoi(getenv(sw)) != 0)
+            return fail(c, CW_ERR_INVALID, "%s selects a measured-and-rejected kernel variant that is not in this build: make EXTRA=-DCW_EXPERIMENTS", sw);
+#endif
     if (getenv("CW_FUSE_MLP")) c->fuse_mlp = true;
     if (getenv("CW_NO_WPACK")) c->wpack_enabled = false;
     if (getenv("CW_MLP_PAIR")) c->mlp_pair = true;
@@ -1050,7 +1059,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                     CWCHK(c, KD(c, cw_launch_mlp_pair, mp, c->st));
                 } else {
                     // fc1 writes gelu(.) in the 16-bit type fc2 would round it to anyway (bit-identical): fc2's activation load halves
-                    const bool mid16 = F > 1280 && !getenv("CW_NO_MID16");
+                    const bool mid16 = F > 1280 && c->mid16;
                     {
                         EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
                         CWCHK(c, gemv_ln(c, mid16 ? EPI_GELU : EPI_GELU_F32, xalt, nb, D, L.w1, F, L.ln2_g, nullptr, ep));
@@ -1571,7 +1580,7 @@ int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, 
             c->skew_cap = want;
         }
     }
-    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, getenv("CW_DTW_BLOCK") ? c->d_path_text : nullptr, getenv("CW_DTW_BLOCK") ? c->d_path_time : nullptr, c->d_path_len, c->st, c->d_skew));
+    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->dtw_block ? c->d_path_text : nullptr, getenv("CW_DTW_BLOCK") ? c->d_path_time : nullptr, c->d_path_len, c->st, c->d_skew));
     KCHK(c);
     tm.stop();
     std::vector<int> fc((size_t)nb * N);
@@ -1928,6 +1937,10 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
         c->nb_encoded = 0;                                   // windows must be re-encoded
         return CW_OK;
     }
+#ifndef CW_EXPERIMENTS
+    if ((!strcmp(name, "rows_ln") || !strcmp(name, "skinny")) && value != 0)
+        return fail(c, CW_ERR_INVALID, "option %s selects a measured-and-rejected kernel variant that is not in this build (make EXTRA=-DCW_EXPERIMENTS)", name);
+#endif
     if (!strcmp(name, "rows_ln")) {   // 17..64-row decode: 0 = preparation launch in front of every GEMV (A/B, differential tests)
         c->rows_ln_enabled = value != 0;
         for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // graphs hold the kernel choice
@@ -1939,6 +1952,16 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
         return CW_OK;
     }
     return fail(c, CW_ERR_INVALID, "unknown option %s", name);
+}
+
+// 1 when the library was built with -DCW_EXPERIMENTS (the measured-and-rejected kernel variants and their A/B switches:
+// DESIGN.md "A/B switches"); the differential tests of those variants skip otherwise.
+int32_t cw_has_experiments(void) {
+#ifdef CW_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int32_t cw_test_set_option(const char* name, int32_t value) {
@@ -2053,6 +2076,9 @@ int32_t cw_test_gemv(cw_ctx* c, int32_t Mb, int32_t N, int32_t K, const float* x
 // rotating weight copies larger than the Infinity Cache (cold weights, as in a decoder pass); us[0] = GEMM, us[1] = finish.
 int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K, const float* x, const float* W, const float* bias,
                        int32_t nks, int32_t reps, float* out, float* us) {
+#ifndef CW_EXPERIMENTS
+    return fail(c, CW_ERR_INVALID, "cw_test_skinny: csrc/skinny.hip is an A/B build (make EXTRA=-DCW_EXPERIMENTS)");
+#endif
     if (!c->bf16) return fail(c, CW_ERR_INVALID, "cw_test_skinny: 16-bit engines only");
     if (Mb < 1 || Mb > 64 || K % 32 || N % 16 || mode < 0 || mode > 2 || (mode == 1 && N % 32)) return fail(c, CW_ERR_INVALID, "cw_test_skinny: bad shape");
     const int MT = (Mb + 15) / 16;

@@ -26,6 +26,7 @@
 
 namespace CW_NS {
 
+#ifdef CW_EXPERIMENTS   // measured against the round-3 path in the step and rejected (profiles/r04_b64_*): A/B builds only
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 __device__ static inline f32x4_t mfma16s(bf16x8_t a, bf16x8_t b, f32x4_t c) { return cw_mfma_16x16x32(a, b, c); }
 __device__ static inline void sk_glds16(const void* gsrc, void* lds_wave_base) {
@@ -340,5 +341,12 @@ int cw_launch_skinny_finish(int epi, const SkinnyFinishParams& p, hipStream_t st
     }
     return CW_OK;
 }
+
+#else
+int cw_skinny_pick_nks(int, int, int) { return 0; }
+int cw_launch_skinny(int, const SkinnyParams&, int, hipStream_t) { return CW_ERR_INVALID; }
+int cw_launch_skinny_finish(int, const SkinnyFinishParams&, hipStream_t) { return CW_ERR_INVALID; }
+void cw_launch_skinny_empty(hipStream_t) {}
+#endif
 
 }  // namespace CW_NS

@@ -248,6 +248,8 @@ void cw_collate_free(cw_collator* c);
 
 /* ---- kernel-level hooks used by the parity tests (host f32 in/out, run in the context's dtype) -------- */
 /* process-wide tuning knobs for the tests: "gemm256_min_tiles" = tile count from which the 256x256 GEMM is used */
+/* 1 when the library carries the measured-and-rejected kernel variants (built with make EXTRA=-DCW_EXPERIMENTS). */
+int32_t cw_has_experiments(void);
 int32_t cw_test_set_option(const char* name, int32_t value);
 int32_t cw_test_gemm(cw_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, const float* W,
                      const float* bias, int32_t gelu, float* out);

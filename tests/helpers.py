@@ -148,3 +148,10 @@ class OracleBackedEngine:
 
     def adjust_pauses(self, start, end, thr):
         raise AssertionError("pause splitting must run on the device in product code")
+
+
+def has_experiments() -> bool:
+    """The library was built with `make EXTRA=-DCW_EXPERIMENTS`: the measured-and-rejected kernel variants ("A/B
+    switches") and the differential tests that hold them correct are available."""
+    from crisperwhisper_amd import _native
+    return bool(_native.load().cw_has_experiments())
