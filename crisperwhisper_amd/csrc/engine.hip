@@ -52,6 +52,10 @@ struct cw_ctx {
     int Bm = 0, S_pad = 0, Vpad = 0;
     size_t esz = 4;
     hipStream_t st = nullptr;
+    hipStream_t st2 = nullptr;          // side stream of the decode step: run-ahead prefetch of the next layer's streams (CW_PREFETCH)
+    hipEvent_t ev_pf[2] = {nullptr, nullptr};
+    int prefetch = 0;                   // 0 off; n > 0: blocks of the prefetch launch
+    unsigned int* d_pf_sink = nullptr;
     std::vector<void*> allocs;
     char err[512] = "";
     bool err_set = false;      // a specific message is pending (set by fail(), cleared by cw_last_error)
@@ -132,6 +136,7 @@ struct cw_ctx {
     bool gen_set = false;
     bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
     bool enc8 = false;                   // encoder linear layers + cross-K/V projection as e4m3 GEMMs ("encoder_gemm_fp8")
+    int enc8_mask = 0;                   // which of them: 1 q/k/v, 2 fc1, 4 fc2, 8 cross-K/V projection (option value 1 = all = 15)
     bool enc8_stale = false;             // a tensor was (re)loaded after the e4m3 copies were made
     void *h8 = nullptr, *mid8 = nullptr; float *sa8 = nullptr, *smid8 = nullptr;   // e4m3 activations and their row scales
     // beam search (cw_beam_*): rows = items x beams; self-attention keys are found through the ancestry table
@@ -280,6 +285,10 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipEventCreate(&c->ev1));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_step[0], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_step[1], hipEventDisableTiming));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[0], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[1], hipEventDisableTiming));
+    if (getenv("CW_PREFETCH")) c->prefetch = atoi(getenv("CW_PREFETCH"));
     HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
     if (d.dtype != CW_DTYPE_F32 && d.dtype != CW_DTYPE_BF16 && d.dtype != CW_DTYPE_F16) return fail(c, CW_ERR_INVALID, "unknown dtype %d", d.dtype);
     c->f16 = d.dtype == CW_DTYPE_F16;
@@ -457,6 +466,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_argmax, (size_t)Bm * TGT * 4));
     CWCHK(c, dmalloc(c, &c->d_last_ts, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_finished, Bm * 4));
     CWCHK(c, dmalloc(c, &c->d_nunf, 4));
+    CWCHK(c, dmalloc(c, &c->d_pf_sink, 4));
     CWCHK(c, dmalloc(c, &c->d_pos, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_cfg, 4 * 4));
     CWCHK(c, dmalloc(c, &c->d_mask, (size_t)V + 16));
     CWCHK(c, dmalloc(c, &c->d_sample_part, (size_t)Bm * 16 * 32));
@@ -521,6 +531,8 @@ void cw_destroy(cw_ctx* c) {
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& e : c->ev_step) if (e) hipEventDestroy(e);
+    for (auto& e : c->ev_pf) if (e) hipEventDestroy(e);
+    if (c->st2) hipStreamDestroy(c->st2);
     if (c->st) hipStreamDestroy(c->st);
     delete c;
 }
@@ -882,13 +894,13 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
     const int M = nb * S;
     for (int l = 0; l < c->d.enc_layers; ++l) {
         LayerW& L = c->enc[l];
-        if (c->enc8) CWCHK(c, KD(c, cw_launch_layernorm_fp8, c->x, L.ln1_g, L.ln1_b, c->h8, c->sa8, M, D, c->st));
+        if (c->enc8_mask & 1) CWCHK(c, KD(c, cw_launch_layernorm_fp8, c->x, L.ln1_g, L.ln1_b, c->h8, c->sa8, M, D, c->st));
         else CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, L.ln1_g, L.ln1_b, c->h, M, D, c->st));
         {
             AParams ap{c->h, D, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.out = c->qb; ep.out1 = c->kb; ep.out2 = c->vb; ep.bias = L.bqkv;
             ep.T = S; ep.S_pad = c->S_pad; ep.H = H; ep.d_model = D;
-            if (c->enc8) CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_HEADS, c->h8, D, L.wqkv8, M, 3 * D, D, c->sa8, L.sqkv, ep, c->st));
+            if (c->enc8_mask & 1) CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_HEADS, c->h8, D, L.wqkv8, M, 3 * D, D, c->sa8, L.sqkv, ep, c->st));
             else CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_HEADS, ap, L.wqkv, M, 3 * D, D, ep, c->st));
         }
         CWCHK(c, KD(c, cw_launch_attn_encoder, bf, c->qb, c->kb, c->vb, c->ao, nb, H, S, c->S_pad, c->st));
@@ -897,25 +909,25 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
             EpiParams ep = epi0(); ep.outf = c->x; ep.resid = c->x; ep.bias = L.bo; ep.ldo = D;
             CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_RESID_F32, ap, L.wo, M, D, D, ep, c->st));
         }
-        if (c->enc8) CWCHK(c, KD(c, cw_launch_layernorm_fp8, c->x, L.ln2_g, L.ln2_b, c->h8, c->sa8, M, D, c->st));
+        if (c->enc8_mask & 2) CWCHK(c, KD(c, cw_launch_layernorm_fp8, c->x, L.ln2_g, L.ln2_b, c->h8, c->sa8, M, D, c->st));
         else CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, L.ln2_g, L.ln2_b, c->h, M, D, c->st));
         {
             AParams ap{c->h, D, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.out = c->mid; ep.bias = L.b1; ep.ldo = F;
-            if (c->enc8) CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_GELU, c->h8, D, L.w18, M, F, D, c->sa8, L.s1, ep, c->st));
+            if (c->enc8_mask & 2) CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_GELU, c->h8, D, L.w18, M, F, D, c->sa8, L.s1, ep, c->st));
             else CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_GELU, ap, L.w1, M, F, D, ep, c->st));
         }
         {
             AParams ap{c->mid, F, 0, 0, 0, 0, nullptr, nullptr};
             EpiParams ep = epi0(); ep.outf = c->x; ep.resid = c->x; ep.bias = L.b2; ep.ldo = D;
-            if (c->enc8) {   // GELU output: its row maxima are only known once fc1 is complete -> one row-wise quantisation pass
+            if (c->enc8_mask & 4) {   // GELU output: its row maxima are only known once fc1 is complete -> one row-wise quantisation pass
                 CWCHK(c, KD(c, cw_launch_quant_rows_fp8, c->mid, M, F, c->mid8, c->smid8, c->st));
                 CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_RESID_F32, c->mid8, F, L.w28, M, D, F, c->smid8, L.s2, ep, c->st));
             } else CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_RESID_F32, ap, L.w2, M, D, F, ep, c->st));
         }
     }
     CWCHK(c, KD(c, cw_launch_layernorm, bf, c->x, c->enc_ln_g, c->enc_ln_b, c->enc_out, M, D, c->st));   // cw_get_encoder_output
-    if (c->enc8) CWCHK(c, KD(c, cw_launch_layernorm_fp8, c->x, c->enc_ln_g, c->enc_ln_b, c->h8, c->sa8, M, D, c->st));
+    if (c->enc8_mask & 8) CWCHK(c, KD(c, cw_launch_layernorm_fp8, c->x, c->enc_ln_g, c->enc_ln_b, c->h8, c->sa8, M, D, c->st));
     KCHK(c);
     tm.stop();
     StageTimer tk(c, CW_STAGE_CROSS_KV);
@@ -924,7 +936,7 @@ int32_t cw_encode(cw_ctx* c, int32_t nb, const int32_t* item, const int32_t* see
         AParams ap{c->enc_out, D, 0, 0, 0, 0, nullptr, nullptr};
         EpiParams ep = epi0(); ep.out = L.ck; ep.out1 = L.cv; ep.bias = L.bkv_c;
         ep.T = S; ep.S_pad = S; ep.H = H; ep.d_model = D;
-        if (c->enc8) CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_HEADS, c->h8, D, L.wkv_c8, M, 2 * D, D, c->sa8, L.skv_c, ep, c->st));
+        if (c->enc8_mask & 8) CWCHK(c, KD(c, cw_launch_gemm_fp8, EPI_HEADS, c->h8, D, L.wkv_c8, M, 2 * D, D, c->sa8, L.skv_c, ep, c->st));
         else CWCHK(c, KD(c, cw_launch_gemm, bf, EPI_HEADS, ap, L.wkv_c, M, 2 * D, D, ep, c->st));
         if (c->kv8) CWCHK(c, KD(c, cw_launch_kv_quant_fp8, L.ck, L.cv, L.ck8, L.cv8, L.kvs, nb, H, S, c->st));
     }
@@ -949,6 +961,52 @@ static int gemv_ln(cw_ctx* c, int epi, const float* x, int Mb, int K, const void
     int r = KD(c, cw_launch_layernorm_f32, x, g, b, c->dxn, Mb, K, c->st);   // f32 parity mode: unfused LN
     if (r != CW_OK) return r;
     return KD(c, cw_launch_gemv, false, epi, c->dxn, Mb, K, W, N, nullptr, nullptr, ep, c->st);
+}
+
+
+// Run-ahead prefetch of a decoder layer's HBM streams (weights + this batch's cross-attention K/V) into the Infinity Cache.
+// A decode kernel's first bytes arrive 1.5-2 us after its launch when they come from HBM; on operands the previous launch left
+// in the 256 MB Infinity Cache the same kernels run 0.7-1.5 us shorter each (tests/gpu_microbench.py).  The
+// layer's 110 MB are therefore touched one layer ahead -- one 4-byte load per 64-byte sector, so the lines go HBM -> Infinity
+// Cache and only 1/16 of the bytes travel on to the CU -- by a light launch on a side stream (a parallel branch of the captured
+// step graph) that shares the CUs with the layer's own launches.
+struct PrefetchRanges { const char* p[8]; unsigned long long n[8]; int count; };
+__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchRanges r, unsigned int* sink) {
+    unsigned int acc = 0;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
+    for (int k = 0; k < r.count; ++k) {
+        const size_t sectors = r.n[k] >> 6;
+        const char* base = r.p[k];
+        size_t s = tid;
+        for (; s + 7 * nthr < sectors; s += 8 * nthr) {          // eight independent loads in flight per lane
+            unsigned int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const unsigned int*)(base + ((s + u * nthr) << 6));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u];
+        }
+        for (; s < sectors; s += nthr) acc ^= *(const unsigned int*)(base + (s << 6));
+    }
+    if (acc == 0x9e3779b9u && sink) *sink = acc;                  // keeps the loads alive; practically never taken
+}
+
+static int launch_prefetch_layer(cw_ctx* c, int l, int nb) {
+    const int D = c->d.d_model, F = c->d.ffn_dim, H = c->d.n_heads;
+    const size_t e = c->esz;
+    LayerW& L = c->dec[l];
+    PrefetchRanges r;
+    memset(&r, 0, sizeof(r));
+    auto add = [&](const void* p, size_t bytes) { if (p && bytes && r.count < 8) { r.p[r.count] = (const char*)p; r.n[r.count] = bytes; ++r.count; } };
+    add(L.wqkv, (size_t)3 * D * D * e);
+    if (c->fuse6_ready && c->fuse6_enabled && nb <= 16 && c->beam_K == 0) add(L.ws3, (size_t)3 * D * D * e);
+    else { add(L.wo, (size_t)D * D * e); add(L.wq_c, (size_t)D * D * e); }
+    add(L.ck, (size_t)nb * H * CW_N_CTX * 64 * e);
+    add(L.cv, (size_t)nb * H * CW_N_CTX * 64 * e);
+    add(L.wo_c, (size_t)D * D * e);
+    add(L.w1, (size_t)F * D * e);
+    add(L.w2, (size_t)D * F * e);
+    hipLaunchKernelGGL(prefetch_kernel, dim3(c->prefetch), dim3(256), 0, c->st2, r, c->d_pf_sink);
+    return CW_OK;
 }
 
 // One decoder forward for the nb rows at the positions held in c->d_pos (device): 8 launches per layer.
@@ -1009,8 +1067,14 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         return KD(c, cw_launch_gemv_rows, (int)EPI_RESID_F32, true, rp, c->st);
     };
     if (rows) CWCHK(c, KD(c, cw_launch_rows_prep, c->dx, nb, D, c->d_xfrag, c->d_rstats, lo_off, c->st));
+    const bool pf = c->prefetch > 0 && c->bf16 && c->beam_K == 0 && !c->kv8;
     for (int l = 0; l < c->d.dec_layers; ++l) {
         LayerW& L = c->dec[l];
+        if (pf && l + 1 < c->d.dec_layers) {   // layer l + 1's streams are touched while layer l runs (side stream: a parallel graph branch)
+            HIPCHK(c, hipEventRecord(c->ev_pf[0], c->st));
+            HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_pf[0], 0));
+            CWCHK(c, launch_prefetch_layer(c, l + 1, nb));
+        }
         {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
             EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
             ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
@@ -1168,6 +1232,10 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             else if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
             else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
         }
+    }
+    if (pf && c->d.dec_layers > 1) {           // join the side stream (required before the capture ends; the last prefetch is long done)
+        HIPCHK(c, hipEventRecord(c->ev_pf[1], c->st2));
+        HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_pf[1], 0));
     }
     if (want_logits) {   // final LN + tied proj_out (:790, :1080), logits in f32 (utils.py:2894)
         EpiParams ep = epi0(); ep.outf = c->dlogits; ep.ldo = c->Vpad;
@@ -1916,7 +1984,7 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
         return CW_OK;
     }
     if (!strcmp(name, "encoder_gemm_fp8")) {
-        if (!value) { c->enc8 = false; c->nb_encoded = 0; return CW_OK; }
+        if (!value) { c->enc8 = false; c->enc8_mask = 0; c->nb_encoded = 0; return CW_OK; }
         if (!c->bf16) return fail(c, CW_ERR_INVALID, "encoder_gemm_fp8 needs a 16-bit engine (the f32 engine is the parity mode)");
         const int D = c->d.d_model, F = c->d.ffn_dim;
         if (D % 256 != 0 || F % 256 != 0 || D > 2048) return fail(c, CW_ERR_INVALID, "encoder_gemm_fp8: d_model / ffn_dim must be multiples of 256 (d_model <= 2048)");
@@ -1934,6 +2002,7 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
         }
         CWCHK(c, enc8_quantise(c));
         c->enc8 = true;
+        c->enc8_mask = value == 1 ? 15 : (value & 15);   // 1 = every GEMM; otherwise a mask (sensitivity sweeps: tools/fp8_sweep.py)
         c->nb_encoded = 0;                                   // windows must be re-encoded
         return CW_OK;
     }

@@ -137,9 +137,10 @@ class Engine:
         if getattr(self, "_enc_fp8", False):
             self.set_encoder_gemm_fp8(True)
 
-    def set_encoder_gemm_fp8(self, on: bool):
-        """(Re)build the e4m3 copies of the resident encoder / cross-K/V weights and switch the encoder GEMMs to them, or back."""
-        self._chk(self.lib.cw_set_option(self.ctx, b"encoder_gemm_fp8", 1 if on else 0))
+    def set_encoder_gemm_fp8(self, on):
+        """(Re)build the e4m3 copies of the resident encoder / cross-K/V weights and switch the encoder GEMMs to them, or back.
+        ``on``: True = every GEMM; an int > 1 = mask (1 q/k/v, 2 fc1, 4 fc2, 8 cross-K/V projection) for sensitivity sweeps."""
+        self._chk(self.lib.cw_set_option(self.ctx, b"encoder_gemm_fp8", int(on) if not isinstance(on, bool) else (1 if on else 0)))
 
     def check_weights(self):
         self._chk(self.lib.cw_check_weights(self.ctx))
