@@ -257,6 +257,50 @@ struct StageTimer {
     }
 };
 
+#ifdef CW_EXPERIMENTS   // measured slower (profiles/r04_prefetch_side_stream_rejected.txt)
+// Run-ahead prefetch of a decoder layer's HBM streams (weights + this batch's cross-attention K/V) into the Infinity Cache.
+// A decode kernel's first bytes arrive 1.5-2 us after its launch when they come from HBM; on operands the previous launch left
+// in the 256 MB Infinity Cache the same kernels run 0.7-1.5 us shorter each (tests/gpu_microbench.py, DESIGN.md 6d).  The
+// layer's 110 MB are therefore touched one layer ahead -- one 4-byte load per 64-byte sector, so the lines go HBM -> Infinity
+// Cache and only 1/16 of the bytes travel on to the CU -- by a light launch on a side stream (a parallel branch of the captured
+// step graph) that shares the CUs with the layer's own launches.
+struct PrefetchRanges { const char* p[8]; unsigned long long n[8]; int count; };
+template <int WIDE>
+__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchRanges r, unsigned int* sink) {
+    unsigned int acc = 0;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
+    for (int k = 0; k < r.count; ++k) {
+        const char* base = r.p[k];
+        if (WIDE) {                                               // every byte, 16 B per lane (A/B)
+            const size_t chunks = r.n[k] >> 4;
+            size_t s = tid;
+            for (; s + 7 * nthr < chunks; s += 8 * nthr) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const uint4*)(base + ((s + u * nthr) << 4));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].w;
+            }
+            for (; s < chunks; s += nthr) acc ^= ((const uint4*)(base))[s].x;
+        } else {
+            const size_t sectors = r.n[k] >> 6;
+            size_t s = tid;
+            for (; s + 7 * nthr < sectors; s += 8 * nthr) {      // eight independent loads in flight per lane
+                unsigned int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const unsigned int*)(base + ((s + u * nthr) << 6));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc ^= v[u];
+            }
+            for (; s < sectors; s += nthr) acc ^= *(const unsigned int*)(base + (s << 6));
+        }
+    }
+    if (acc == 0x9e3779b9u && sink) *sink = acc;                  // keeps the loads alive; practically never taken
+}
+
+
+#endif
+
 extern "C" {
 
 int32_t cw_abi_version(void) { return 1; }
@@ -288,7 +332,9 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[0], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[1], hipEventDisableTiming));
+#ifdef CW_EXPERIMENTS
     if (getenv("CW_PREFETCH")) c->prefetch = atoi(getenv("CW_PREFETCH"));
+#endif
     HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
     if (d.dtype != CW_DTYPE_F32 && d.dtype != CW_DTYPE_BF16 && d.dtype != CW_DTYPE_F16) return fail(c, CW_ERR_INVALID, "unknown dtype %d", d.dtype);
     c->f16 = d.dtype == CW_DTYPE_F16;
@@ -303,7 +349,7 @@ static int create_impl(cw_ctx* c) {
     if (getenv("CW_NO_MID16")) c->mid16 = false;
     if (getenv("CW_DTW_BLOCK")) c->dtw_block = true;
 #ifndef CW_EXPERIMENTS
-    for (const char* sw : {"CW_ROWS_LN", "CW_FUSE_MLP", "CW_MLP_PAIR", "CW_SKINNY"})
+    for (const char* sw : {"CW_ROWS_LN", "CW_FUSE_MLP", "CW_MLP_PAIR", "CW_SKINNY", "CW_PREFETCH"})
         if (getenv(sw) && atoi(getenv(sw)) != 0)
             return fail(c, CW_ERR_INVALID, "%s selects a measured-and-rejected kernel variant that is not in this build: make EXTRA=-DCW_EXPERIMENTS", sw);
 #endif
@@ -964,32 +1010,7 @@ static int gemv_ln(cw_ctx* c, int epi, const float* x, int Mb, int K, const void
 }
 
 
-// Run-ahead prefetch of a decoder layer's HBM streams (weights + this batch's cross-attention K/V) into the Infinity Cache.
-// A decode kernel's first bytes arrive 1.5-2 us after its launch when they come from HBM; on operands the previous launch left
-// in the 256 MB Infinity Cache the same kernels run 0.7-1.5 us shorter each (tests/gpu_microbench.py, DESIGN.md 6d).  The
-// layer's 110 MB are therefore touched one layer ahead -- one 4-byte load per 64-byte sector, so the lines go HBM -> Infinity
-// Cache and only 1/16 of the bytes travel on to the CU -- by a light launch on a side stream (a parallel branch of the captured
-// step graph) that shares the CUs with the layer's own launches.
-struct PrefetchRanges { const char* p[8]; unsigned long long n[8]; int count; };
-__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchRanges r, unsigned int* sink) {
-    unsigned int acc = 0;
-    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthr = (size_t)gridDim.x * 256;
-    for (int k = 0; k < r.count; ++k) {
-        const size_t sectors = r.n[k] >> 6;
-        const char* base = r.p[k];
-        size_t s = tid;
-        for (; s + 7 * nthr < sectors; s += 8 * nthr) {          // eight independent loads in flight per lane
-            unsigned int v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *(const unsigned int*)(base + ((s + u * nthr) << 6));
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc ^= v[u];
-        }
-        for (; s < sectors; s += nthr) acc ^= *(const unsigned int*)(base + (s << 6));
-    }
-    if (acc == 0x9e3779b9u && sink) *sink = acc;                  // keeps the loads alive; practically never taken
-}
-
+#ifdef CW_EXPERIMENTS
 static int launch_prefetch_layer(cw_ctx* c, int l, int nb) {
     const int D = c->d.d_model, F = c->d.ffn_dim, H = c->d.n_heads;
     const size_t e = c->esz;
@@ -1005,9 +1026,17 @@ static int launch_prefetch_layer(cw_ctx* c, int l, int nb) {
     add(L.wo_c, (size_t)D * D * e);
     add(L.w1, (size_t)F * D * e);
     add(L.w2, (size_t)D * F * e);
-    hipLaunchKernelGGL(prefetch_kernel, dim3(c->prefetch), dim3(256), 0, c->st2, r, c->d_pf_sink);
+    static const int wide = getenv("CW_PREFETCH_WIDE") ? atoi(getenv("CW_PREFETCH_WIDE")) : 0;
+    static const int what = getenv("CW_PREFETCH_WHAT") ? atoi(getenv("CW_PREFETCH_WHAT")) : 3;   // 1 weights, 2 cross K/V, 3 both
+    if (!(what & 1)) { int k = 0; for (int i = 0; i < r.count; ++i) if (r.p[i] == (const char*)L.ck || r.p[i] == (const char*)L.cv) { r.p[k] = r.p[i]; r.n[k] = r.n[i]; ++k; } r.count = k; }
+    if (!(what & 2)) { int k = 0; for (int i = 0; i < r.count; ++i) if (r.p[i] != (const char*)L.ck && r.p[i] != (const char*)L.cv) { r.p[k] = r.p[i]; r.n[k] = r.n[i]; ++k; } r.count = k; }
+    if (wide) hipLaunchKernelGGL(prefetch_kernel<1>, dim3(c->prefetch), dim3(256), 0, c->st2, r, c->d_pf_sink);
+    else hipLaunchKernelGGL(prefetch_kernel<0>, dim3(c->prefetch), dim3(256), 0, c->st2, r, c->d_pf_sink);
     return CW_OK;
 }
+#else
+static int launch_prefetch_layer(cw_ctx*, int, int) { return CW_ERR_INVALID; }
+#endif
 
 // One decoder forward for the nb rows at the positions held in c->d_pos (device): 8 launches per layer.
 static int decode_step(cw_ctx* c, int nb, bool want_logits) {

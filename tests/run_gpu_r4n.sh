@@ -1,16 +1,24 @@
 #!/bin/bash
-# run-ahead prefetch A/B (CW_PREFETCH = blocks of the side-stream launch; 0 = off)
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
-for pf in 0 32 64 128 256 0; do
-  export CW_PREFETCH=$pf
-  timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config3 --no-longform > gpurun_out/r4n_bench_pf$pf.json 2>gpurun_out/r4n_pf$pf.err
+run() {
+  timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config3 --no-longform > gpurun_out/r4n_b.json 2>gpurun_out/r4n_b.err
   python - <<PY
 import json
 try:
-    d=json.loads(open("gpurun_out/r4n_bench_pf$pf.json").read().strip().splitlines()[-1])
-    print("prefetch=$pf step", round(d["ms_per_step"],1), "decode ms/step", round(d["stage_roofline"]["decode_step"]["ms_per_step"],4), "parity", d["parity"]["ok"])
+    d=json.loads(open("gpurun_out/r4n_b.json").read().strip().splitlines()[-1])
+    print("$1 step", round(d["ms_per_step"],1), "decode ms/step", round(d["stage_roofline"]["decode_step"]["ms_per_step"],4), "parity", d["parity"]["ok"])
 except Exception as e:
-    print("prefetch=$pf failed", e); print(open("gpurun_out/r4n_pf$pf.err").read()[-800:])
+    print("$1 failed", e); print(open("gpurun_out/r4n_b.err").read()[-800:])
 PY
-done
+}
+export CW_PREFETCH=0; run "off"
+export CW_PREFETCH=256 CW_PREFETCH_WIDE=1 CW_PREFETCH_WHAT=3; run "graph wide all 256"
+export CW_PREFETCH=256 CW_PREFETCH_WIDE=1 CW_PREFETCH_WHAT=1; run "graph wide weights 256"
+export CW_PREFETCH=256 CW_PREFETCH_WIDE=0 CW_PREFETCH_WHAT=3; run "graph sector all 256"
+export CW_NO_GRAPH=1
+export CW_PREFETCH=0; run "eager off"
+export CW_PREFETCH=256 CW_PREFETCH_WIDE=1 CW_PREFETCH_WHAT=3; run "eager wide all 256"
+export CW_PREFETCH=256 CW_PREFETCH_WIDE=0 CW_PREFETCH_WHAT=3; run "eager sector all 256"
+export CW_PREFETCH=256 CW_PREFETCH_WIDE=0 CW_PREFETCH_WHAT=1; run "eager sector weights 256"
+export CW_PREFETCH=64 CW_PREFETCH_WIDE=1 CW_PREFETCH_WHAT=3; run "eager wide all 64"
