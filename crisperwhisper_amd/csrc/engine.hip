@@ -136,7 +136,7 @@ struct cw_ctx {
     bool gen_set = false;
     bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
     bool enc8 = false;                   // encoder linear layers + cross-K/V projection as e4m3 GEMMs ("encoder_gemm_fp8")
-    int enc8_mask = 0;                   // which of them: 1 q/k/v, 2 fc1, 4 fc2, 8 cross-K/V projection (option value 1 = all = 15)
+    int enc8_mask = 0;                   // which of them: 1 q/k/v, 2 fc1, 4 fc2, 8 cross-K/V projection (option value 1 = all, 16 + mask = subset)
     bool enc8_stale = false;             // a tensor was (re)loaded after the e4m3 copies were made
     void *h8 = nullptr, *mid8 = nullptr; float *sa8 = nullptr, *smid8 = nullptr;   // e4m3 activations and their row scales
     // beam search (cw_beam_*): rows = items x beams; self-attention keys are found through the ancestry table
@@ -2031,7 +2031,7 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
         }
         CWCHK(c, enc8_quantise(c));
         c->enc8 = true;
-        c->enc8_mask = value == 1 ? 15 : (value & 15);   // 1 = every GEMM; otherwise a mask (sensitivity sweeps: tools/fp8_sweep.py)
+        c->enc8_mask = value >= 16 ? ((value - 16) & 15) : 15;   // 1 = every GEMM; 16 + mask = a subset (tools/fp8_sweep.py)
         c->nb_encoded = 0;                                   // windows must be re-encoded
         return CW_OK;
     }

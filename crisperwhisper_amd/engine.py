@@ -68,7 +68,9 @@ class Engine:
         cache, half the bytes of its dominant stream -- an accuracy-gated performance mode, not the parity path.
         ``encoder_gemm_dtype="fp8"`` (16-bit engines only; BASELINE configs[3]): the encoder's qkv / fc1 / fc2 projections and
         the cross-K/V projection run as e4m3 x e4m3 MFMA GEMMs with row-wise scales (weights quantised once after loading,
-        activations by the LayerNorm that produces them) -- likewise accuracy-gated, not the parity path."""
+        activations by the LayerNorm that produces them) -- likewise accuracy-gated, not the parity path.  ``"fp8:fc1"`` (any subset of
+        qkv / fc1 / fc2 / cross_kv joined by "+") quantises only those; "fp8:fc1" together with ``cross_kv_dtype="fp8"`` is the
+        largest subset that reproduces every reference clip of the batch-64 workload (profiles/r04_fp8_sweep.txt)."""
         self.lib = N.load()
         self.spec = spec
         self.dtype = dtype
@@ -100,9 +102,12 @@ class Engine:
             raise ValueError(f"cross_kv_dtype must be None or 'fp8', got {cross_kv_dtype!r}")
         if cross_kv_dtype == "fp8":
             self._chk(self.lib.cw_set_option(self.ctx, b"cross_kv_fp8", 1))
-        if encoder_gemm_dtype not in (None, "bf16", "f16", "f32", "fp8"):
-            raise ValueError(f"encoder_gemm_dtype must be None or 'fp8', got {encoder_gemm_dtype!r}")
-        self._enc_fp8 = encoder_gemm_dtype == "fp8"
+        sub = encoder_gemm_dtype[4:] if isinstance(encoder_gemm_dtype, str) and encoder_gemm_dtype.startswith("fp8:") else None
+        if sub is not None and (not sub or any(t not in ("qkv", "fc1", "fc2", "cross_kv") for t in sub.split("+"))):
+            raise ValueError(f"encoder_gemm_dtype {encoder_gemm_dtype!r}: the subset after 'fp8:' is qkv / fc1 / fc2 / cross_kv joined by '+'")
+        if sub is None and encoder_gemm_dtype not in (None, "bf16", "f16", "f32", "fp8"):
+            raise ValueError(f"encoder_gemm_dtype must be None, 'fp8' or 'fp8:<subset>', got {encoder_gemm_dtype!r}")
+        self._enc_fp8 = sub if sub is not None else (encoder_gemm_dtype == "fp8")
 
     # ------------------------------------------------------------------
     def _chk(self, rc: int):
@@ -135,12 +140,17 @@ class Engine:
             self.load_tensor(k, v)
         self.check_weights()
         if getattr(self, "_enc_fp8", False):
-            self.set_encoder_gemm_fp8(True)
+            self.set_encoder_gemm_fp8(self._enc_fp8)
 
     def set_encoder_gemm_fp8(self, on):
         """(Re)build the e4m3 copies of the resident encoder / cross-K/V weights and switch the encoder GEMMs to them, or back.
-        ``on``: True = every GEMM; an int > 1 = mask (1 q/k/v, 2 fc1, 4 fc2, 8 cross-K/V projection) for sensitivity sweeps."""
-        self._chk(self.lib.cw_set_option(self.ctx, b"encoder_gemm_fp8", int(on) if not isinstance(on, bool) else (1 if on else 0)))
+        ``on``: True = every GEMM; a str of names out of "qkv", "fc1", "fc2", "cross_kv" joined by "+" (or an int mask: 1 q/k/v, 2 fc1,
+        4 fc2, 8 cross-K/V projection) = that subset.  "fc1+fc2" is the subset that reproduces every reference clip of the batch-64
+        workload (profiles/r04_fp8_sweep.txt)."""
+        if isinstance(on, str):
+            on = sum({"qkv": 1, "fc1": 2, "fc2": 4, "cross_kv": 8}[t] for t in on.split("+") if t)
+        value = (1 if on else 0) if isinstance(on, bool) else (16 + int(on) if int(on) > 0 else 0)
+        self._chk(self.lib.cw_set_option(self.ctx, b"encoder_gemm_fp8", value))
 
     def check_weights(self):
         self._chk(self.lib.cw_check_weights(self.ctx))

@@ -36,7 +36,7 @@ def main():
     clips = [syn.synth_audio(i, 480000, "noise") for i in range(B)]
     W = {n: syn.weight_tensor(g, n, s, 0, "aligned") for n, s in syn.weight_shapes(g).items()}
     names = {1: "q/k/v", 2: "fc1", 4: "fc2", 8: "cross-K/V proj"}
-    configs = [(0, None)] + [(m, None) for m in (1, 2, 4, 8, 3, 7, 9, 11, 13, 15)] + [(0, "fp8"), (8, "fp8"), (15, "fp8")]
+    configs = [(0, None)] + [(m, None) for m in (1, 2, 4, 8, 6, 3, 5, 7, 14, 15)] + [(0, "fp8"), (2, "fp8"), (6, "fp8"), (14, "fp8"), (15, "fp8")]
     rows = []
     for mask, kv in configs:
         eng = Engine(spec, dtype="bf16", max_batch=B, cross_kv_dtype=kv)
@@ -44,7 +44,7 @@ def main():
             eng.load_state_dict(W)
             if mask:
                 eng.check_weights()
-                eng.set_encoder_gemm_fp8(mask if mask != 1 else True)
+                eng.set_encoder_gemm_fp8(int(mask))
             nf = eng.upload_pcm(clips)
 
             def one():
