@@ -1031,6 +1031,47 @@ def test_longform_600s_at_bench_geometry_vs_transformers(dtype):
     finally:
         pipe.engine.close()
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_thresholds_at_bench_geometry_through_the_native_seek_loop(dtype):
+    """logprob_threshold / no_speech_threshold at the BENCH geometry (large-v3 shapes, aligned weights) through the public
+    pipeline call, i.e. cw_transcribe's own skip logic and the samplers' log-probability tracking at full size, in the parity
+    engine and in both 16-bit engines: golden = the reference pipeline call through transformers with thresholds placed between
+    the probed values so that one window is skipped (tests/golden/gen_golden_thresholds_bench.py: 100 s recording, 5 chunks, 10
+    passes).  Identical text, words within 20 ms, fewer words than without thresholds; the two compared quantities of the first
+    window agree with what transformers compared."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "e2e_thresholds_bench_golden.json")
+    if not os.path.exists(path):
+        pytest.skip("bench-geometry thresholds golden not generated")
+    gold = Hh.gold_json("e2e_thresholds_bench_golden.json")
+    from tests.golden.gen_golden_thresholds import audio
+    x = audio()[: gold["seconds"] * 16000]
+    g, v = syn.large_v3_geometry()
+    spec = syn.model_spec(g, v, n_align=15)
+    pipe = cw.pipeline("automatic-speech-recognition", model=cw.ModelBundle(spec, dict(_aligned_weights(g, gold["weight_seed"]).items())),
+                       tokenizer=collate.Vocabulary.from_synthetic(v), chunk_length_s=30, batch_size=gold["batch_size"], return_timestamps="word",
+                       torch_dtype={"bf16": "bfloat16", "f16": "float16", "f32": "float32"}[dtype], device="cuda:0", num_beams=1)
+    try:
+        gk = gold["generate_kwargs"]
+        eng = pipe.engine
+        _, nf = eng.mel([x[:480000]])
+        eng.encode([0], [0], [3000])
+        eng.set_thresholds(gk["logprob_threshold"], gk["no_speech_threshold"])
+        nsp = eng.no_speech_probs(1, v.sot)
+        eng.decode(np.array([[v.sot, v.lang_id("en"), v.transcribe]], np.int32), max_length=3 + gk["max_new_tokens"])
+        alp = eng.avg_logprobs(1)
+        want = gold["passes"][0][0]
+        print(f"thresholds {dtype}: first window avg_logprob {float(alp[0]):.4f} (reference {want['avg_logprob']:.4f}), "
+              f"no_speech_prob {float(nsp[0]):.3e} (reference {want['no_speech_prob']:.3e})")
+        assert abs(float(alp[0]) - want["avg_logprob"]) <= (2e-3 if dtype == "f32" else 3e-2), (alp, want)
+        out = pipe(x, generate_kwargs=dict(gk))
+        assert out["text"] == gold["text"]
+        ok, why = Hh.words_equal(out["chunks"], gold["chunks"], tol=0.02)
+        assert ok, why
+        assert len(out["chunks"]) < gold["n_words_without_thresholds"]
+    finally:
+        pipe.engine.close()
+
 
 @pytest.mark.parametrize("case", ["greedy"])
 def test_logprob_and_no_speech_thresholds_vs_transformers(tiny, case):
