@@ -421,3 +421,21 @@ def test_generate_kwargs_are_honoured_or_refused():
                 {"no_speech_threshold": 0.6, "temperature": 0.0}, {"logprob_threshold": -1.0}, {"return_timestamps": False}):
         with pytest.raises(ValueError):
             chk(dict(bad))
+
+
+def test_pipeline_default_num_beams_wins_over_the_checkpoints_generation_config():
+    """What `pipeline(...)(x)` without generate_kwargs decodes with (REF/transcribe.py:33): under the installed transformers the
+    ASR pipeline's own default generation config (num_beams = 5, TF/pipelines/automatic_speech_recognition.py:160-163) is what
+    `pipe.generation_config` ends up with -- also when the checkpoint's generation_config says num_beams = 1 or 3 (probed here on
+    a tiny model; TF/pipelines/base.py:887-908 resolves through model._prepare_generation_config).  The drop-in's default
+    (pipeline.DEFAULT_NUM_BEAMS) is therefore a constant, not read from the checkpoint."""
+    transformers = pytest.importorskip("transformers")
+    from crisperwhisper_amd import pipeline as P, synthetic as syn
+    from tests.golden import hf_synth as H
+    g, v = syn.tiny_geometry()
+    for nb in (None, 1, 3):
+        model = H.build_model(g, v, n_align=4)
+        if nb is not None:
+            model.generation_config.num_beams = nb
+        pipe = H.build_pipeline(model, H.build_tokenizer(v), H.build_feature_extractor(g), batch_size=1)
+        assert pipe.generation_config.num_beams == P.DEFAULT_NUM_BEAMS == 5, (nb, pipe.generation_config.num_beams)
