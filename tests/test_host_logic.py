@@ -430,7 +430,9 @@ def test_pipeline_default_num_beams_wins_over_the_checkpoints_generation_config(
     a tiny model; TF/pipelines/base.py:887-908 resolves through model._prepare_generation_config).  The drop-in's default
     (pipeline.DEFAULT_NUM_BEAMS) is therefore a constant, not read from the checkpoint."""
     transformers = pytest.importorskip("transformers")
-    from crisperwhisper_amd import pipeline as P, synthetic as syn
+    import importlib
+    from crisperwhisper_amd import synthetic as syn
+    P = importlib.import_module("crisperwhisper_amd.pipeline")
     from tests.golden import hf_synth as H
     g, v = syn.tiny_geometry()
     for nb in (None, 1, 3):
