@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--cpu-tokens", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the reference leg; 0 = calibrated per stage on "
                     "the host (oracle/hf_reference.py:calibrate_threads: GEMM-shaped encoder vs M=1 decoder steps)")
-    ap.add_argument("--cpu-timeout", type=int, default=240, help="hard limit (s) of the reference leg")
+    ap.add_argument("--cpu-timeout", type=int, default=360, help="hard limit (s) of the reference leg (two samples of the clip)")
     ap.add_argument("--cpu-port", action="store_true", help="also time the numpy/C oracle (kind=port) beside the reference")
     ap.add_argument("--kernel-iters", type=int, default=200)
     ap.add_argument("--cross-kv", default="bf16", choices=["bf16", "fp8"],
@@ -120,7 +120,8 @@ def cpu_reference(geometry, n_tok, threads, timeout_s, style="aligned"):
     clip of the bench workload (clip 0) with the bench's token count and the same seeded weights as the GPU engine.
     Runs as a subprocess (oracle/hf_reference.py) under a hard timeout so that a slow host cannot lose the GPU line."""
     import subprocess
-    cmd = [sys.executable, "-m", "oracle.hf_reference", "--geometry", geometry, "--tokens", str(n_tok), "--threads", str(threads), "--style", style]
+    cmd = [sys.executable, "-m", "oracle.hf_reference", "--geometry", geometry, "--tokens", str(n_tok), "--threads", str(threads), "--style", style,
+           "--repeats", "2"]
     try:
         p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired:
@@ -134,6 +135,8 @@ def cpu_reference(geometry, n_tok, threads, timeout_s, style="aligned"):
     st = r["stage_s"]
     return {"value": r["words"] / r["wall_s"], "unit": "aligned words/s", "cores": r["threads"], "host_cpus": r["host_cpus"],
             "cpu_model": r["cpu_model"], "kind": "reference", "rtf": r["wall_s"] / r["audio_s"],
+            # every sample of the same clip (value = the fastest): host timings of this leg moved by 20 % between rounds
+            "samples_aligned_words_per_s": [r["words"] / w for w in r.get("wall_s_samples", [r["wall_s"]])],
             # seconds per probe for every torch thread count tried on this host ("gemm" = encoder-shaped, "gemv" = one decoder
             # forward's op chain); the reference leg runs each stage at its fastest count, not at os.cpu_count()
             "thread_calibration": r.get("thread_calibration") or None,

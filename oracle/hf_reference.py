@@ -113,7 +113,7 @@ def calibrate_threads(d_model: int, ffn: int, candidates=(2, 4, 8, 16, 32, 64, 1
 
 
 def time_reference_pipeline(geom, vocab, tensors, audio: np.ndarray, n_tok: int, n_align: int = 15,
-                            threads: int | None = None) -> Dict:
+                            threads: int | None = None, repeats: int = 1) -> Dict:
     """One clip through the reference call (REF/transcribe.py:21-33: chunk_length_s=30, return_timestamps="word";
     batch_size=1 because the eager word-timestamp path retains 5.76 GB of encoder attention maps per clip) +
     adjust_pauses_for_hf_pipeline_output, timed end to end on the host cores.  Greedy (``num_beams=1``: the 2024 reference
@@ -159,11 +159,23 @@ def time_reference_pipeline(geom, vocab, tensors, audio: np.ndarray, n_tok: int,
     spy(model.model.decoder, "forward", "decoder", t_dec)
     spy(model, "_extract_token_timestamps", "token_timestamps")
     gk = {"num_beams": 1, "language": "<|en|>", "task": "transcribe", "max_new_tokens": n_tok, "min_new_tokens": n_tok}
-    t0 = time.perf_counter()
-    res = pipe(audio.copy(), generate_kwargs=gk)
-    res = OP.adjust_pauses_for_hf_pipeline_output(res)
-    wall = time.perf_counter() - t0
-    return {"wall_s": wall, "words": len(res["chunks"]), "audio_s": len(audio) / 16000.0, "threads": max(t_enc, t_dec),
+    # the same clip `repeats` times (host timings of one sample moved by 20 % between rounds on the same host class): every wall
+    # time is reported, the stage split is that of the fastest sample; a second sample is skipped when the first was slow
+    walls, best = [], None
+    for rep in range(max(1, int(repeats))):
+        if rep > 0 and walls[0] > 100.0:
+            break
+        for k in stage:
+            stage[k] = 0.0
+            calls[k] = 0
+        t0 = time.perf_counter()
+        res = pipe(audio.copy(), generate_kwargs=gk)
+        res = OP.adjust_pauses_for_hf_pipeline_output(res)
+        walls.append(time.perf_counter() - t0)
+        if best is None or walls[-1] < best[0]:
+            best = (walls[-1], dict(stage), dict(calls))
+    wall, stage, calls = best
+    return {"wall_s": wall, "wall_s_samples": [round(w, 3) for w in walls], "words": len(res["chunks"]), "audio_s": len(audio) / 16000.0, "threads": max(t_enc, t_dec),
             "threads_encoder": t_enc, "threads_decoder": t_dec, "thread_calibration": calib,
             "build_s": t_build, "stage_s": {k: round(v, 3) for k, v in stage.items()}, "stage_calls": calls,
             "text": res["text"], "chunks": res["chunks"]}
@@ -180,13 +192,14 @@ def main():
     ap.add_argument("--tokens", type=int, default=128)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--style", default="aligned", choices=["iid", "aligned"])
+    ap.add_argument("--repeats", type=int, default=1)
     a = ap.parse_args()
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from crisperwhisper_amd import synthetic as syn
     g, v = syn.large_v3_geometry() if a.geometry == "large-v3" else syn.tiny_geometry()
     tensors = ((n, syn.weight_tensor(g, n, shape, 0, a.style)) for n, shape in syn.weight_shapes(g).items())
     x = syn.synth_audio(0, 480000, "noise")
-    r = time_reference_pipeline(g, v, tensors, x, a.tokens, n_align=15 if a.geometry == "large-v3" else 3, threads=a.threads or None)
+    r = time_reference_pipeline(g, v, tensors, x, a.tokens, n_align=15 if a.geometry == "large-v3" else 3, threads=a.threads or None, repeats=a.repeats)
     r.pop("chunks"); r.pop("text")
     r["cpu_model"] = cpu_model_name()
     r["host_cpus"] = os.cpu_count()
