@@ -27,12 +27,12 @@
 #include "kernels.h"
 #include <stdlib.h>
 #include <mutex>
+#include "gemm_tiles.h"
 
 namespace CW_NS {
 
 #define BM 128
 #define BN 128
-#define BK 64
 #define LDS_STRIDE 72  // bf16 per LDS row: 64 + 8 pad (144 B) keeps ds_read_b128 fragment reads spread
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -51,29 +51,6 @@ __device__ inline const TA* a_row_ptr(const AParams& ap, int m, int M, int k0) {
     return (const TA*)ap.A + ((size_t)(ap.row_off[b] + t_in)) * ap.C_in + c0;
 }
 
-// Grouped tile order (logical id -> (m-tile, n-tile)): ids walk down GM m-tiles of one n-tile before moving to
-// the next n-tile, so the ~32 blocks resident on an XCD share 8 A panels x 4 W panels (< 4 MB L2) instead of
-// streaming the whole weight matrix once per m-tile row (measured 24x over-fetch on fc1 with row-major order).
-__device__ inline void grouped_tile(int tile, int tiles_m, int tiles_n, int& mt, int& nt) {
-    const int GM = 8;
-    const int width = GM * tiles_n;
-    const int group = tile / width;
-    const int first_m = group * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int in_g = tile - group * width;
-    mt = first_m + in_g % gsz;
-    nt = in_g / gsz;
-}
-
-// XCD-aware, bijective block remap (8 XCDs, block b is dispatched to XCD b % 8): consecutive logical
-// tiles, which share an A row-panel, land on the same XCD's L2.
-__device__ inline int xcd_remap(int bid, int nwg) {
-    const int nx = 8;
-    int xcd = bid % nx, slot = bid / nx;
-    int q = nwg / nx, r = nwg % nx;
-    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + slot;
-}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(AParams ap, const bf16_t* __restrict__ W, int M, int N,
@@ -312,8 +289,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(AParams ap, const b
 // L2/HBM re-fetch of the operand panels.  Same source-side XOR swizzle, staging map, raster and epilogues.
 // LDS: 2 stages x (A 32 KB | W 32 KB) = 128 KB dynamic.
 // ---------------------------------------------------------------------------------------------------
-#define BM2 256
-#define BN2 256
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(AParams ap, const bf16_t* __restrict__ W, int M, int N,
                                                             int K, EpiParams ep, int tiles_n,
@@ -1618,6 +1593,8 @@ void cw_gemm_set_256_min_tiles(int n) { g_256_min_tiles = n; }
 static int g_use_8ph = -1;  // quarter-tile (8-phase) schedule instead of ping-pong; -1: from the environment (CW_NO_GEMM_8PH)
 void cw_gemm_set_pp(int on) { g_use_pp = on; }
 void cw_gemm_set_8ph(int on) { g_use_8ph = on; }
+static int g_use_w128 = -1;  // four waves of 128 x 128 (round 4, measured slower: -DCW_EXPERIMENTS builds only); -1: from the environment (CW_GEMM_W128=1)
+void cw_gemm_set_w128(int on) { g_use_w128 = on; }
 
 template <int EPI>
 static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, int N, int K, const EpiParams& ep,
@@ -1636,7 +1613,14 @@ static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, 
         if (g_use_pp < 0) g_use_pp = getenv("CW_NO_GEMM_PP") == nullptr;
         const bool use_pp = g_use_pp != 0;
         if (g_use_8ph < 0) g_use_8ph = getenv("CW_NO_GEMM_8PH") == nullptr;
-        if (g_use_glds && g_zero_page && g_use_256 && use_pp && g_use_8ph && tm2 * tn2 >= g_256_min_tiles && ap.amode == 0 && N % BN2 == 0) {
+#ifdef CW_EXPERIMENTS
+        if (g_use_w128 < 0) g_use_w128 = getenv("CW_GEMM_W128") != nullptr;
+#else
+        g_use_w128 = 0;
+#endif
+        if (g_use_glds && g_zero_page && g_use_256 && g_use_w128 && tm2 * tn2 >= g_256_min_tiles && ap.amode == 0 && N % BN2 == 0) {
+            cw_launch_gemm_w128(EPI, (const bf16_t*)ap.A, ap.lda, (const bf16_t*)W, M, N, K, ep, tm2, tn2, st);
+        } else if (g_use_glds && g_zero_page && g_use_256 && use_pp && g_use_8ph && tm2 * tn2 >= g_256_min_tiles && ap.amode == 0 && N % BN2 == 0) {
             static std::once_flag attr_8;
             std::call_once(attr_8, [] {
                 hipFuncSetAttribute((const void*)gemm_bf16_8ph_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);

@@ -117,14 +117,17 @@ def test_gemm_fp8_exact_on_representable_inputs_and_quantisation_model_otherwise
     assert rel_err(got, exact) < 0.12                                                   # what e4m3 operands cost on N(0, 1) data
 
 
-@pytest.mark.parametrize("sched", ["pingpong", "8phase"])
+@pytest.mark.parametrize("sched", ["pingpong", "8phase", "w128"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 256, 128), (513, 768, 192), (2000, 512, 5120), (3333, 1280, 1280), (1500, 3840, 1280),
                                    (777, 512, 256), (12000, 1280, 320)])
 def test_gemm_pingpong_schedule_is_bit_identical_to_lockstep(engines, M, N, K, sched):
     """The staggered 256-tile GEMM schedules -- ping-pong (two wave groups half a K-tile apart, LDS-DMA two tiles ahead) and
     the quarter-tile "8-phase" one (half-tile DMA every phase, counted vmcnt, round 3) -- accumulate in exactly the order of the
     lockstep kernel: same bits, run after run (a half tile overwritten early or read late shows up here), for 1, 2, 3, 4, 5, 20
-    and 80 K-tiles, with and without an M-edge tile, also with every CU holding a block (12000 rows)."""
+    and 80 K-tiles, with and without an M-edge tile, also with every CU holding a block (12000 rows).  "w128" (round 4): four
+    waves of 128 x 128 per block, self-pipelined in half steps of 32 MFMAs (csrc/gemm_w128.hip)."""
+    if sched == "w128" and not Hh.has_experiments():
+        pytest.skip("csrc/gemm_w128.hip is an A/B build (measured slower): library built without -DCW_EXPERIMENTS")
     eng = engines["bf16"]
     rng = np.random.default_rng(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
@@ -133,12 +136,14 @@ def test_gemm_pingpong_schedule_is_bit_identical_to_lockstep(engines, M, N, K, s
     A = (A.view(np.uint32) & 0xFFFF0000).view(np.float32); W = (W.view(np.uint32) & 0xFFFF0000).view(np.float32)
     assert eng.lib.cw_test_set_option(b"gemm256_min_tiles", 1) == 0
     try:
+        assert eng.lib.cw_test_set_option(b"gemm_w128", 0) == 0
         assert eng.lib.cw_test_set_option(b"gemm_pp", 0) == 0
         want = eng.test_gemm(A, W, b, True)
         ref = OMOD.gelu((A.astype(np.float64) @ W.astype(np.float64).T + b).astype(np.float32))
         assert rel_err(want, ref) < 2e-2
         assert eng.lib.cw_test_set_option(b"gemm_pp", 1) == 0
         assert eng.lib.cw_test_set_option(b"gemm_8ph", 1 if sched == "8phase" else 0) == 0
+        assert eng.lib.cw_test_set_option(b"gemm_w128", 1 if sched == "w128" else 0) == 0
         for rep in range(6):
             got = eng.test_gemm(A, W, b, True)
             assert np.array_equal(got, want), (M, N, K, rep, int((got != want).sum()))
@@ -146,6 +151,7 @@ def test_gemm_pingpong_schedule_is_bit_identical_to_lockstep(engines, M, N, K, s
         eng.lib.cw_test_set_option(b"gemm256_min_tiles", 200)
         eng.lib.cw_test_set_option(b"gemm_pp", 1)
         eng.lib.cw_test_set_option(b"gemm_8ph", 1)
+        eng.lib.cw_test_set_option(b"gemm_w128", 0)
 
 
 @pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
