@@ -947,6 +947,46 @@ def test_batch64_free_running_every_clip_vs_transformers(dtype):
     finally:
         eng.close()
 
+@pytest.mark.parametrize("B", [16, 17, 33, 48])
+def test_odd_batch_sizes_free_running_vs_transformers(B):
+    """The decoder's row-count regimes at the bench geometry, free-running bf16 against each clip's transformers reference: 16 rows
+    (the reference's own batch_size, REF/transcribe.py:27: last size of the <= 16-row latency path), 17 and 33 (first rows of the
+    second and third MFMA row tile of the 17..64-row path: 15 and 31 padded rows), 48 (three full tiles).  Rows are independent, so
+    every clip must come out as it does at batch 8 / 64: identical text, words within 20 ms."""
+    import os
+    gold = {}
+    for name in ("e2e_bench_golden.json", "e2e_bench_b64_golden.json"):
+        path = os.path.join(os.path.dirname(__file__), "golden", name)
+        if not os.path.exists(path):
+            pytest.skip(f"{name} not generated")
+        gj = Hh.gold_json(name)
+        for c in gj["clips"]:
+            gold.setdefault(int(c["seed"]), c)
+        gk = gj["generate_kwargs"]
+    g, v = syn.large_v3_geometry()
+    spec = syn.model_spec(g, v, n_align=15)
+    vocab = collate.Vocabulary.from_synthetic(v)
+    eng = Engine(spec, dtype="bf16", max_batch=B)
+    try:
+        for n, shape in syn.weight_shapes(g).items():
+            eng.load_tensor(n, syn.weight_tensor(g, n, shape, 0, "aligned"))
+        _, nf = eng.mel([syn.synth_audio(i, 480000, "noise") for i in range(B)])
+        out = generation.generate(eng, B, nf, language=gk["language"], task=gk["task"], max_new_tokens=gk["max_new_tokens"],
+                                  min_new_tokens=gk["min_new_tokens"], num_beams=1)
+        same = ok = tot = 0
+        for k in range(B):
+            n = len(out["token_timestamps"][k])
+            text, words = collate.decode_asr(vocab, [{"tokens": out["sequences"][k][:n], "token_timestamps": out["token_timestamps"][k],
+                                                      "stride": (30.0, 0.0, 0.0)}])
+            if text == gold[k]["text"] and len(words) == len(gold[k]["chunks"]):
+                same += 1
+                a, b = _words_close(words, gold[k]["chunks"])
+                ok += a; tot += b
+        print(f"batch {B} bf16: {same}/{B} clips identical text, {ok}/{tot} words within 0.02 s")
+        assert same == B and ok >= 0.99 * tot and tot > 0, (same, ok, tot)
+    finally:
+        eng.close()
+
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_bench_geometry_second_weight_seed_other_audio(dtype):
