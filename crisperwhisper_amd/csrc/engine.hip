@@ -80,6 +80,7 @@ struct cw_ctx {
                                     //   fc1 through planes + finish launch.  Both measured slower in the step (profiles/r04_b64_*_rejected_*): A/B only
     float* d_planes = nullptr;      // [S][rows][N] K-split partial products of the LayerNorm projections (skinny.hip)
     size_t planes_cap = 0;          // floats
+    float* d_sk_stats = nullptr;    // [16][64][2] slice statistics of the rows (skinny.hip)
     float* d_rstats = nullptr;      // [max(D, F) / 16][64][2] per-block LayerNorm partial sums of the 17..64-row producers
     bool fuse6_enabled = true;      // CW_NO_FUSE6=1: eight launches per layer (A/B)
     bool fuse_mlp = false;          // CW_FUSE_MLP=1: also fuse cross out-projection + fc1 (six launches; measured slower, A/B)
@@ -504,6 +505,7 @@ static int create_impl(cw_ctx* c) {
     if (Bm > 16) {   // four K slices of the widest LayerNorm projection for 64 rows (5.2 MB at large-v3)
         c->planes_cap = (size_t)4 * 64 * (3 * D > F ? 3 * D : F);
         CWCHK(c, dmalloc(c, &c->d_planes, c->planes_cap * 4, false));
+        CWCHK(c, dmalloc(c, &c->d_sk_stats, (size_t)16 * 64 * 2 * 4));
     }
     CWCHK(c, dmalloc(c, &c->d_xfrag2, (size_t)64 * 5120 * 2));
     c->Vpad = (V + 3) & ~3;
@@ -1065,13 +1067,17 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         SkinnyParams sp;
         memset(&sp, 0, sizeof(sp));
         sp.x = c->dx; sp.W = W; sp.Mb = nb; sp.K = D; sp.N = N; sp.planes = c->d_planes;
-        const int nks = KD(c, cw_skinny_pick_nks, N, D, (int)(c->planes_cap / ((size_t)nb * N)));
+        int smax = (int)(c->planes_cap / ((size_t)nb * N));
+        if (smax > 16) smax = 16;
+        const int nks = KD(c, cw_skinny_pick_nks, N, D, smax);
         if (nks < 1) return CW_ERR_INVALID;
+        sp.stats = c->d_sk_stats;
         int r = KD(c, cw_launch_skinny, 0, sp, nks, c->st);
         if (r != CW_OK) return r;
         SkinnyFinishParams fp;
         memset(&fp, 0, sizeof(fp));
         fp.planes = c->d_planes; fp.S = (D / 32) / nks; fp.Mb = nb; fp.N = N; fp.x = c->dx; fp.K = D; fp.wsum = wsum; fp.ep = ep;
+        fp.stats = c->d_sk_stats;
         return KD(c, cw_launch_skinny_finish, epi, fp, c->st);
     };
     const bool rows = !skinny && frag && c->rows_ln_ready && c->rows_ln_enabled && c->ln_folded && D <= 1280;
@@ -2179,6 +2185,8 @@ int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K
     return fail(c, CW_ERR_INVALID, "cw_test_skinny: csrc/skinny.hip is an A/B build (make EXTRA=-DCW_EXPERIMENTS)");
 #endif
     if (!c->bf16) return fail(c, CW_ERR_INVALID, "cw_test_skinny: 16-bit engines only");
+    const bool slice_stats = (mode & 4) != 0;   // LayerNorm statistics from the GEMM's slice records instead of re-reading x
+    mode &= 3;
     if (Mb < 1 || Mb > 64 || K % 32 || N % 16 || mode < 0 || mode > 2 || (mode == 1 && N % 32)) return fail(c, CW_ERR_INVALID, "cw_test_skinny: bad shape");
     const int MT = (Mb + 15) / 16;
     if (nks <= 0) nks = KD(c, cw_skinny_pick_nks, N, K, mode == 2 ? 0 : 16);
@@ -2187,7 +2195,8 @@ int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K
     const size_t wbytes = (size_t)N * K * 2;
     int ncopy = 1;
     if (reps > 0) { ncopy = (int)((size_t)320 * 1024 * 1024 / wbytes) + 1; if (ncopy > 64) ncopy = 64; }
-    float *dx = nullptr, *dB = nullptr, *dO = nullptr, *dws = nullptr, *dP = nullptr; void *dW = nullptr, *dWp = nullptr, *dxf = nullptr, *dfr = nullptr;
+    float *dx = nullptr, *dB = nullptr, *dO = nullptr, *dws = nullptr, *dP = nullptr, *dst = nullptr; void *dW = nullptr, *dWp = nullptr, *dxf = nullptr, *dfr = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dst, (size_t)64 * 64 * 2 * 4));
     HIPCHK(c, hipMalloc((void**)&dx, (size_t)Mb * K * 4)); HIPCHK(c, hipMalloc(&dW, wbytes)); HIPCHK(c, hipMalloc(&dWp, wbytes * ncopy));
     HIPCHK(c, hipMalloc((void**)&dO, (size_t)Mb * N * 4)); HIPCHK(c, hipMalloc((void**)&dB, (size_t)N * 4)); HIPCHK(c, hipMalloc((void**)&dws, (size_t)N * 4));
     HIPCHK(c, hipMalloc((void**)&dP, (size_t)S * Mb * N * 4)); HIPCHK(c, hipMalloc(&dxf, (size_t)MT * 16 * K * 2)); HIPCHK(c, hipMalloc(&dfr, (size_t)MT * 16 * N * 2));
@@ -2214,6 +2223,10 @@ int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K
     memset(&fp, 0, sizeof(fp));
     fp.planes = dP; fp.S = S; fp.Mb = Mb; fp.N = N; fp.x = dx; fp.K = K; fp.wsum = dws; fp.ep = epi0();
     fp.ep.bias = dB; fp.ep.outf = dO; fp.ep.out = dfr; fp.ep.ldo = N;
+    if (slice_stats && mode != 2) {
+        if (S > 16) { hipFree(dst); return fail(c, CW_ERR_INVALID, "cw_test_skinny: slice statistics need S <= 16"); }
+        sp.stats = dst; fp.stats = dst;
+    }
     const int epi = mode == 1 ? EPI_GELU_FRAG : EPI_STORE_F32;
     int r = KD(c, cw_launch_skinny, mode == 2 ? 1 : 0, sp, nks, c->st);
     if (r == CW_OK && mode != 2) r = KD(c, cw_launch_skinny_finish, epi, fp, c->st);
@@ -2265,7 +2278,7 @@ int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K
         }
         if (r != CW_OK) fail(c, r, "cw_test_skinny: timing graph failed");
     }
-    hipFree(dx); hipFree(dW); hipFree(dWp); hipFree(dO); hipFree(dB); hipFree(dws); hipFree(dP); hipFree(dxf); hipFree(dfr);
+    hipFree(dx); hipFree(dW); hipFree(dWp); hipFree(dO); hipFree(dB); hipFree(dws); hipFree(dP); hipFree(dxf); hipFree(dfr); hipFree(dst);
     return r;
 }
 

@@ -202,6 +202,7 @@ struct SkinnyParams {
     int Mb, K, N;
     int Kb;                // filled in by the launcher: K columns per block
     float* planes;         // mode 0: [S][Mb][N] f32 partial products, S = K / Kb
+    float* stats;          // mode 0, optional: [S][Mb][2] slice statistics of the rows (mean, sum of squares about it) for the consumer's LayerNorm
     float* outf;           // mode 1: [Mb][ldo] f32, accumulated in place
     const float* bias;     // mode 1: [N] or null (added by slice 0)
     int ldo;
@@ -211,6 +212,7 @@ struct SkinnyFinishParams {
     const float* planes;   // [S][Mb][N]
     int S, Mb, N;
     const float* x;        // [Mb][K] rows whose LayerNorm statistics apply (null: none)
+    const float* stats;    // non-null: [S][Mb][2] slice statistics left by the GEMM -- used instead of re-reading x (K = row length)
     int K;
     const float* wsum;     // [N] row sums of the folded 16-bit weights (W' 1); null with x == null
     EpiParams ep;          // destination + folded bias; EPI_STORE_F32 / EPI_QKV_CACHE / EPI_GELU_FRAG

@@ -110,6 +110,20 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyParams p) {
             sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);   // the row's 8 lanes
             c[h] = live[h] ? sum / (float)p.Kb : 0.f;
             if (oct == 0) cs[wave * 16 + h * 8 + r8] = c[h];
+            // slice statistics of the row for the consumer's LayerNorm (combined over the S slices in fixed order): mean and
+            // the sum of squares ABOUT that mean -- no E[x^2] - mean^2 cancellation.  One column tile writes them.
+            if (p.stats && blockIdx.x == 0) {
+                float m2 = 0.f;
+#pragma unroll
+                for (int s = 0; s < NKS; ++s)
+                    if (s < nks) {
+                        const float4 q = v[2 * s + h];
+                        const float a0 = q.x - c[h], a1 = q.y - c[h], a2 = q.z - c[h], a3 = q.w - c[h];
+                        m2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                    }
+                m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
+                if (oct == 0 && live[h]) *(float2*)(p.stats + ((size_t)blockIdx.y * p.Mb + wave * 16 + h * 8 + r8) * 2) = make_float2(c[h], m2);
+            }
         }
         // element (row16, k) of a fragment sits at lane' = (k / 8) * 16 + row16, slot k % 8: 8 bytes per lane
         unsigned char* dst0 = sk_smem + (size_t)wave * nks * 1024 + ((oct >> 1) * 16 + r8) * 16 + (oct & 1) * 8;
@@ -223,7 +237,20 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(SkinnyFinishParams p
         if (p.ep.bias) bs = *(const float4*)(p.ep.bias + n);
     }
     float mean = 0.f, rstd = 1.f;
-    if (p.x) {
+    if (p.stats) {
+        // LayerNorm statistics of the row from the S slice records the GEMM left (mean_s, M2_s over Kb values each):
+        // mean = avg mean_s,  M2 = sum M2_s + Kb sum (mean_s - mean)^2   -- every thread the same S small loads, no reduction
+        float ms[16], m2 = 0.f;
+        const int S = p.S < 16 ? p.S : 16;
+        for (int s = 0; s < S; ++s) {
+            const float2 r = *(const float2*)(p.stats + ((size_t)s * p.Mb + m) * 2);
+            ms[s] = r.x; mean += r.x; m2 += r.y;
+        }
+        mean /= (float)S;
+        const float kb = (float)p.K / (float)S;
+        for (int s = 0; s < S; ++s) m2 += kb * (ms[s] - mean) * (ms[s] - mean);
+        rstd = 1.0f / sqrtf(m2 / (float)p.K + 1e-5f);
+    } else if (p.x) {
         const int nvec = p.K >> 2;
         float4 v[5];
 #pragma unroll
@@ -328,7 +355,7 @@ int cw_launch_skinny(int mode, const SkinnyParams& p0, int nks, hipStream_t st) 
 }
 
 int cw_launch_skinny_finish(int epi, const SkinnyFinishParams& p, hipStream_t st) {
-    if (p.Mb < 1 || p.N % 4 || p.S < 1 || !p.planes || (p.x && (p.K % 4 || p.K > 5120))) return CW_ERR_INVALID;
+    if (p.Mb < 1 || p.N % 4 || p.S < 1 || !p.planes || (p.x && (p.K % 4 || p.K > 5120)) || (p.stats && p.S > 16)) return CW_ERR_INVALID;
     const dim3 grid(p.Mb, (p.N + 1023) / 1024);
     switch (epi) {
         case EPI_STORE_F32: hipLaunchKernelGGL((skinny_finish_kernel<EPI_STORE_F32>), grid, dim3(256), 0, st, p); break;

@@ -199,6 +199,10 @@ def test_skinny_projections_17_to_64_rows(engines, dt, tol, Mb, N, K, nks):
     ref = _ln_plain(x) @ W.astype(np.float64).T + b
     got, _ = eng.test_skinny(0, x, W, b, nks=nks)
     assert rel_err(got, ref) < tol, (dt, Mb, N, K, "ln", rel_err(got, ref))
+    S_ = (K // 32) // (nks if nks else 1)
+    if nks and S_ <= 16:                                   # LayerNorm statistics combined from the GEMM's K-slice records
+        got, _ = eng.test_skinny(4, x, W, b, nks=nks)
+        assert rel_err(got, ref) < tol, (dt, Mb, N, K, "ln, slice statistics", rel_err(got, ref))
     if N % 32 == 0:                                         # the GELU epilogue writes MFMA fragments of the next projection (K' = N)
         got, _ = eng.test_skinny(1, x, W, b, nks=nks)
         refg = OMOD.gelu(ref.astype(np.float32)).astype(np.float64)
