@@ -20,6 +20,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace CW_NS {
 
@@ -1367,7 +1368,14 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
         }
 #endif
         if (!p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.B > 16) return CW_ERR_INVALID;
-        hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, 1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+        // A/B (CW_CROSS_LDS_PAD=bytes): unused dynamic LDS that limits how many blocks share a CU (the 960 blocks of a B = 8 launch
+        // are all resident at once: their tails -- softmax, V pass, reductions -- then run together after the last byte landed)
+        static const int lds_pad = getenv("CW_CROSS_LDS_PAD") ? atoi(getenv("CW_CROSS_LDS_PAD")) : 0;
+        if (lds_pad > 0) {
+            static std::once_flag attr;
+            std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)attn_cross_split_kernel<bf16_t, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+        }
+        hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, 1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), (size_t)lds_pad, st, p);
         return CW_OK;
     }
     static const bool per_row = getenv("CW_CROSS_PER_ROW") != nullptr;   // A/B: one block per row even under beam search
