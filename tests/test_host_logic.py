@@ -421,6 +421,13 @@ def test_generate_kwargs_are_honoured_or_refused():
                 {"no_speech_threshold": 0.6, "temperature": 0.0}, {"logprob_threshold": -1.0}, {"return_timestamps": False}):
         with pytest.raises(ValueError):
             chk(dict(bad))
+    # refusals that depend on the beam width are raised up front with the width the call would actually decode with (the
+    # pipeline default when the call names none), not after the audio was loaded
+    thr = {"temperature": 0.0, "logprob_threshold": -1.0, "no_speech_threshold": 0.6}
+    with pytest.raises(ValueError, match="pipeline default"):
+        chk(dict(thr), 5)
+    chk(dict(thr, num_beams=1), 5)
+    chk(dict(thr), 1)
 
 
 def test_pipeline_default_num_beams_wins_over_the_checkpoints_generation_config():
