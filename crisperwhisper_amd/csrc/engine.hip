@@ -2073,6 +2073,7 @@ int32_t cw_test_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "beam_topk_1block")) { cw_bf16::cw_beam_topk_set_1block(value); cw_f16::cw_beam_topk_set_1block(value); return CW_OK; }
     if (!strcmp(name, "gemm_pp")) { cw_bf16::cw_gemm_set_pp(value); cw_f16::cw_gemm_set_pp(value); return CW_OK; }
     if (!strcmp(name, "gemm_8ph")) { cw_bf16::cw_gemm_set_8ph(value); cw_f16::cw_gemm_set_8ph(value); return CW_OK; }
+    if (!strcmp(name, "gemv_loop")) { cw_bf16::cw_gemv_set_loop(value); cw_f16::cw_gemv_set_loop(value); return CW_OK; }
     if (!strcmp(name, "gemm_w128")) { cw_bf16::cw_gemm_set_w128(value); cw_f16::cw_gemm_set_w128(value); return CW_OK; }
     if (!strcmp(name, "cross_valu")) { cw_bf16::cw_cross_set_valu(value); cw_f16::cw_cross_set_valu(value); return CW_OK; }
     return CW_ERR_INVALID;

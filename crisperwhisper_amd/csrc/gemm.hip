@@ -1378,6 +1378,134 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Very wide LayerNorm GEMV (the 51866-column logits projection, Mb <= 16, K <= 1280, fragment-major weights): the same
+// arithmetic as gemv2_bf16_kernel in a PERSISTENT column loop.  3242 column tiles as 1081 blocks of three are 2.1 rounds of
+// resident blocks; every block redoes the LayerNorm of the rows and every round pays its own ramp (33 us for 133 MB = 4.0 TB/s).
+// Here the grid is sized to be resident at once (<= 3 blocks per CU), a block normalises the rows ONCE, then walks the tiles
+// b, b + G, b + 2G, ... with the next tile's weights requested before the current tile's MFMAs: one continuous stream per
+// block.  Per tile: the wave's K steps on the matrix cores, cross-wave sum through one of two alternating LDS buffers (one
+// barrier per tile), store.  Per-element summation order = gemv2's (wave partials over steps w, w + 4, w + 8, then waves
+// 0..3): bit-identical logits.
+// ---------------------------------------------------------------------------------------------------
+template <int RPW, int NSLOT, int PER_LANE>
+__global__ __launch_bounds__(256) void gemv_loop_kernel(const float* __restrict__ x, int Mb, int K, const bf16_t* __restrict__ W, int N,
+                                                        const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int xs_stride = K + 8;
+    bf16_t* xs = (bf16_t*)smem3;                               // [16][K+8]
+    float* red = (float*)(smem3 + (size_t)16 * xs_stride * 2);  // [2][4 waves][4][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int steps = K >> 7, nvec = K >> 2, KS = K >> 5;
+    const int ntiles = (N + 15) >> 4;
+    const bool ln_affine = ln_b != nullptr;
+
+    // first tile's weights and the rows: every request out before the LayerNorm arithmetic
+    u32x4_t wq[NSLOT][4], wn[NSLOT][4];
+    auto load_tile = [&](int tile, u32x4_t (&w)[NSLOT][4]) {
+        const u32x4_t* base = (const u32x4_t*)W + (size_t)tile * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int step = wave + 4 * s;
+            step = step < steps ? step : steps - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[s][j] = CW_STREAM_LD(base + (size_t)(step * 4 + j) * 64);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile, wq);
+    float4 xv[RPW][PER_LANE], gv[PER_LANE], bv[PER_LANE];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        int row = wave + 4 * i;
+        row = row < Mb ? row : Mb - 1;
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) {
+            int v4 = lane + 64 * c;
+            v4 = v4 < nvec ? v4 : nvec - 1;
+            xv[i][c] = *(const float4*)(x + (size_t)row * K + v4 * 4);
+        }
+    }
+    if (ln_affine) {
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) {
+            int v4 = lane + 64 * c;
+            v4 = v4 < nvec ? v4 : nvec - 1;
+            gv[c] = *(const float4*)(ln_g + v4 * 4);
+            bv[c] = *(const float4*)(ln_b + v4 * 4);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        float sx = 0.f;
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) {
+            const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+            sx += ok * ((xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w));
+        }
+        const float mean = wave_sum(sx) / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) {
+            const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+            float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
+            q += ok * ((a * a + b * b) + (cc * cc + d * d));
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+        const int row = wave + 4 * i;
+#pragma unroll
+        for (int c = 0; c < PER_LANE; ++c) {
+            float4 v = xv[i][c];
+            if (ln_affine) {
+                v.x = (v.x - mean) * rstd * gv[c].x + bv[c].x; v.y = (v.y - mean) * rstd * gv[c].y + bv[c].y;
+                v.z = (v.z - mean) * rstd * gv[c].z + bv[c].z; v.w = (v.w - mean) * rstd * gv[c].w + bv[c].w;
+            } else {
+                v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+            }
+            int v4 = lane + 64 * c;
+            v4 = v4 < nvec ? v4 : nvec - 1;                    // clamped lanes rewrite identical data
+            ushort4 o;
+            o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+            *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
+        }
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) load_tile(nxt, wn);                   // the next tile's stream runs under this tile's MFMAs and exchange
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int step = wave + 4 * s;
+            if (step < steps) {
+                const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc = mfma16(*(const bf16x8_t*)(xr + j * 32), __builtin_bit_cast(bf16x8_t, wq[s][j]), acc);
+            }
+        }
+        float* rb = red + buf * (4 * 4 * 64);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rb[(wave * 4 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        {
+            const int r = tid >> 6;
+            const float v = rb[(0 * 4 + r) * 64 + lane] + rb[(1 * 4 + r) * 64 + lane] + rb[(2 * 4 + r) * 64 + lane] + rb[(3 * 4 + r) * 64 + lane];
+            const int m = g * 4 + r, n = tile * 16 + l15;
+            if (m < Mb && n < N) out[(size_t)m * ldo + n] = v + (bias ? bias[n] : 0.f);
+        }
+        buf ^= 1;                                               // the buffer just read is written again two tiles (= one barrier) later
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wq[s][j] = wn[s][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Decode GEMV for 17..64 batch rows: weights streamed ONCE for all rows (the row-group loop above re-streams
 // them per 16 rows).  Two launches:
 //   gemv_prep_kernel   one block per batch row: attention-partial combine / LayerNorm (both optional), round to
@@ -1593,6 +1721,8 @@ void cw_gemm_set_256_min_tiles(int n) { g_256_min_tiles = n; }
 static int g_use_8ph = -1;  // quarter-tile (8-phase) schedule instead of ping-pong; -1: from the environment (CW_NO_GEMM_8PH)
 void cw_gemm_set_pp(int on) { g_use_pp = on; }
 void cw_gemm_set_8ph(int on) { g_use_8ph = on; }
+static int g_gemv_loop = -1;  // persistent column loop for very wide LayerNorm GEMVs (logits); -1: from the environment (CW_NO_GEMV_LOOP)
+void cw_gemv_set_loop(int on) { g_gemv_loop = on; }
 static int g_use_w128 = -1;  // four waves of 128 x 128 (round 4, measured slower: -DCW_EXPERIMENTS builds only); -1: from the environment (CW_GEMM_W128=1)
 void cw_gemm_set_w128(int on) { g_use_w128 = on; }
 
@@ -1742,7 +1872,16 @@ static void launch_gemv2_shape(dim3 grid, size_t lds, int ksplit, const float* x
         // (column indices are clamped and stores masked per column, so N need not be a multiple of the block's columns.)  Very wide
         // outputs (the 51866-column logits: 3242 tiles, 12.7 per CU) take three tiles per block: every tile re-reads the 40 KB of
         // activation rows, which at one tile per block is half of all the bytes a CU takes in
-        if (ln_g && ksplit == 1 && grid.x >= 1024) {
+        if (g_gemv_loop < 0) g_gemv_loop = getenv("CW_NO_GEMV_LOOP") == nullptr;   // A/B: 0 = three tiles per block instead of the persistent column loop
+        const bool no_loop = g_gemv_loop == 0;
+        if (EPI == EPI_STORE_F32 && ln_g && ksplit == 1 && grid.x >= 1024 && wpk && Kb == K && K % 128 == 0 && K <= 1280 && !cb.part_ml && !no_loop && m_base == 0) {
+            // the logits projection: persistent column loop, grid resident at once (3 blocks per CU), tiles spread evenly
+            static const int cap = getenv("CW_GEMV_LOOP_CAP") ? atoi(getenv("CW_GEMV_LOOP_CAP")) : 512;   // blocks in the grid per round of tiles (2 per CU measured best: 24.8 us; 3 per CU 25.9)
+            const int tiles = (int)grid.x, rounds = (tiles + cap - 1) / cap, gsz = (tiles + rounds - 1) / rounds;
+            const size_t lds3 = (size_t)16 * (K + 8) * 2 + 2 * 4 * 4 * 64 * 4;
+            hipLaunchKernelGGL((gemv_loop_kernel<RPW, NSLOT, PER_LANE>), dim3(gsz), dim3(256), lds3, st, x, Mb, K, (const bf16_t*)W, N, ln_g, ln_b,
+                               ep.bias, ep.outf, ep.ldo);
+        } else if (ln_g && ksplit == 1 && grid.x >= 1024) {
             dim3 g3((grid.x + 2) / 3, 1);
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI, RPW, false, false, NSLOT, PER_LANE, 3>), g3, dim3(256), lds + 2 * 4 * 4 * 64 * 4, st,
                                x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);

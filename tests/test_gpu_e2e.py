@@ -1181,6 +1181,42 @@ def test_unknown_generate_kwargs_raise_instead_of_being_dropped(tiny):
     finally:
         pipe.engine.close()
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("rows", [1, 8, 13])
+def test_logits_projection_persistent_column_loop_is_bit_identical(dt, rows):
+    """The 51866-column logits projection (final LayerNorm + tied proj_out, TF modeling_whisper.py:790, 1080) as a persistent
+    column loop (gemm.hip: gemv_loop_kernel: one resident grid, rows normalised once per block, next tile's weights requested
+    under the current tile's MFMAs) against the three-tiles-per-block launch of the same arithmetic: identical bits for every
+    logit of every row, 1 / 8 / 13 rows (two and four rows per wave), teacher-forced over several positions."""
+    g, v = syn.large_v3_geometry()
+    g.enc_layers = g.dec_layers = 2
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19)]
+    W = syn.random_weights(g, seed=21)
+    T = 8
+    clips = [syn.synth_audio(700 + i, 480000 - 11000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
+    rng = np.random.default_rng(5)
+    ids = np.concatenate([[v.sot, v.lang_id("en"), v.transcribe], [v.timestamp_begin], rng.integers(300, 50000, T - 4)])
+    forced = np.full((rows, T), -1, np.int32); forced[:, 3:] = ids[3:]
+    prompt = np.tile(ids[None, :3], (rows, 1))
+    eng = Engine(spec, dtype=dt, max_batch=rows)
+    try:
+        eng.load_state_dict(W)
+        eng.mel(clips)
+        eng.encode(list(range(rows)), [0] * rows, [3000] * rows)
+        res = {}
+        for loop in (1, 0):
+            assert eng.lib.cw_test_set_option(b"gemv_loop", loop) == 0
+            cap = eng.capture_logits(rows, T)
+            eng.decode(prompt, max_length=T, forced=forced)
+            res[loop] = cap[:T - 3].copy()
+            eng.stop_capture()
+        assert np.isfinite(res[1]).all() and np.abs(res[1]).max() > 0
+        assert np.array_equal(res[1], res[0]), int((res[1] != res[0]).sum())
+    finally:
+        eng.lib.cw_test_set_option(b"gemv_loop", 1)
+        eng.close()
+
 
 @pytest.mark.parametrize("rows", [3, 8, 12])
 def test_fused_decoder_stage_tracks_eight_launch_layer(rows):
