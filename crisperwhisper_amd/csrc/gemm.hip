@@ -412,6 +412,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(AParams ap, const bf
     }
 }
 
+#ifdef CW_EXPERIMENTS   // ping-pong schedule of the 256 tile: superseded by the 8-phase schedule (round 3), kept for A/B builds
 // ---------------------------------------------------------------------------------------------------
 // Ping-pong flavour of the 256x256x64 LDS-DMA GEMM (plain row-major A, N % 256 == 0): same tile, LDS image, swizzle,
 // DMA map and epilogue as gemm_bf16_256_kernel, different time structure.  There all 8 waves move in lockstep through
@@ -558,6 +559,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
         }
     }
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Quarter-tile ("8-phase") flavour of the same 256x256x64 LDS-DMA GEMM (round 3).  The ping-pong kernel above ends every
@@ -1757,6 +1760,7 @@ static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, 
             });
             hipLaunchKernelGGL((gemm_bf16_8ph_kernel<EPI>), dim3(tm2 * tn2), dim3(512), 131072, st, (const bf16_t*)ap.A, ap.lda,
                                (const bf16_t*)W, M, N, K, ep, tn2);
+#ifdef CW_EXPERIMENTS
         } else if (g_use_glds && g_zero_page && g_use_256 && use_pp && tm2 * tn2 >= g_256_min_tiles && ap.amode == 0 && N % BN2 == 0) {
             static std::once_flag attr_pp;
             std::call_once(attr_pp, [] {
@@ -1764,6 +1768,7 @@ static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, 
             });
             hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(tm2 * tn2), dim3(512), 131072, st, (const bf16_t*)ap.A, ap.lda,
                                (const bf16_t*)W, M, N, K, ep, tn2, g_zero_page);
+#endif
         } else if (g_use_glds && g_zero_page && g_use_256 && tm2 * tn2 >= g_256_min_tiles) {
             static std::once_flag attr_once;     // one per EPI instantiation (function-local static in a template)
             std::call_once(attr_once, [] {
