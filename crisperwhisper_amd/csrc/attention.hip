@@ -529,7 +529,7 @@ int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* 
     if (bf16) {
         if (S_pad % KT != 0 || S_pad < S) return CW_ERR_INVALID;
 #ifdef CW_EXPERIMENTS
-        static const bool v1 = getenv("CW_ATTN_V1") != nullptr;   // the round-1 32-queries-per-wave kernel (A/B comparisons)
+        const bool v1 = cw_sw::cw_switches().attn_v1;   // the round-1 32-queries-per-wave kernel (A/B comparisons)
         if (v1)
             hipLaunchKernelGGL(attn_encoder_bf16_kernel, dim3(((S + 127) / 128) * H * B), dim3(256), 0, st, (const bf16_t*)Q,
                                (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, H, S, S_pad);
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
 
 int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
     size_t lds = ((size_t)((p.cap + 63) & ~63) + DEC_GROUPS * 64 + 64) * sizeof(float);
-    static const bool anc_v1 = getenv("CW_ANC_ATTN_V1") != nullptr;   // A/B: beam self-attention through the serial kernel only
+    const bool anc_v1 = cw_sw::cw_switches().anc_attn_v1;   // A/B: beam self-attention through the serial kernel only
     if (p.anc && (anc_v1 || p.n_keys > 0 || !p.pos)) {
         if (bf16) hipLaunchKernelGGL((attn_decode_anc_kernel<bf16_t>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
         else hipLaunchKernelGGL((attn_decode_anc_kernel<float>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
@@ -1370,7 +1370,7 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
         if (!p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.B > 16) return CW_ERR_INVALID;
         // A/B (CW_CROSS_LDS_PAD=bytes): unused dynamic LDS that limits how many blocks share a CU (the 960 blocks of a B = 8 launch
         // are all resident at once: their tails -- softmax, V pass, reductions -- then run together after the last byte landed)
-        static const int lds_pad = getenv("CW_CROSS_LDS_PAD") ? atoi(getenv("CW_CROSS_LDS_PAD")) : 0;
+        const int lds_pad = cw_sw::cw_switches().cross_lds_pad;
         if (lds_pad > 0) {
             static std::once_flag attr;
             std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)attn_cross_split_kernel<bf16_t, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
@@ -1378,9 +1378,9 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
         hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, 1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), (size_t)lds_pad, st, p);
         return CW_OK;
     }
-    static const bool per_row = getenv("CW_CROSS_PER_ROW") != nullptr;   // A/B: one block per row even under beam search
-    static const int valu = getenv("CW_CROSS_VALU") ? 1 : 0;             // A/B: instruction-bound 8-lane-group kernel for 2..6 rows per K/V
-    static const bool no_tr = getenv("CW_CROSS_NO_TR") != nullptr;       // A/B: 2-byte LDS reads instead of the transposing read
+    const bool per_row = cw_sw::cw_switches().cross_per_row;   // A/B: one block per row even under beam search
+    const int valu = cw_sw::cw_switches().cross_valu; // A/B: instruction-bound 8-lane-group kernel for 2..6 rows per K/V
+    const bool no_tr = cw_sw::cw_switches().cross_no_tr; // A/B: 2-byte LDS reads instead of the transposing read
     if (bf16 && p.kv_div > 1 && p.kv_div <= 16 && p.B % p.kv_div == 0 && !per_row && !(valu || g_cross_valu) &&
         (p.n_keys + ATT_NS - 1) / ATT_NS <= 256) {
         dim3 grid(p.H, p.B / p.kv_div, ATT_NS);

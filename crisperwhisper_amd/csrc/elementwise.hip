@@ -648,7 +648,7 @@ size_t cw_beam_topk_scratch_floats(int rows) { return (size_t)rows * BT_NS * BT_
 
 int cw_launch_beam_topk(const SampleParams& p, int n_cand, float* cand_val, int* cand_id, float* scratch, hipStream_t st) {
     if (n_cand < 1 || n_cand > 64) return CW_ERR_INVALID;
-    if (g_topk_1block < 0) g_topk_1block = getenv("CW_BEAM_TOPK_1BLOCK") != nullptr;
+    if (g_topk_1block < 0) g_topk_1block = cw_sw::cw_switches().beam_topk_1block;
     const bool one_block = g_topk_1block != 0;
     if (scratch && !one_block && (p.V + BT_NS - 1) / BT_NS <= BT_PER_LANE * 256) {
         hipLaunchKernelGGL(beam_topk_partial_kernel, dim3(BT_NS, p.B), dim3(256), 0, st, p, n_cand, scratch);

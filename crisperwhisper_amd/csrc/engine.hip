@@ -333,32 +333,35 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[0], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[1], hipEventDisableTiming));
-#ifdef CW_EXPERIMENTS
-    if (getenv("CW_PREFETCH")) c->prefetch = atoi(getenv("CW_PREFETCH"));
-#endif
+    c->prefetch = cw_sw::cw_switches().prefetch;   // experiments builds only (cw_create refuses it otherwise)
     HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
     if (d.dtype != CW_DTYPE_F32 && d.dtype != CW_DTYPE_BF16 && d.dtype != CW_DTYPE_F16) return fail(c, CW_ERR_INVALID, "unknown dtype %d", d.dtype);
     c->f16 = d.dtype == CW_DTYPE_F16;
     c->bf16 = d.dtype == CW_DTYPE_BF16 || c->f16;
-    if (getenv("CW_NO_GRAPH")) c->use_graph = false;
-    if (getenv("CW_NO_LN_FOLD")) c->fold_enabled = false;
-    if (getenv("CW_NO_FUSE6")) c->fuse6_enabled = false;
-    if (getenv("CW_ROWS_LN")) c->rows_ln_enabled = true;
-    if (getenv("CW_NO_ROWS_HILO")) c->rows_hilo = false;
-    if (getenv("CW_SKINNY")) c->skinny_mode = atoi(getenv("CW_SKINNY"));
-    if (getenv("CW_NO_STACK_CENTER")) c->stack_center = false;
-    if (getenv("CW_NO_MID16")) c->mid16 = false;
-    if (getenv("CW_DTW_BLOCK")) c->dtw_block = true;
+    const cw_sw::Switches& sw = cw_sw::cw_switches();   // the environment, read once per process
 #ifndef CW_EXPERIMENTS
-    for (const char* sw : {"CW_ROWS_LN", "CW_FUSE_MLP", "CW_MLP_PAIR", "CW_SKINNY", "CW_PREFETCH"})
-        if (getenv(sw) && atoi(getenv(sw)) != 0)
-            return fail(c, CW_ERR_INVALID, "%s selects a measured-and-rejected kernel variant that is not in this build: make EXTRA=-DCW_EXPERIMENTS", sw);
+    {
+        const struct { const char* name; bool set; } rejected[] = {{"CW_ROWS_LN", sw.rows_ln}, {"CW_FUSE_MLP", sw.fuse_mlp}, {"CW_MLP_PAIR", sw.mlp_pair},
+                                                                   {"CW_SKINNY", sw.skinny != 0}, {"CW_PREFETCH", sw.prefetch != 0}};
+        for (const auto& r : rejected)
+            if (r.set)
+                return fail(c, CW_ERR_INVALID, "%s selects a measured-and-rejected kernel variant that is not in this build: make EXTRA=-DCW_EXPERIMENTS", r.name);
+    }
 #endif
-    if (getenv("CW_FUSE_MLP")) c->fuse_mlp = true;
-    if (getenv("CW_NO_WPACK")) c->wpack_enabled = false;
-    if (getenv("CW_MLP_PAIR")) c->mlp_pair = true;
-    if (getenv("CW_STACK_NT3")) c->stack_nt3 = atoi(getenv("CW_STACK_NT3"));
-    if (getenv("CW_STACK_NT5")) c->stack_nt5 = atoi(getenv("CW_STACK_NT5"));
+    c->use_graph = !sw.no_graph;
+    c->fold_enabled = !sw.no_ln_fold;
+    c->fuse6_enabled = !sw.no_fuse6;
+    c->rows_ln_enabled = sw.rows_ln;
+    c->rows_hilo = !sw.no_rows_hilo;
+    c->skinny_mode = sw.skinny;
+    c->stack_center = !sw.no_stack_center;
+    c->mid16 = !sw.no_mid16;
+    c->dtw_block = sw.dtw_block;
+    c->fuse_mlp = sw.fuse_mlp;
+    c->wpack_enabled = !sw.no_wpack;
+    c->mlp_pair = sw.mlp_pair;
+    c->stack_nt3 = sw.stack_nt3;
+    c->stack_nt5 = sw.stack_nt5;
     c->esz = c->bf16 ? 2 : 4;
     c->Bm = Bm;
     c->S_pad = 1536;
@@ -1028,8 +1031,8 @@ static int launch_prefetch_layer(cw_ctx* c, int l, int nb) {
     add(L.wo_c, (size_t)D * D * e);
     add(L.w1, (size_t)F * D * e);
     add(L.w2, (size_t)D * F * e);
-    static const int wide = getenv("CW_PREFETCH_WIDE") ? atoi(getenv("CW_PREFETCH_WIDE")) : 0;
-    static const int what = getenv("CW_PREFETCH_WHAT") ? atoi(getenv("CW_PREFETCH_WHAT")) : 3;   // 1 weights, 2 cross K/V, 3 both
+    const int wide = cw_sw::cw_switches().prefetch_wide;
+    const int what = cw_sw::cw_switches().prefetch_what;   // 1 weights, 2 cross K/V, 3 both
     if (!(what & 1)) { int k = 0; for (int i = 0; i < r.count; ++i) if (r.p[i] == (const char*)L.ck || r.p[i] == (const char*)L.cv) { r.p[k] = r.p[i]; r.n[k] = r.n[i]; ++k; } r.count = k; }
     if (!(what & 2)) { int k = 0; for (int i = 0; i < r.count; ++i) if (r.p[i] != (const char*)L.ck && r.p[i] != (const char*)L.cv) { r.p[k] = r.p[i]; r.n[k] = r.n[i]; ++k; } r.count = k; }
     if (wide) hipLaunchKernelGGL(prefetch_kernel<1>, dim3(c->prefetch), dim3(256), 0, c->st2, r, c->d_pf_sink);
@@ -1683,7 +1686,7 @@ int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, 
             c->skew_cap = want;
         }
     }
-    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->dtw_block ? c->d_path_text : nullptr, getenv("CW_DTW_BLOCK") ? c->d_path_time : nullptr, c->d_path_len, c->st, c->d_skew));
+    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->dtw_block ? c->d_path_text : nullptr, c->dtw_block ? c->d_path_time : nullptr, c->d_path_len, c->st, c->d_skew));
     KCHK(c);
     tm.stop();
     std::vector<int> fc((size_t)nb * N);
@@ -2073,6 +2076,12 @@ int32_t cw_test_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "beam_topk_1block")) { cw_bf16::cw_beam_topk_set_1block(value); cw_f16::cw_beam_topk_set_1block(value); return CW_OK; }
     if (!strcmp(name, "gemm_pp")) { cw_bf16::cw_gemm_set_pp(value); cw_f16::cw_gemm_set_pp(value); return CW_OK; }
     if (!strcmp(name, "gemm_8ph")) { cw_bf16::cw_gemm_set_8ph(value); cw_f16::cw_gemm_set_8ph(value); return CW_OK; }
+    if (!strcmp(name, "gemm_gm")) {
+#ifndef CW_EXPERIMENTS
+        return CW_ERR_INVALID;
+#endif
+        cw_bf16::cw_gemm_set_gm(value); cw_f16::cw_gemm_set_gm(value); return CW_OK;
+    }
     if (!strcmp(name, "gemv_loop")) { cw_bf16::cw_gemv_set_loop(value); cw_f16::cw_gemv_set_loop(value); return CW_OK; }
     if (!strcmp(name, "gemm_w128")) { cw_bf16::cw_gemm_set_w128(value); cw_f16::cw_gemm_set_w128(value); return CW_OK; }
     if (!strcmp(name, "cross_valu")) { cw_bf16::cw_cross_set_valu(value); cw_f16::cw_cross_set_valu(value); return CW_OK; }
@@ -2091,8 +2100,7 @@ int32_t cw_test_gemm(cw_ctx* c, int32_t M, int32_t N, int32_t K, const float* A,
     EpiParams ep = epi0(); ep.out = dO; ep.bias = bias ? dB : nullptr; ep.ldo = N;
     int r = KD(c, cw_launch_gemm, c->bf16, gelu ? EPI_GELU : EPI_STORE, ap, dW, M, N, K, ep, c->st);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemm: %s", hipGetErrorString(er)); }
-    if (const char* reps_s = getenv("CW_TEST_GEMM_REPS")) {   // kernel A/B timing for the profiles (stderr only)
-        const int reps = atoi(reps_s);
+    if (const int reps = cw_sw::cw_switches().test_gemm_reps) {   // kernel A/B timing for the profiles (stderr only)
         hipEvent_t e0, e1;
         if (r == CW_OK && reps > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             hipEventRecord(e0, c->st);
@@ -2130,8 +2138,7 @@ int32_t cw_test_gemm_fp8(cw_ctx* c, int32_t M, int32_t N, int32_t K, const float
     if (r == CW_OK) r = KD(c, cw_launch_gemm_fp8, gelu ? EPI_GELU : EPI_STORE, dA8, K, dW8, M, N, K, dsa, dsw, ep, c->st);
     if (r != CW_OK) fail(c, r, "test_gemm_fp8: launch rejected (M=%d N=%d K=%d)", M, N, K);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_gemm_fp8: %s", hipGetErrorString(er)); }
-    if (const char* reps_s = getenv("CW_TEST_GEMM_REPS")) {   // kernel timing for the profiles (stderr only)
-        const int reps = atoi(reps_s);
+    if (const int reps = cw_sw::cw_switches().test_gemm_reps) {   // kernel timing for the profiles (stderr only)
         hipEvent_t e0, e1;
         if (r == CW_OK && reps > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             hipEventRecord(e0, c->st);
@@ -2217,7 +2224,7 @@ int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K
     SkinnyParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.x = dx; sp.xf = dxf; sp.W = dWp; sp.Mb = Mb; sp.K = K; sp.N = N; sp.planes = dP; sp.outf = dO; sp.bias = dB; sp.ldo = N;
-    if (reps > 0 && getenv("CW_SK_DBG")) sp.dbg = atoi(getenv("CW_SK_DBG"));   // ablation of the timed launches (-DCW_SK_DEBUG builds)
+    if (reps > 0 && getenv("CW_SK_DBG")) sp.dbg = atoi(getenv("CW_SK_DBG"));   // ablation of the timed launches (-DCW_SK_DEBUG builds; tools/skinny_ablate.py changes it between calls, so not in cw_switches)
     const int sk_dbg = sp.dbg;
     sp.dbg = 0;
     SkinnyFinishParams fp;
@@ -2297,8 +2304,7 @@ int32_t cw_test_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, const floa
     }
     int r = KD(c, cw_launch_attn_encoder, c->bf16, dq, dk, dv, dout, B, H, S, S_pad, c->st);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_attention: %s", hipGetErrorString(er)); }
-    if (const char* reps_s = getenv("CW_TEST_ATTN_REPS")) {   // kernel A/B timing for the profiles (stderr only)
-        const int reps = atoi(reps_s);
+    if (const int reps = cw_sw::cw_switches().test_attn_reps) {   // kernel A/B timing for the profiles (stderr only)
         hipEvent_t e0, e1;
         if (r == CW_OK && reps > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             hipEventRecord(e0, c->st);
@@ -2342,8 +2348,7 @@ int32_t cw_test_cross_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, int3
     int r = KD(c, cw_launch_attn_cross_split, c->bf16, p, c->st);
     if (r != CW_OK) fail(c, r, "test_cross_attention: launch rejected (B=%d H=%d S=%d kv_div=%d)", B, H, S, kv_div);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_cross_attention: %s", hipGetErrorString(er)); }
-    if (const char* reps_s = getenv("CW_TEST_ATTN_REPS")) {   // kernel A/B timing for the profiles (stderr only)
-        const int reps = atoi(reps_s);
+    if (const int reps = cw_sw::cw_switches().test_attn_reps) {   // kernel A/B timing for the profiles (stderr only)
         hipEvent_t e0, e1;
         if (r == CW_OK && reps > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             hipEventRecord(e0, c->st);

@@ -582,6 +582,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 //     the other reads fragments and issues DMA.
 // Same LDS image, swizzle, epilogue and per-element summation order as the other 256-tile kernels (bit-identical results).
 // ---------------------------------------------------------------------------------------------------
+#ifdef CW_EXPERIMENTS
+__constant__ int c_gemm_gm = 8;
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const bf16_t* __restrict__ A, int lda,
                                                             const bf16_t* __restrict__ W, int M, int N, int K,
@@ -591,9 +595,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_8ph_kernel(const bf16_t* __rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wn = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
+#ifdef CW_EXPERIMENTS
+    // tile-order A/B (option "gemm_gm"): g > 0 m-tiles per group; g < 0 the same groups of -g WITHOUT the XCD remap
+    // (consecutive tiles dealt round-robin over the eight L2s).  profiles/r04_gemm_tile_order_ab.txt
+    const int gm_ = c_gemm_gm;
+    const int tile = gm_ < 0 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    int mt_, nt_;
+    grouped_tile(tile, gridDim.x / tiles_n, tiles_n, mt_, nt_, gm_ < 0 ? -gm_ : gm_);
+#else
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     int mt_, nt_;
     grouped_tile(tile, gridDim.x / tiles_n, tiles_n, mt_, nt_);
+#endif
     const int m0 = mt_ * BM2, n0 = nt_ * BN2;
 
     // DMA map of a half tile (128 rows x 128 B): wave w, load q: rows w*16 + q*8 .. +7, lane -> (row lane >> 3, 16 B chunk
@@ -1724,6 +1737,14 @@ void cw_gemm_set_256_min_tiles(int n) { g_256_min_tiles = n; }
 static int g_use_8ph = -1;  // quarter-tile (8-phase) schedule instead of ping-pong; -1: from the environment (CW_NO_GEMM_8PH)
 void cw_gemm_set_pp(int on) { g_use_pp = on; }
 void cw_gemm_set_8ph(int on) { g_use_8ph = on; }
+void cw_gemm_set_gm(int gm) {   // experiments builds: tile order of the 8-phase kernel (see the kernel)
+#ifdef CW_EXPERIMENTS
+    if (gm == 0) gm = 8;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_gemm_gm), &gm, sizeof(int));
+#else
+    (void)gm;
+#endif
+}
 static int g_gemv_loop = -1;  // persistent column loop for very wide LayerNorm GEMVs (logits); -1: from the environment (CW_NO_GEMV_LOOP)
 void cw_gemv_set_loop(int on) { g_gemv_loop = on; }
 static int g_use_w128 = -1;  // four waves of 128 x 128 (round 4, measured slower: -DCW_EXPERIMENTS builds only); -1: from the environment (CW_GEMM_W128=1)
@@ -1738,16 +1759,16 @@ static void launch_gemm_epi(bool bf16, const AParams& ap, const void* W, int M, 
         std::call_once(once, [] {
             void* z = nullptr;
             if (hipMalloc(&z, 256) == hipSuccess) { hipMemset(z, 0, 256); g_zero_page = (const bf16_t*)z; }
-            if (getenv("CW_NO_GLDS")) g_use_glds = false;
-            if (getenv("CW_NO_GEMM256")) g_use_256 = false;
+            if (cw_sw::cw_switches().no_glds) g_use_glds = false;
+            if (cw_sw::cw_switches().no_gemm256) g_use_256 = false;
         });
         // large shapes: 256x256 tiles once they fill most of the chip (>= 200 tiles); small M keeps the 128 tiles
         const int tm2 = (M + BM2 - 1) / BM2, tn2 = (N + BN2 - 1) / BN2;
-        if (g_use_pp < 0) g_use_pp = getenv("CW_NO_GEMM_PP") == nullptr;
+        if (g_use_pp < 0) g_use_pp = !cw_sw::cw_switches().no_gemm_pp;
         const bool use_pp = g_use_pp != 0;
-        if (g_use_8ph < 0) g_use_8ph = getenv("CW_NO_GEMM_8PH") == nullptr;
+        if (g_use_8ph < 0) g_use_8ph = !cw_sw::cw_switches().no_gemm_8ph;
 #ifdef CW_EXPERIMENTS
-        if (g_use_w128 < 0) g_use_w128 = getenv("CW_GEMM_W128") != nullptr;
+        if (g_use_w128 < 0) g_use_w128 = cw_sw::cw_switches().gemm_w128;
 #else
         g_use_w128 = 0;
 #endif
@@ -1877,11 +1898,11 @@ static void launch_gemv2_shape(dim3 grid, size_t lds, int ksplit, const float* x
         // (column indices are clamped and stores masked per column, so N need not be a multiple of the block's columns.)  Very wide
         // outputs (the 51866-column logits: 3242 tiles, 12.7 per CU) take three tiles per block: every tile re-reads the 40 KB of
         // activation rows, which at one tile per block is half of all the bytes a CU takes in
-        if (g_gemv_loop < 0) g_gemv_loop = getenv("CW_NO_GEMV_LOOP") == nullptr;   // A/B: 0 = three tiles per block instead of the persistent column loop
+        if (g_gemv_loop < 0) g_gemv_loop = !cw_sw::cw_switches().no_gemv_loop;   // A/B: 0 = three tiles per block instead of the persistent column loop
         const bool no_loop = g_gemv_loop == 0;
         if (EPI == EPI_STORE_F32 && ln_g && ksplit == 1 && grid.x >= 1024 && wpk && Kb == K && K % 128 == 0 && K <= 1280 && !cb.part_ml && !no_loop && m_base == 0) {
             // the logits projection: persistent column loop, grid resident at once (3 blocks per CU), tiles spread evenly
-            static const int cap = getenv("CW_GEMV_LOOP_CAP") ? atoi(getenv("CW_GEMV_LOOP_CAP")) : 512;   // blocks in the grid per round of tiles (2 per CU measured best: 24.8 us; 3 per CU 25.9)
+            const int cap = cw_sw::cw_switches().gemv_loop_cap;   // blocks in the grid per round of tiles (2 per CU measured best: 24.8 us; 3 per CU 25.9)
             const int tiles = (int)grid.x, rounds = (tiles + cap - 1) / cap, gsz = (tiles + rounds - 1) / rounds;
             const size_t lds3 = (size_t)16 * (K + 8) * 2 + 2 * 4 * 4 * 64 * 4;
             hipLaunchKernelGGL((gemv_loop_kernel<RPW, NSLOT, PER_LANE>), dim3(gsz), dim3(256), lds3, st, x, Mb, K, (const bf16_t*)W, N, ln_g, ln_b,
@@ -1915,7 +1936,7 @@ static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, co
     while (K / ksplit > 1280) ksplit *= 2;
     // fc2 (K = 5120, N = 1280, two column tiles per block): the largest K split that still gives every block its own CU --
     // grid (40, 5) = 200 blocks of 64 KB of weights instead of (40, 4) = 160 of 80 KB: 5.15 -> 4.98 us (8 slices: 5.47)
-    static const int fc2_ks = getenv("CW_FC2_KSPLIT") ? atoi(getenv("CW_FC2_KSPLIT")) : 0;
+    const int fc2_ks = cw_sw::cw_switches().fc2_ksplit;
     if (EPI == EPI_RESID_F32 && !ln_g && !cb.part_ml && ep.outf == ep.resid && K > 1280 && N % 32 == 0) {
         if (fc2_ks > 0) { if (fc2_ks >= ksplit && K % (fc2_ks * 128) == 0) ksplit = fc2_ks; }
         else for (int ks = ksplit + 1; (N / 32) * ks <= 256; ++ks) if (K % (ks * 128) == 0) ksplit = ks;
@@ -1925,7 +1946,7 @@ static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, co
     // slices -- grid (40, 5) instead of (80, 2) -- bring the same weights with 49 KB of partials.
     // (off by default: -0.2 us per layer, but the regrouped partial sums move the residual stream by a few 2^-12 steps, and
     // one clip of the second-seed bf16 golden parts from transformers at a near-tie; CW_COMB_NT2=1)
-    static const bool comb_nt2 = getenv("CW_COMB_NT2") != nullptr;
+    const bool comb_nt2 = cw_sw::cw_switches().comb_nt2;
     if (comb_nt2 && EPI == EPI_RESID_F32 && cb.part_ml && !ln_g && ep.outf == ep.resid && K % 256 == 0 && K >= 512 && N % 32 == 0) {
         const int ks = K / 256;
         const size_t lds2 = (size_t)16 * (256 + 8) * 2 + 2 * 4 * 4 * 64 * 4;
@@ -1963,7 +1984,7 @@ static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N
     const int Kb = K / ksplit;
     dim3 grid((N + 15) / 16, ksplit);
     const bool atomic = EPI == EPI_RESID_F32 && ksplit > 1;
-    static const bool prea = getenv("CW_MT_NO_PREA") == nullptr;   // A/B: activation fragments fetched on demand
+    const bool prea = !cw_sw::cw_switches().mt_no_prea;   // A/B: activation fragments fetched on demand
 #define CW_MT_LAUNCH(NS)                                                                                              \
     do {                                                                                                              \
         if (atomic && prea)                                                                                           \

@@ -11,8 +11,7 @@ namespace CW_NS {
 // Grouped tile order (logical id -> (m-tile, n-tile)): ids walk down GM m-tiles of one n-tile before moving to
 // the next n-tile, so the ~32 blocks resident on an XCD share 8 A panels x 4 W panels (< 4 MB L2) instead of
 // streaming the whole weight matrix once per m-tile row (measured 24x over-fetch on fc1 with row-major order).
-__device__ inline void grouped_tile(int tile, int tiles_m, int tiles_n, int& mt, int& nt) {
-    const int GM = 8;
+__device__ inline void grouped_tile(int tile, int tiles_m, int tiles_n, int& mt, int& nt, const int GM = 8) {
     const int width = GM * tiles_n;
     const int group = tile / width;
     const int first_m = group * GM;

@@ -1,5 +1,6 @@
 // Internal launcher interface between the kernel translation units and the engine.
 #pragma once
+#include "switches.h"
 #include "common.h"
 
 // A-operand addressing for the tile GEMMs: plain row-major or implicit conv1d(k=3, pad=1) gather.
@@ -239,6 +240,7 @@ struct MelTables {
     void cw_gemm_set_256_min_tiles(int n); \
     void cw_gemm_set_pp(int on); \
     void cw_gemm_set_8ph(int on); \
+    void cw_gemm_set_gm(int gm); \
     void cw_gemm_set_w128(int on); \
     void cw_gemv_set_loop(int on); \
     int cw_launch_gemm_w128(int epi, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const EpiParams& ep, int tm2, int tn2, hipStream_t st); \

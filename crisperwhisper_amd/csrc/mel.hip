@@ -344,9 +344,9 @@ int cw_launch_mel(const MelTables& t, const float* pcm, int B, int n_mels, float
                   hipStream_t st) {
     if (n_mels > 256 || B <= 0) return CW_ERR_INVALID;
     (void)hipMemsetAsync(gmax, 0, sizeof(unsigned int) * B, st);   // ordered encoding: 0 is below every float
-    static const bool valu = getenv("CW_MEL_VALU") != nullptr;   // A/B: round-1 VALU kernel
+    const bool valu = cw_sw::cw_switches().mel_valu;   // A/B: round-1 VALU kernel
 #ifdef CW_SK_DEBUG
-    MelTables t2 = t; t2.dbg = getenv("CW_MEL_DBG") ? atoi(getenv("CW_MEL_DBG")) : 0;
+    MelTables t2 = t; t2.dbg = cw_sw::cw_switches().mel_dbg;
 #else
     const MelTables& t2 = t;
 #endif

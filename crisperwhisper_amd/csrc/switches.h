@@ -1,0 +1,27 @@
+// A/B switches of the kernel launchers and the engine, read from the environment ONCE per process (first use) --
+// no launch path calls getenv.  Every switch defaults to the fast path; DESIGN.md "A/B switches" lists what each
+// one selects and the profile that measured it.
+#pragma once
+
+namespace cw_sw {
+
+struct Switches {
+    // engine (cw_create)
+    bool no_graph, no_ln_fold, no_fuse6, rows_ln, no_rows_hilo, no_stack_center, no_mid16, dtw_block, fuse_mlp, no_wpack, mlp_pair;
+    int skinny, prefetch, prefetch_wide, prefetch_what, stack_nt3, stack_nt5;
+    // attention launchers
+    bool attn_v1, anc_attn_v1, cross_per_row, cross_valu, cross_no_tr;
+    int cross_lds_pad;
+    // GEMM / GEMV launchers
+    bool no_glds, no_gemm256, no_gemm_pp, no_gemm_8ph, gemm_w128, no_gemv_loop, comb_nt2, mt_no_prea;
+    int gemv_loop_cap, fc2_ksplit;
+    // sampling, mel
+    bool beam_topk_1block, mel_valu;
+    int mel_dbg;
+    // timing loops of the cw_test_* entry points (0 = off)
+    int test_gemm_reps, test_attn_reps;
+};
+
+const Switches& cw_switches();
+
+}  // namespace cw_sw
