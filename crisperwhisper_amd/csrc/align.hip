@@ -322,7 +322,7 @@ size_t cw_dtw_skew_floats(int B, int N, int S) {           // workspace of the w
 int cw_launch_dtw(const float* mat, int B, int N, int S, const int* n_cols, unsigned char* trace, int* first_col,
                   int* path_text, int* path_time, int* path_len, hipStream_t st, float* skew) {
     if (N > DTW_THREADS || N <= 0) return CW_ERR_INVALID;
-    if (cw_sw::cw_switches().dtw_block || !skew) {   // CW_DTW_BLOCK: the round-1 block kernel, kept for A/B runs
+    if (!skew) {   // no skew workspace: the round-1 block kernel (contexts created under CW_DTW_BLOCK=1, A/B runs)
         hipLaunchKernelGGL(dtw_kernel, dim3(B), dim3(DTW_THREADS), 0, st, mat, N, S, n_cols, trace, first_col, path_text,
                            path_time, path_len);
         return CW_OK;

@@ -333,12 +333,11 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[0], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[1], hipEventDisableTiming));
-    c->prefetch = cw_sw::cw_switches().prefetch;   // experiments builds only (cw_create refuses it otherwise)
     HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
     if (d.dtype != CW_DTYPE_F32 && d.dtype != CW_DTYPE_BF16 && d.dtype != CW_DTYPE_F16) return fail(c, CW_ERR_INVALID, "unknown dtype %d", d.dtype);
     c->f16 = d.dtype == CW_DTYPE_F16;
     c->bf16 = d.dtype == CW_DTYPE_BF16 || c->f16;
-    const cw_sw::Switches& sw = cw_sw::cw_switches();   // the environment, read once per process
+    const cw_sw::Switches sw = cw_sw::read_switches();   // the environment as it is now: a context's switches are fixed at creation
 #ifndef CW_EXPERIMENTS
     {
         const struct { const char* name; bool set; } rejected[] = {{"CW_ROWS_LN", sw.rows_ln}, {"CW_FUSE_MLP", sw.fuse_mlp}, {"CW_MLP_PAIR", sw.mlp_pair},
@@ -362,6 +361,7 @@ static int create_impl(cw_ctx* c) {
     c->mlp_pair = sw.mlp_pair;
     c->stack_nt3 = sw.stack_nt3;
     c->stack_nt5 = sw.stack_nt5;
+    c->prefetch = sw.prefetch;   // experiments builds only (refused above otherwise)
     c->esz = c->bf16 ? 2 : 4;
     c->Bm = Bm;
     c->S_pad = 1536;
@@ -1686,7 +1686,7 @@ int32_t cw_token_timestamps(cw_ctx* c, int32_t nb, int32_t L, int32_t n_prompt, 
             c->skew_cap = want;
         }
     }
-    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->dtw_block ? c->d_path_text : nullptr, c->dtw_block ? c->d_path_time : nullptr, c->d_path_len, c->st, c->d_skew));
+    CWCHK(c, cw_launch_dtw(c->d_mat, nb, N, S, c->d_ncols, c->d_trace, c->d_first_col, c->dtw_block ? c->d_path_text : nullptr, c->dtw_block ? c->d_path_time : nullptr, c->d_path_len, c->st, c->dtw_block ? nullptr : c->d_skew));
     KCHK(c);
     tm.stop();
     std::vector<int> fc((size_t)nb * N);
@@ -1846,7 +1846,7 @@ int32_t cw_dtw(cw_ctx* c, const float* mat, int32_t N, int32_t M, int32_t* text_
     HIPCHK(c, hipMemcpy(dn, &M, 4, hipMemcpyHostToDevice));
     float* dskew = nullptr;
     HIPCHK(c, hipMalloc((void**)&dskew, cw_dtw_skew_floats(1, N, M) * 4));
-    int r = cw_launch_dtw(dmat, 1, N, M, dn, dtr, dfc, dpt, dpj, dpl, c->st, dskew);
+    int r = cw_launch_dtw(dmat, 1, N, M, dn, dtr, dfc, dpt, dpj, dpl, c->st, c->dtw_block ? nullptr : dskew);
     if (r == CW_OK) {
         std::vector<int> pt(N + M + 2), pj(N + M + 2);
         int n = 0;

@@ -7,7 +7,7 @@ namespace cw_sw {
 static bool flag(const char* name) { return getenv(name) != nullptr; }
 static int num(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
-static Switches read_switches() {
+Switches read_switches() {
     Switches s{};
     s.no_graph = flag("CW_NO_GRAPH");
     s.no_ln_fold = flag("CW_NO_LN_FOLD");

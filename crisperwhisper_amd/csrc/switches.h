@@ -1,5 +1,5 @@
-// A/B switches of the kernel launchers and the engine, read from the environment ONCE per process (first use) --
-// no launch path calls getenv.  Every switch defaults to the fast path; DESIGN.md "A/B switches" lists what each
+// A/B switches of the kernel launchers and the engine.  The launchers read them ONCE per process (first use), a context
+// reads its own when it is created (cw_create) -- no launch path calls getenv.  Every switch defaults to the fast path; DESIGN.md "A/B switches" lists what each
 // one selects and the profile that measured it.
 #pragma once
 
@@ -22,6 +22,7 @@ struct Switches {
     int test_gemm_reps, test_attn_reps;
 };
 
-const Switches& cw_switches();
+const Switches& cw_switches();   // parsed on first use, then fixed for the process (the launchers)
+Switches read_switches();            // parsed now (cw_create: a context's own switches are fixed when it is created)
 
 }  // namespace cw_sw
