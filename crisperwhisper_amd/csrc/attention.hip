@@ -1458,9 +1458,12 @@ __device__ inline void fp8x16_to_f32(const uint4& r, float* o) {
 
 #define CROSS8_GROUPS (CROSS_THREADS / 4)
 #define C8U 2             // key rows per lane in flight: 2 x 128 groups = 256 slots for the 250 keys of a 6-way split
+// Round 4: a block moves only 32 KB, so its time is its latency chain, not its bytes.  The V rows of the first (at 1500
+// frames: only) pass are requested together with the K rows instead of after the softmax -- one memory round trip per block
+// instead of two, results bit-identical (profiles/r04_cross_fp8_latency.txt).
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_fp8_kernel(CrossSplitParams p) {
     __shared__ float sc[512];
-    __shared__ float red[CROSS8_GROUPS * 64];
+    __shared__ __attribute__((aligned(16))) float red[CROSS8_GROUPS * 64];
     __shared__ float scratch[64];
     const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
@@ -1469,6 +1472,11 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_fp8_kernel(Cro
     const int bk = p.kv_div > 1 ? b / p.kv_div : b;
     const unsigned char* Kh = (const unsigned char*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
     const unsigned char* Vh = (const unsigned char*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
+    uint4 kr[C8U], v0[C8U];
+#pragma unroll
+    for (int u = 0; u < C8U; ++u) kr[u] = *(const uint4*)(Kh + (size_t)min(grp + u * CROSS8_GROUPS, nk - 1) * 64);
+#pragma unroll
+    for (int u = 0; u < C8U; ++u) v0[u] = *(const uint4*)(Vh + (size_t)min(grp + u * CROSS8_GROUPS, nk - 1) * 64);
     const float ks = p.kv_scale[((size_t)bk * p.H + h) * 2], vs = p.kv_scale[((size_t)bk * p.H + h) * 2 + 1];
     float qv[16];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 16, qv);
@@ -1476,9 +1484,10 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_fp8_kernel(Cro
 
     float mx = -INFINITY;
     for (int k0 = grp; k0 < nk; k0 += C8U * CROSS8_GROUPS) {
-        uint4 kr[C8U];
+        if (k0 != grp) {
 #pragma unroll
-        for (int u = 0; u < C8U; ++u) kr[u] = *(const uint4*)(Kh + (size_t)min(k0 + u * CROSS8_GROUPS, nk - 1) * 64);
+            for (int u = 0; u < C8U; ++u) kr[u] = *(const uint4*)(Kh + (size_t)min(k0 + u * CROSS8_GROUPS, nk - 1) * 64);
+        }
 #pragma unroll
         for (int u = 0; u < C8U; ++u) {
             const int k = k0 + u * CROSS8_GROUPS;
@@ -1517,7 +1526,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_fp8_kernel(Cro
     for (int k0 = grp; k0 < nk; k0 += C8U * CROSS8_GROUPS) {
         uint4 vr[C8U];
 #pragma unroll
-        for (int u = 0; u < C8U; ++u) vr[u] = *(const uint4*)(Vh + (size_t)min(k0 + u * CROSS8_GROUPS, nk - 1) * 64);
+        for (int u = 0; u < C8U; ++u) vr[u] = k0 == grp ? v0[u] : *(const uint4*)(Vh + (size_t)min(k0 + u * CROSS8_GROUPS, nk - 1) * 64);
 #pragma unroll
         for (int u = 0; u < C8U; ++u) {
             const int k = k0 + u * CROSS8_GROUPS;
@@ -1531,10 +1540,13 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_fp8_kernel(Cro
         }
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) red[grp * 64 + sub * 16 + e] = acc[e];
+    for (int e = 0; e < 16; e += 4) *(float4*)&red[grp * 64 + sub * 16 + e] = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
     __syncthreads();
     if (tid < 64) {
+        // summed in group order by one wave: a two-level sum over all 512 threads is ~1 us shorter per block but regroups the
+        // f32 additions, and one clip of the batch-64 e4m3 golden then parts from transformers at a near-tie
         float r = 0.f;
+#pragma unroll 16
         for (int gI = 0; gI < CROSS8_GROUPS; ++gI) r += red[gI * 64 + tid];
         p.part_o[((size_t)sp * p.B + b) * p.H * 64 + h * 64 + tid] = r * vs;
     }
