@@ -1457,104 +1457,130 @@ __device__ inline void fp8x16_to_f32(const uint4& r, float* o) {
 }
 
 #define CROSS8_GROUPS (CROSS_THREADS / 4)
-#define C8U 2             // key rows per lane in flight: 2 x 128 groups = 256 slots for the 250 keys of a 6-way split
-// Round 4: a block moves only 32 KB, so its time is its latency chain, not its bytes.  The V rows of the first (at 1500
-// frames: only) pass are requested together with the K rows instead of after the softmax -- one memory round trip per block
-// instead of two, results bit-identical (profiles/r04_cross_fp8_latency.txt).
+#define C8U 2             // key rows per lane: 2 x 128 groups = 256 slots for the 250 keys of a 6-way split
+__device__ inline float row_ror4_add(float v) { return v + dpp_mov<0x124, 0xf>(0.f, v); }   // + lane + 4 within the row of 16 (row_ror:4)
+// Round 4: the round-2 structure of attn_cross_split_kernel on e4m3 rows.  A block moves only 32 KB, so its time is its latency
+// chain, not its bytes: every K and V row is requested up front (one memory round trip), a lane keeps the scores of its two
+// keys in registers through the K pass, the exponentials and the V pass (no score goes through LDS; alignment heads write
+// theirs straight to the alignment buffer), and the only block-wide exchanges are the running maximum (8 floats) and the
+// 8 x 64 partial outputs: 2 barriers per block instead of 7, the 128-group serial LDS sum became four cross-lane steps + 8
+// adds.  Needs nk <= 2 * 128 keys per block.  profiles/r04_cross_fp8_latency.txt
+// NSB = key splits per block.  With many rows (B x H x ATT_NS blocks >> what is resident) the launch is bound by the bytes a CU
+// has in flight -- resident blocks x bytes per block / block lifetime -- and a 32 KB block spends most of its lifetime in its
+// fixed chain: NSB = 2 lets one block carry two adjacent splits (64 KB requested up front, the same two barriers), each split
+// computed exactly as a block of its own would (bit-identical partials).  grid (H, B, ATT_NS / NSB).
+template <int NSB>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_fp8_kernel(CrossSplitParams p) {
-    __shared__ float sc[512];
-    __shared__ __attribute__((aligned(16))) float red[CROSS8_GROUPS * 64];
-    __shared__ float scratch[64];
-    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    __shared__ float s_max[NSB * 8];
+    __shared__ __attribute__((aligned(16))) float red[NSB * 8 * 64];
+    __shared__ float red_l[NSB * 8];
+    const int h = blockIdx.x, b = blockIdx.y, sp0 = blockIdx.z * NSB;
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
-    const int k_lo = sp * per, k_hi = min(p.n_keys, k_lo + per), nk = k_hi - k_lo;
-    const int tid = threadIdx.x, sub = tid & 3, grp = tid >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, sub = tid & 3, grp = tid >> 2;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int G = CROSS8_GROUPS;
     const int bk = p.kv_div > 1 ? b / p.kv_div : b;
-    const unsigned char* Kh = (const unsigned char*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
-    const unsigned char* Vh = (const unsigned char*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 16;
-    uint4 kr[C8U], v0[C8U];
+    const unsigned char* Kb = (const unsigned char*)p.K + ((size_t)bk * p.H + h) * p.n_keys * 64 + sub * 16;
+    const unsigned char* Vb = (const unsigned char*)p.V + ((size_t)bk * p.H + h) * p.n_keys * 64 + sub * 16;
+    int k_lo[NSB], nk[NSB];
+    uint4 kr[NSB][C8U], vr[NSB][C8U];
 #pragma unroll
-    for (int u = 0; u < C8U; ++u) kr[u] = *(const uint4*)(Kh + (size_t)min(grp + u * CROSS8_GROUPS, nk - 1) * 64);
+    for (int s = 0; s < NSB; ++s) {
+        k_lo[s] = (sp0 + s) * per;
+        nk[s] = min(p.n_keys, k_lo[s] + per) - k_lo[s];
 #pragma unroll
-    for (int u = 0; u < C8U; ++u) v0[u] = *(const uint4*)(Vh + (size_t)min(grp + u * CROSS8_GROUPS, nk - 1) * 64);
+        for (int u = 0; u < C8U; ++u) kr[s][u] = *(const uint4*)(Kb + (size_t)(k_lo[s] + min(grp + u * G, nk[s] - 1)) * 64);   // unconditional, clamped
+    }
+#pragma unroll
+    for (int s = 0; s < NSB; ++s)
+#pragma unroll
+        for (int u = 0; u < C8U; ++u) vr[s][u] = *(const uint4*)(Vb + (size_t)(k_lo[s] + min(grp + u * G, nk[s] - 1)) * 64);
     const float ks = p.kv_scale[((size_t)bk * p.H + h) * 2], vs = p.kv_scale[((size_t)bk * p.H + h) * 2 + 1];
     float qv[16];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 16, qv);
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 16 + 8, qv + 8);
 
-    float mx = -INFINITY;
-    for (int k0 = grp; k0 < nk; k0 += C8U * CROSS8_GROUPS) {
-        if (k0 != grp) {
+    float d[NSB][C8U], mx[NSB];
 #pragma unroll
-            for (int u = 0; u < C8U; ++u) kr[u] = *(const uint4*)(Kh + (size_t)min(k0 + u * CROSS8_GROUPS, nk - 1) * 64);
-        }
+    for (int s = 0; s < NSB; ++s) {
+        mx[s] = -INFINITY;
 #pragma unroll
         for (int u = 0; u < C8U; ++u) {
-            const int k = k0 + u * CROSS8_GROUPS;
-            if (k < nk) {
-                float kv[16];
-                fp8x16_to_f32(kr[u], kv);
-                float d = 0.f;
+            float kv[16];
+            fp8x16_to_f32(kr[s][u], kv);
+            float t = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) d = fmaf(qv[e], kv[e], d);
-                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64);
-                d *= ks;
-                if (sub == 0) sc[k] = d;
-                mx = fmaxf(mx, d);
-            }
+            for (int e = 0; e < 16; ++e) t = fmaf(qv[e], kv[e], t);
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64);
+            d[s][u] = (grp + u * G < nk[s]) ? t * ks : -INFINITY;
+            mx[s] = fmaxf(mx[s], d[s][u]);
         }
+        mx[s] = wave_max(mx[s]);
+        if (lane == 0) s_max[s * 8 + wave] = mx[s];
     }
-    mx = block_max(mx, scratch);
-    float sum = 0.f;
-    for (int k = tid; k < nk; k += CROSS_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
-    sum = block_sum(sum, scratch);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NSB; ++s) {
+        float m = s_max[s * 8];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, s_max[s * 8 + w]);
+        mx[s] = m;
+    }
 
     const int slot = p.align_out ? p.align_slot[h] : -1;
-    if (slot >= 0) {
-        const int arow = p.pos[b];
-        const size_t rowi = ((size_t)b * p.n_align + slot) * p.align_rows + arow;
-        float* dst = p.align_out + rowi * p.n_keys + k_lo;
-        for (int k = tid; k < nk; k += CROSS_THREADS) dst[k] = sc[k];
-        if (tid == 0) { p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = sum; }
-    }
-    if (tid == 0) {
-        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp) * 2;
-        ml[0] = mx; ml[1] = sum;
-    }
-
-    float acc[16] = {};
-    for (int k0 = grp; k0 < nk; k0 += C8U * CROSS8_GROUPS) {
-        uint4 vr[C8U];
+    const size_t rowi = slot >= 0 ? ((size_t)b * p.n_align + slot) * p.align_rows + p.pos[b] : 0;
 #pragma unroll
-        for (int u = 0; u < C8U; ++u) vr[u] = k0 == grp ? v0[u] : *(const uint4*)(Vh + (size_t)min(k0 + u * CROSS8_GROUPS, nk - 1) * 64);
+    for (int s = 0; s < NSB; ++s) {
+        float acc[16] = {};
+        float lsum = 0.f;
 #pragma unroll
         for (int u = 0; u < C8U; ++u) {
-            const int k = k0 + u * CROSS8_GROUPS;
-            if (k < nk) {
-                float vv[16];
-                fp8x16_to_f32(vr[u], vv);
-                const float pk = sc[k];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+            const int k = grp + u * G;
+            float vv[16];
+            fp8x16_to_f32(vr[s][u], vv);
+            const float pk = (k < nk[s]) ? expf(d[s][u] - mx[s]) : 0.f;
+            if (sub == 0 && k < nk[s]) {
+                lsum += pk;
+                if (slot >= 0) p.align_out[rowi * p.n_keys + k_lo[s] + k] = pk;   // un-normalised; align_normalize_kernel finishes the row
             }
-        }
-    }
 #pragma unroll
-    for (int e = 0; e < 16; e += 4) *(float4*)&red[grp * 64 + sub * 16 + e] = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+            for (int e = 0; e < 16; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+        }
+        // sum over the wave's 16 key groups (lane bits 2..5)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = xor32_sum(xor16_sum(row_ror8_add(row_ror4_add(acc[e]))));
+        lsum = wave_sum(lsum);
+        if (lane < 4) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) *(float4*)&red[(s * 8 + wave) * 64 + sub * 16 + e] = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+        }
+        if (lane == 0) red_l[s * 8 + wave] = lsum;
+    }
     __syncthreads();
-    if (tid < 64) {
-        // summed in group order by one wave: a two-level sum over all 512 threads is ~1 us shorter per block but regroups the
-        // f32 additions, and one clip of the batch-64 e4m3 golden then parts from transformers at a near-tie
+    if (tid < 64 * NSB) {
+        const int s = tid >> 6, c = tid & 63;
         float r = 0.f;
-#pragma unroll 16
-        for (int gI = 0; gI < CROSS8_GROUPS; ++gI) r += red[gI * 64 + tid];
-        p.part_o[((size_t)sp * p.B + b) * p.H * 64 + h * 64 + tid] = r * vs;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) r += red[(s * 8 + w) * 64 + c];
+        p.part_o[((size_t)(sp0 + s) * p.B + b) * p.H * 64 + h * 64 + c] = r * vs;
+    } else if (tid < 64 * NSB + NSB) {
+        const int s = tid - 64 * NSB;
+        float l = 0.f, m = s_max[s * 8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { l += red_l[s * 8 + w]; m = fmaxf(m, s_max[s * 8 + w]); }
+        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp0 + s) * 2;
+        ml[0] = m; ml[1] = l;
+        if (slot >= 0) { p.align_ml[(rowi * ATT_NS + sp0 + s) * 2] = m; p.align_ml[(rowi * ATT_NS + sp0 + s) * 2 + 1] = l; }
     }
 }
 
 int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st) {
-    if ((p.n_keys + ATT_NS - 1) / ATT_NS > 512 || !p.kv_scale) return CW_ERR_INVALID;
-    hipLaunchKernelGGL(attn_cross_split_fp8_kernel, dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+    if ((p.n_keys + ATT_NS - 1) / ATT_NS > C8U * CROSS8_GROUPS || !p.kv_scale) return CW_ERR_INVALID;
+    // two splits per block once the grid is several times what is resident (4 blocks of 512 threads per CU); A/B: CW_CROSS8_NSB=1|2
+    const int force = cw_sw::cw_switches().cross8_nsb;
+    const bool pair = ATT_NS % 2 == 0 && (force ? force == 2 : (size_t)p.H * p.B * ATT_NS >= 4096);
+    if (pair) hipLaunchKernelGGL(attn_cross_split_fp8_kernel<2>, dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
+    else hipLaunchKernelGGL(attn_cross_split_fp8_kernel<1>, dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
     return CW_OK;
 }
 

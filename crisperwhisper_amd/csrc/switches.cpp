@@ -32,6 +32,7 @@ Switches read_switches() {
     s.cross_valu = flag("CW_CROSS_VALU");
     s.cross_no_tr = flag("CW_CROSS_NO_TR");
     s.cross_lds_pad = num("CW_CROSS_LDS_PAD", 0);
+    s.cross8_nsb = num("CW_CROSS8_NSB", 0);
     s.no_glds = flag("CW_NO_GLDS");
     s.no_gemm256 = flag("CW_NO_GEMM256");
     s.no_gemm_pp = flag("CW_NO_GEMM_PP");
