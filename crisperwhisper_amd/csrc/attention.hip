@@ -1407,10 +1407,14 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
 // the structure of attn_cross_split_kernel with 4 lanes x 16 elements per key row.
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define X8_SPLIT_BYTES 16384   // fragment-major V of one (batch, head, key split): 8 waves x 64 lanes x 4 dim tiles x 8 keys
 
+// vfrag: V is written in the order attn_cross_mfma8_kernel's B fragments read it -- per (batch, head, key split) X8_SPLIT_BYTES
+// bytes [wave 8][lane 64][dim tile 4][8 keys]: lane (j, g) of wave w holds, for dim 16 dt + j, keys 32 w + 8 g .. + 7 of the
+// split (zeros past the split's last key), so a wave's V operand is one contiguous 2 KB read and needs no transposition.
 __global__ __launch_bounds__(512) void kv_quant_fp8_kernel(const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                            unsigned char* __restrict__ K8, unsigned char* __restrict__ V8,
-                                                           float* __restrict__ kv_scale, int S) {
+                                                           float* __restrict__ kv_scale, int S, int vfrag) {
     __shared__ float scratch[64];
     const int h = blockIdx.x, b = blockIdx.y, which = blockIdx.z, H = gridDim.x;
     const size_t base = ((size_t)b * H + h) * S * 64;
@@ -1428,6 +1432,27 @@ __global__ __launch_bounds__(512) void kv_quant_fp8_kernel(const bf16_t* __restr
     const float scale = amax > 0.f ? amax / 448.0f : 1.0f;     // e4m3 max finite = 448
     const float inv = 1.0f / scale;
     if (threadIdx.x == 0) kv_scale[((size_t)b * H + h) * 2 + which] = scale;
+    if (which == 1 && vfrag) {
+        unsigned char* dstf = V8 + ((size_t)b * H + h) * (ATT_NS * X8_SPLIT_BYTES);
+        const int per = (S + ATT_NS - 1) / ATT_NS;
+        for (int u = threadIdx.x; u < ATT_NS * (X8_SPLIT_BYTES / 8); u += 512) {
+            const int dt = u & 3, ln = (u >> 2) & 63, w = (u >> 8) & 7, sp = u >> 11;
+            const int j = ln & 15, g = ln >> 4;
+            const int nk = min(S, (sp + 1) * per) - sp * per;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int ks = 32 * w + 8 * g + r;
+                v[r] = ks < nk ? bf16_to_f32(src[(size_t)(sp * per + ks) * 64 + 16 * dt + j]) * inv : 0.f;
+            }
+            int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+            int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+            *(uint2*)(dstf + (size_t)u * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < nvec; i += 512) {
         float v[8];
         Row8<bf16_t>::ld(src + (size_t)i * 8, v);
@@ -1439,10 +1464,18 @@ __global__ __launch_bounds__(512) void kv_quant_fp8_kernel(const bf16_t* __restr
     }
 }
 
+// the e4m3 cross-attention runs on the fp8 matrix cores and reads V in fragment-major order unless CW_CROSS8_VALU=1 (round-2/4
+// VALU kernel over a row-major V, A/B); the quantiser writes the layout the attention kernel of this process reads
+static bool cross8_mfma(int n_keys) { return !cw_sw::cw_switches().cross8_valu && (n_keys + ATT_NS - 1) / ATT_NS <= 256; }
+size_t cw_kv8_v_bytes(int H, int S) {   // bytes of the e4m3 V cache per batch item (either layout fits)
+    const size_t row_major = (size_t)H * S * 64, frag = (size_t)H * ATT_NS * X8_SPLIT_BYTES;
+    return row_major > frag ? row_major : frag;
+}
 int cw_launch_kv_quant_fp8(const void* K, const void* V, void* K8, void* V8, float* kv_scale, int B, int H, int S,
                            hipStream_t st) {
+    if (S < 1 || (ATT_NS - 1) * ((S + ATT_NS - 1) / ATT_NS) >= S) return CW_ERR_INVALID;
     hipLaunchKernelGGL(kv_quant_fp8_kernel, dim3(H, B, 2), dim3(512), 0, st, (const bf16_t*)K, (const bf16_t*)V,
-                       (unsigned char*)K8, (unsigned char*)V8, kv_scale, S);
+                       (unsigned char*)K8, (unsigned char*)V8, kv_scale, S, cross8_mfma(S) ? 1 : 0);
     return CW_OK;
 }
 
@@ -1574,8 +1607,171 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_fp8_kernel(Cro
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// e4m3 cross-attention on the fp8 matrix cores (v_mfma_f32_16x16x32_fp8_fp8; operand layout probed in
+// tools/probe/mfma_fp8_layout.hip).  grid (H, B, ATT_NS), 512 threads; a wave owns 32 consecutive keys of the split.
+// The VALU kernel above spends 16 conversions + 32 multiply-adds per key and lane plus 64 cross-lane adds per block; here the
+// cache bytes go to the matrix pipe as they come from HBM and nothing is converted:
+//   * S = Q K^T: A = the query (one row of work, so rows 0..2 of the 16 carry the query as THREE e4m3 terms
+//     q c1 = t0 + t1 / 16 + t2 / 256, residuals exact in f32: 12 significant bits, the rows are weighted after the product),
+//     B = the K rows as loaded (lane (key j, g): dims 16 g .. + 15, two MFMAs over the permuted contraction index);
+//     lane (j, 0) then holds the three row sums of key j -- no cross-lane add;
+//   * O = P V: A = the probabilities (x 256) as three e4m3 terms again (through a wave-private 32-float LDS row: the score
+//     fragment has key j in lane j, the A fragment wants keys 8 g .. + 7 per lane), B = V in the fragment-major order the
+//     quantiser wrote (one contiguous 32-byte read per lane): four MFMAs, lane (j, 0) holds dim 16 dt + j;
+//   * the running maximum (8 floats), the partial planes, (m, l) pairs and alignment rows are those of the VALU kernel.
+// ---------------------------------------------------------------------------------------------------
+__device__ inline unsigned pk4_e4m3(float a, float b, float c, float d) {
+    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
+__device__ inline void unpk4_e4m3(unsigned w, float* o) {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), c = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+    o[0] = a[0]; o[1] = a[1]; o[2] = c[0]; o[3] = c[1];
+}
+// x[0..7] (|x| <= 448) = t0 + t1 / 16 + t2 / 256 with t_i on the e4m3 grid; returns term `term` (0..2) as 8 bytes, 0 otherwise
+__device__ inline long split3_e4m3(const float* x, int term) {
+    float r[8], f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = x[e];
+    uint2 t[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        t[s].x = pk4_e4m3(r[0], r[1], r[2], r[3]);
+        t[s].y = pk4_e4m3(r[4], r[5], r[6], r[7]);
+        if (s < 2) {
+            unpk4_e4m3(t[s].x, f); unpk4_e4m3(t[s].y, f + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (r[e] - f[e]) * 16.f;
+        }
+    }
+    const uint2 sel = term == 0 ? t[0] : term == 1 ? t[1] : term == 2 ? t[2] : make_uint2(0u, 0u);
+    return (long)(((unsigned long)sel.y << 32) | sel.x);
+}
+__global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSplitParams p) {
+    __shared__ float s_max[8];
+    __shared__ __attribute__((aligned(16))) float red[8 * 64];
+    __shared__ float red_l[8];
+    __shared__ __attribute__((aligned(16))) float s_p[8 * 32];
+    __shared__ long s_aq[2 * 64];
+    __shared__ float s_c1;
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
+    const int k_lo = sp * per, nk = min(p.n_keys, k_lo + per) - k_lo;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = wave * 32;
+    const int D = p.H * 64;
+    const int bk = p.kv_div > 1 ? b / p.kv_div : b;
+    const size_t bh = (size_t)bk * p.H + h;
+    const unsigned char* Kh = (const unsigned char*)p.K + (bh * p.n_keys + k_lo) * 64;
+    const unsigned char* Vf = (const unsigned char*)p.V + (bh * ATT_NS + sp) * X8_SPLIT_BYTES + (size_t)wave * 2048 + lane * 32;
+    // every load of the block first
+    uint4 kf[2], vf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) kf[t] = *(const uint4*)(Kh + (size_t)min(kb + t * 16 + r, nk - 1) * 64 + g * 16);
+    vf[0] = *(const uint4*)Vf; vf[1] = *(const uint4*)(Vf + 16);
+    const float ks = p.kv_scale[bh * 2], vs = p.kv_scale[bh * 2 + 1];
+    // the query fragments are the same for all eight waves: wave 0 loads the row (16 B-per-lane loads cost the CU's address
+    // unit 16 clocks each whatever they fetch), scales it to the e4m3 range and splits it; the others pick the 16 bytes up from
+    // LDS behind a barrier that their own K / V loads are in flight across
+    if (wave == 0) {
+        float qf[16];
+        const float* qp = p.q + (size_t)b * D + h * 64 + g * 16;
+        const float4 q0 = *(const float4*)qp, q1 = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
+        qf[0] = q0.x; qf[1] = q0.y; qf[2] = q0.z; qf[3] = q0.w; qf[4] = q1.x; qf[5] = q1.y; qf[6] = q1.z; qf[7] = q1.w;
+        qf[8] = q2.x; qf[9] = q2.y; qf[10] = q2.z; qf[11] = q2.w; qf[12] = q3.x; qf[13] = q3.y; qf[14] = q3.z; qf[15] = q3.w;
+        float am = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(qf[e]));
+        am = fmaxf(am, __shfl_xor(am, 16, 64));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        const float cq = am > 0.f ? 448.0f / am : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) qf[e] *= cq;
+        s_aq[lane] = split3_e4m3(qf, r);
+        s_aq[64 + lane] = split3_e4m3(qf + 8, r);
+        if (lane == 0) s_c1 = cq;
+    }
+    __syncthreads();
+    const long aq0 = s_aq[lane], aq1 = s_aq[64 + lane];
+    const float c1 = s_c1;
+    const float s_unscale = ks / c1;
+    float sc[2], mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq0, (long)(((unsigned long)kf[t].y << 32) | kf[t].x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq1, (long)(((unsigned long)kf[t].w << 32) | kf[t].z), c, 0, 0, 0);
+        const float v = ((c[2] * 0.0625f + c[1]) * 0.0625f + c[0]) * s_unscale;      // small terms first
+        sc[t] = (g == 0 && kb + t * 16 + r < nk) ? v : -INFINITY;
+        mx = fmaxf(mx, sc[t]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) s_max[wave] = mx;
+    __syncthreads();
+    mx = s_max[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) mx = fmaxf(mx, s_max[w]);
+
+    const int slot = p.align_out ? p.align_slot[h] : -1;
+    const size_t rowi = slot >= 0 ? ((size_t)b * p.n_align + slot) * p.align_rows + p.pos[b] : 0;
+    float pk[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int k = kb + t * 16 + r;
+        pk[t] = (g == 0 && k < nk) ? expf(sc[t] - mx) : 0.f;
+        if (slot >= 0 && g == 0 && k < nk) p.align_out[rowi * p.n_keys + k_lo + k] = pk[t];   // un-normalised; align_normalize_kernel finishes the row
+    }
+    const float lsum = wave_sum(pk[0] + pk[1]);
+    // score fragment (key j in lane j) -> A fragment (lane (term, g): keys 8 g .. + 7): a wave-private LDS row
+    float* spw = s_p + wave * 32;
+    if (g == 0) { spw[r] = pk[0] * 256.f; spw[16 + r] = pk[1] * 256.f; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float pf[8];
+    {
+        const float4 p0 = *(const float4*)(spw + g * 8), p1 = *(const float4*)(spw + g * 8 + 4);
+        pf[0] = p0.x; pf[1] = p0.y; pf[2] = p0.z; pf[3] = p0.w; pf[4] = p1.x; pf[5] = p1.y; pf[6] = p1.z; pf[7] = p1.w;
+    }
+    const long ap = split3_e4m3(pf, r);
+    const unsigned vw[8] = {vf[0].x, vf[0].y, vf[0].z, vf[0].w, vf[1].x, vf[1].y, vf[1].z, vf[1].w};
+    float o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ap, (long)(((unsigned long)vw[2 * dt + 1] << 32) | vw[2 * dt]), c, 0, 0, 0);
+        o[dt] = (c[2] * 0.0625f + c[1]) * 0.0625f + c[0];
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) red[wave * 64 + dt * 16 + r] = o[dt];
+    }
+    if (lane == 0) red_l[wave] = lsum;
+    __syncthreads();
+    if (tid < 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) a += red[w * 64 + tid];
+        p.part_o[((size_t)sp * p.B + b) * D + h * 64 + tid] = a * (vs * (1.0f / 256.0f));
+    } else if (tid == 64) {
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) l += red_l[w];
+        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp) * 2;
+        ml[0] = mx; ml[1] = l;
+        if (slot >= 0) { p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l; }
+    }
+}
+
 int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > C8U * CROSS8_GROUPS || !p.kv_scale) return CW_ERR_INVALID;
+    if (p.n_keys < 1 || (ATT_NS - 1) * ((p.n_keys + ATT_NS - 1) / ATT_NS) >= p.n_keys) return CW_ERR_INVALID;   // a split without a key
+    if (cross8_mfma(p.n_keys)) {
+        hipLaunchKernelGGL(attn_cross_mfma8_kernel, dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+        return CW_OK;
+    }
     // two splits per block once the grid is several times what is resident (4 blocks of 512 threads per CU); A/B: CW_CROSS8_NSB=1|2
     const int force = cw_sw::cw_switches().cross8_nsb;
     const bool pair = ATT_NS % 2 == 0 && (force ? force == 2 : (size_t)p.H * p.B * ATT_NS >= 4096);

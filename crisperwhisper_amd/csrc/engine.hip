@@ -2011,8 +2011,9 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
         if (!c->bf16) return fail(c, CW_ERR_INVALID, "cross_kv_fp8 needs the bf16 engine (the f32 engine is the parity mode)");
         if (!c->dec[0].ck8) {
             const size_t n = (size_t)c->Bm * c->d.n_heads * CW_N_CTX * 64;
+            const size_t nv = (size_t)c->Bm * cw_bf16::cw_kv8_v_bytes(c->d.n_heads, CW_N_CTX);   // V: fragment-major for the fp8 matrix cores
             for (auto& L : c->dec) {
-                CWCHK(c, dmalloc(c, &L.ck8, n, false)); CWCHK(c, dmalloc(c, &L.cv8, n, false));
+                CWCHK(c, dmalloc(c, &L.ck8, n, false)); CWCHK(c, dmalloc(c, &L.cv8, nv, false));
                 CWCHK(c, dmalloc(c, &L.kvs, (size_t)c->Bm * c->d.n_heads * 2 * 4));
             }
         }
@@ -2071,7 +2072,9 @@ int32_t cw_has_experiments(void) {
 #endif
 }
 
+static int g_test_cross_fp8 = 0;   // cw_test_cross_attention through the e4m3 cache (option "cross_test_fp8")
 int32_t cw_test_set_option(const char* name, int32_t value) {
+    if (!strcmp(name, "cross_test_fp8")) { g_test_cross_fp8 = value; return CW_OK; }
     if (!strcmp(name, "gemm256_min_tiles")) { cw_bf16::cw_gemm_set_256_min_tiles(value); cw_f16::cw_gemm_set_256_min_tiles(value); return CW_OK; }
     if (!strcmp(name, "beam_topk_1block")) { cw_bf16::cw_beam_topk_set_1block(value); cw_f16::cw_beam_topk_set_1block(value); return CW_OK; }
     if (!strcmp(name, "gemm_pp")) { cw_bf16::cw_gemm_set_pp(value); cw_f16::cw_gemm_set_pp(value); return CW_OK; }
@@ -2345,14 +2348,25 @@ int32_t cw_test_cross_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, int3
     CrossSplitParams p{};
     p.q = dq; p.K = dk; p.V = dv; p.n_keys = S; p.part_o = dpo; p.part_ml = dml; p.align_out = dal; p.align_ml = daml;
     p.align_slot = dslot; p.pos = dpos; p.n_align = 1; p.align_rows = 1; p.B = B; p.H = H; p.kv_div = kv_div;
-    int r = KD(c, cw_launch_attn_cross_split, c->bf16, p, c->st);
+    // option "cross_test_fp8": the rows go through the e4m3 cache instead (quantiser + the fp8 cross-attention kernel)
+    void *dk8 = nullptr, *dv8 = nullptr; float* dkvs = nullptr;
+    const bool fp8 = g_test_cross_fp8 && c->bf16;
+    if (fp8) {
+        HIPCHK(c, hipMalloc(&dk8, nkv)); HIPCHK(c, hipMalloc(&dv8, (size_t)Bk * cw_bf16::cw_kv8_v_bytes(H, S)));
+        HIPCHK(c, hipMalloc((void**)&dkvs, (size_t)Bk * H * 2 * 4));
+        int rq = KD(c, cw_launch_kv_quant_fp8, dk, dv, dk8, dv8, dkvs, Bk, H, S, c->st);
+        if (rq != CW_OK) { hipFree(dk8); hipFree(dv8); hipFree(dkvs); return fail(c, rq, "test_cross_attention: quantiser rejected S=%d", S); }
+        p.K = dk8; p.V = dv8; p.kv_scale = dkvs;
+    }
+    auto launch = [&]() { return fp8 ? KD(c, cw_launch_attn_cross_split_fp8, p, c->st) : KD(c, cw_launch_attn_cross_split, c->bf16, p, c->st); };
+    int r = launch();
     if (r != CW_OK) fail(c, r, "test_cross_attention: launch rejected (B=%d H=%d S=%d kv_div=%d)", B, H, S, kv_div);
     if (r == CW_OK) { hipError_t er = hipStreamSynchronize(c->st); if (er != hipSuccess) r = fail(c, CW_ERR_HIP, "test_cross_attention: %s", hipGetErrorString(er)); }
     if (const int reps = cw_sw::cw_switches().test_attn_reps) {   // kernel A/B timing for the profiles (stderr only)
         hipEvent_t e0, e1;
         if (r == CW_OK && reps > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             hipEventRecord(e0, c->st);
-            for (int i = 0; i < reps && r == CW_OK; ++i) r = KD(c, cw_launch_attn_cross_split, c->bf16, p, c->st);
+            for (int i = 0; i < reps && r == CW_OK; ++i) r = launch();
             hipEventRecord(e1, c->st);
             hipEventSynchronize(e1);
             float ms = 0.f;
@@ -2367,6 +2381,7 @@ int32_t cw_test_cross_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, int3
                        hipMemcpy(align_ml, daml, (size_t)B * ATT_NS * 2 * 4, hipMemcpyDeviceToHost) != hipSuccess))
         r = fail(c, CW_ERR_HIP, "test_cross_attention copy");
     hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dpo); hipFree(dml); hipFree(dal); hipFree(daml); hipFree(dslot); hipFree(dpos);
+    if (dk8) hipFree(dk8); if (dv8) hipFree(dv8); if (dkvs) hipFree(dkvs);
     return r;
 }
 

@@ -271,6 +271,48 @@ def test_cross_attention_decode_kernels(engines, dt, tol, B, H, S, kv_div, path)
     assert np.abs(al - p[:, H - 1]).max() < tol, (dt, path, np.abs(al - p[:, H - 1]).max())
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("path", ["mfma8", "valu"])
+@pytest.mark.parametrize("B,H,S,kv_div", [(4, 2, 1500, 1), (10, 3, 1500, 5), (3, 2, 750, 1), (2, 2, 50, 1), (6, 1, 1499, 2)])
+def test_cross_attention_over_the_e4m3_cache(engines, dt, path, B, H, S, kv_div):
+    """Opt-in e4m3 cross-attention cache: quantiser (one scale per (item, head, K|V), amax / 448) + the cross-attention kernel
+    over it, against float64 softmax attention on the DEQUANTISED cache -- i.e. the kernels add nothing beyond the quantisation
+    they are specified to do.  mfma8: v_mfma_f32_16x16x32_fp8_fp8 with the query and the probabilities carried as three e4m3 terms
+    (12 significant bits: tolerance 2e-4 on outputs and alignment probabilities), V read in the fragment-major order the
+    quantiser writes; valu (CW_CROSS8_VALU=1 in the process, else skipped): conversions + f32 FMAs, f32 tolerance.  Column-
+    dependent V scale: a transposed or permuted V fragment cannot pass; S = 50: splits of 9 keys, seven waves without a key;
+    kv_div: beam rows sharing one cache."""
+    import os
+    from crisperwhisper_amd import _native
+    valu_proc = bool(os.environ.get("CW_CROSS8_VALU"))
+    if (path == "valu") != valu_proc:
+        pytest.skip("the e4m3 kernel / cache layout is chosen once per process (CW_CROSS8_VALU)")
+    rng = np.random.default_rng(B * 1000 + S + kv_div + 7)
+    q = (rng.standard_normal((B, H, 64)) * 0.35).astype(np.float32)
+    k = rng.standard_normal((B // kv_div, H, S, 64)).astype(np.float32)
+    v = rng.standard_normal((B // kv_div, H, S, 64)).astype(np.float32)
+    k[0, 0, S // 3] *= 4.0
+    v *= np.linspace(0.5, 2.0, 64, dtype=np.float32)
+    k, v = _round16(dt, k, v)
+    def deq(x):
+        s = (np.abs(x).max(axis=(2, 3), keepdims=True).astype(np.float32) / np.float32(448.0)).astype(np.float32)
+        inv = (np.float32(1.0) / s).astype(np.float32)
+        return _e4m3_round((x * inv).astype(np.float32)) * s.astype(np.float64)
+    kk = np.repeat(deq(k), kv_div, axis=0); vv = np.repeat(deq(v), kv_div, axis=0)
+    s = np.einsum("bhd,bhkd->bhk", q.astype(np.float64), kk)
+    pr = np.exp(s - s.max(-1, keepdims=True)); pr /= pr.sum(-1, keepdims=True)
+    ref = np.einsum("bhk,bhkd->bhd", pr, vv).reshape(B, H * 64)
+    lib = _native.load()
+    assert lib.cw_test_set_option(b"cross_test_fp8", 1) == 0
+    try:
+        got, al = engines[dt].test_cross_attention(q, k, v, kv_div=kv_div, align_head=H - 1)
+    finally:
+        lib.cw_test_set_option(b"cross_test_fp8", 0)
+    tol = 2e-4 if path == "mfma8" else 5e-6
+    assert rel_err(got, ref) < tol, (dt, path, rel_err(got, ref))
+    assert np.abs(al - pr[:, H - 1]).max() < tol, (dt, path, np.abs(al - pr[:, H - 1]).max())
+
+
 def test_cross_attention_rejects_key_counts_that_leave_a_split_empty(engines):
     """7 keys over 6 splits of ceil(7 / 6) = 2: splits 4 and 5 would own no key (the kernels clamp loads to the split's last key);
     the launcher refuses instead of reading in front of the cache."""
