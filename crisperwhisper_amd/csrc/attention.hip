@@ -1410,8 +1410,9 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define X8_SPLIT_BYTES 16384   // fragment-major V of one (batch, head, key split): 8 waves x 64 lanes x 4 dim tiles x 8 keys
 
 // vfrag: V is written in the order attn_cross_mfma8_kernel's B fragments read it -- per (batch, head, key split) X8_SPLIT_BYTES
-// bytes [wave 8][lane 64][dim tile 4][8 keys]: lane (j, g) of wave w holds, for dim 16 dt + j, keys 32 w + 8 g .. + 7 of the
-// split (zeros past the split's last key), so a wave's V operand is one contiguous 2 KB read and needs no transposition.
+// bytes [wave 8][half 2][lane 64][2 dim tiles][8 keys]: lane (j, g) of wave w holds, for dim 16 dt + j (dt = 2 half + 0 | 1),
+// keys 32 w + 8 g .. + 7 of the split (zeros past the split's last key), so a wave's V operand is two fully used contiguous
+// 1 KB reads (16 B per lane each) and needs no transposition.
 __global__ __launch_bounds__(512) void kv_quant_fp8_kernel(const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                            unsigned char* __restrict__ K8, unsigned char* __restrict__ V8,
                                                            float* __restrict__ kv_scale, int S, int vfrag) {
@@ -1436,7 +1437,7 @@ __global__ __launch_bounds__(512) void kv_quant_fp8_kernel(const bf16_t* __restr
         unsigned char* dstf = V8 + ((size_t)b * H + h) * (ATT_NS * X8_SPLIT_BYTES);
         const int per = (S + ATT_NS - 1) / ATT_NS;
         for (int u = threadIdx.x; u < ATT_NS * (X8_SPLIT_BYTES / 8); u += 512) {
-            const int dt = u & 3, ln = (u >> 2) & 63, w = (u >> 8) & 7, sp = u >> 11;
+            const int dt = ((u >> 7) & 1) * 2 + (u & 1), ln = (u >> 1) & 63, w = (u >> 8) & 7, sp = u >> 11;
             const int j = ln & 15, g = ln >> 4;
             const int nk = min(S, (sp + 1) * per) - sp * per;
             float v[8];
@@ -1648,29 +1649,41 @@ __device__ inline long split3_e4m3(const float* x, int term) {
     const uint2 sel = term == 0 ? t[0] : term == 1 ? t[1] : term == 2 ? t[2] : make_uint2(0u, 0u);
     return (long)(((unsigned long)sel.y << 32) | sel.x);
 }
+// NSB = key splits per block (grid (H, B, ATT_NS / NSB)): with thousands of blocks the launch is bound by the bytes a CU has in
+// flight; two adjacent splits per block double them (a wave owns 32 keys of each) under the same three barriers, and every
+// split is computed exactly as a block of its own would (bit-identical partials).
+template <int NSB>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSplitParams p) {
-    __shared__ float s_max[8];
-    __shared__ __attribute__((aligned(16))) float red[8 * 64];
-    __shared__ float red_l[8];
+    __shared__ float s_max[NSB * 8];
+    __shared__ __attribute__((aligned(16))) float red[NSB * 8 * 64];
+    __shared__ float red_l[NSB * 8];
     __shared__ __attribute__((aligned(16))) float s_p[8 * 32];
     __shared__ long s_aq[2 * 64];
     __shared__ float s_c1;
-    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+    const int h = blockIdx.x, b = blockIdx.y, sp0 = blockIdx.z * NSB;
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
-    const int k_lo = sp * per, nk = min(p.n_keys, k_lo + per) - k_lo;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kb = wave * 32;
     const int D = p.H * 64;
     const int bk = p.kv_div > 1 ? b / p.kv_div : b;
     const size_t bh = (size_t)bk * p.H + h;
-    const unsigned char* Kh = (const unsigned char*)p.K + (bh * p.n_keys + k_lo) * 64;
-    const unsigned char* Vf = (const unsigned char*)p.V + (bh * ATT_NS + sp) * X8_SPLIT_BYTES + (size_t)wave * 2048 + lane * 32;
     // every load of the block first
-    uint4 kf[2], vf[2];
+    int k_lo[NSB], nk[NSB];
+    uint4 kf[NSB][2], vf[NSB][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) kf[t] = *(const uint4*)(Kh + (size_t)min(kb + t * 16 + r, nk - 1) * 64 + g * 16);
-    vf[0] = *(const uint4*)Vf; vf[1] = *(const uint4*)(Vf + 16);
+    for (int s = 0; s < NSB; ++s) {
+        k_lo[s] = (sp0 + s) * per;
+        nk[s] = min(p.n_keys, k_lo[s] + per) - k_lo[s];
+        const unsigned char* Kh = (const unsigned char*)p.K + (bh * p.n_keys + k_lo[s]) * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) kf[s][t] = *(const uint4*)(Kh + (size_t)min(kb + t * 16 + r, nk[s] - 1) * 64 + g * 16);
+    }
+#pragma unroll
+    for (int s = 0; s < NSB; ++s) {
+        const unsigned char* Vf = (const unsigned char*)p.V + (bh * ATT_NS + sp0 + s) * X8_SPLIT_BYTES + (size_t)wave * 2048 + lane * 16;
+        vf[s][0] = *(const uint4*)Vf; vf[s][1] = *(const uint4*)(Vf + 1024);
+    }
     const float ks = p.kv_scale[bh * 2], vs = p.kv_scale[bh * 2 + 1];
     // the query fragments are the same for all eight waves: wave 0 loads the row (16 B-per-lane loads cost the CU's address
     // unit 16 clocks each whatever they fetch), scales it to the e4m3 range and splits it; the others pick the 16 bytes up from
@@ -1695,73 +1708,86 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
     }
     __syncthreads();
     const long aq0 = s_aq[lane], aq1 = s_aq[64 + lane];
-    const float c1 = s_c1;
-    const float s_unscale = ks / c1;
-    float sc[2], mx = -INFINITY;
+    const float s_unscale = ks / s_c1;
+    float sc[NSB][2], mx[NSB];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq0, (long)(((unsigned long)kf[t].y << 32) | kf[t].x), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq1, (long)(((unsigned long)kf[t].w << 32) | kf[t].z), c, 0, 0, 0);
-        const float v = ((c[2] * 0.0625f + c[1]) * 0.0625f + c[0]) * s_unscale;      // small terms first
-        sc[t] = (g == 0 && kb + t * 16 + r < nk) ? v : -INFINITY;
-        mx = fmaxf(mx, sc[t]);
+    for (int s = 0; s < NSB; ++s) {
+        mx[s] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq0, (long)(((unsigned long)kf[s][t].y << 32) | kf[s][t].x), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq1, (long)(((unsigned long)kf[s][t].w << 32) | kf[s][t].z), c, 0, 0, 0);
+            const float v = ((c[2] * 0.0625f + c[1]) * 0.0625f + c[0]) * s_unscale;      // small terms first
+            sc[s][t] = (g == 0 && kb + t * 16 + r < nk[s]) ? v : -INFINITY;
+            mx[s] = fmaxf(mx[s], sc[s][t]);
+        }
+        mx[s] = wave_max(mx[s]);
+        if (lane == 0) s_max[s * 8 + wave] = mx[s];
     }
-    mx = wave_max(mx);
-    if (lane == 0) s_max[wave] = mx;
     __syncthreads();
-    mx = s_max[0];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) mx = fmaxf(mx, s_max[w]);
+    for (int s = 0; s < NSB; ++s) {
+        float m = s_max[s * 8];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, s_max[s * 8 + w]);
+        mx[s] = m;
+    }
 
     const int slot = p.align_out ? p.align_slot[h] : -1;
     const size_t rowi = slot >= 0 ? ((size_t)b * p.n_align + slot) * p.align_rows + p.pos[b] : 0;
-    float pk[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int k = kb + t * 16 + r;
-        pk[t] = (g == 0 && k < nk) ? expf(sc[t] - mx) : 0.f;
-        if (slot >= 0 && g == 0 && k < nk) p.align_out[rowi * p.n_keys + k_lo + k] = pk[t];   // un-normalised; align_normalize_kernel finishes the row
-    }
-    const float lsum = wave_sum(pk[0] + pk[1]);
-    // score fragment (key j in lane j) -> A fragment (lane (term, g): keys 8 g .. + 7): a wave-private LDS row
     float* spw = s_p + wave * 32;
-    if (g == 0) { spw[r] = pk[0] * 256.f; spw[16 + r] = pk[1] * 256.f; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float pf[8];
-    {
-        const float4 p0 = *(const float4*)(spw + g * 8), p1 = *(const float4*)(spw + g * 8 + 4);
-        pf[0] = p0.x; pf[1] = p0.y; pf[2] = p0.z; pf[3] = p0.w; pf[4] = p1.x; pf[5] = p1.y; pf[6] = p1.z; pf[7] = p1.w;
-    }
-    const long ap = split3_e4m3(pf, r);
-    const unsigned vw[8] = {vf[0].x, vf[0].y, vf[0].z, vf[0].w, vf[1].x, vf[1].y, vf[1].z, vf[1].w};
-    float o[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ap, (long)(((unsigned long)vw[2 * dt + 1] << 32) | vw[2 * dt]), c, 0, 0, 0);
-        o[dt] = (c[2] * 0.0625f + c[1]) * 0.0625f + c[0];
-    }
-    if (g == 0) {
+    for (int s = 0; s < NSB; ++s) {
+        float pk[2];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) red[wave * 64 + dt * 16 + r] = o[dt];
+        for (int t = 0; t < 2; ++t) {
+            const int k = kb + t * 16 + r;
+            pk[t] = (g == 0 && k < nk[s]) ? expf(sc[s][t] - mx[s]) : 0.f;
+            if (slot >= 0 && g == 0 && k < nk[s]) p.align_out[rowi * p.n_keys + k_lo[s] + k] = pk[t];   // un-normalised; align_normalize_kernel finishes the row
+        }
+        const float lsum = wave_sum(pk[0] + pk[1]);
+        // score fragment (key j in lane j) -> A fragment (lane (term, g): keys 8 g .. + 7): a wave-private LDS row
+        if (s > 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // the previous split's reads are done
+        if (g == 0) { spw[r] = pk[0] * 256.f; spw[16 + r] = pk[1] * 256.f; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float pf[8];
+        {
+            const float4 p0 = *(const float4*)(spw + g * 8), p1 = *(const float4*)(spw + g * 8 + 4);
+            pf[0] = p0.x; pf[1] = p0.y; pf[2] = p0.z; pf[3] = p0.w; pf[4] = p1.x; pf[5] = p1.y; pf[6] = p1.z; pf[7] = p1.w;
+        }
+        const long ap = split3_e4m3(pf, r);
+        const unsigned vw[8] = {vf[s][0].x, vf[s][0].y, vf[s][0].z, vf[s][0].w, vf[s][1].x, vf[s][1].y, vf[s][1].z, vf[s][1].w};
+        float o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ap, (long)(((unsigned long)vw[2 * dt + 1] << 32) | vw[2 * dt]), c, 0, 0, 0);
+            o[dt] = (c[2] * 0.0625f + c[1]) * 0.0625f + c[0];
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) red[(s * 8 + wave) * 64 + dt * 16 + r] = o[dt];
+        }
+        if (lane == 0) red_l[s * 8 + wave] = lsum;
     }
-    if (lane == 0) red_l[wave] = lsum;
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 64 * NSB) {
+        const int s = tid >> 6, c = tid & 63;
         float a = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) a += red[w * 64 + tid];
-        p.part_o[((size_t)sp * p.B + b) * D + h * 64 + tid] = a * (vs * (1.0f / 256.0f));
-    } else if (tid == 64) {
-        float l = 0.f;
+        for (int w = 0; w < 8; ++w) a += red[(s * 8 + w) * 64 + c];
+        p.part_o[((size_t)(sp0 + s) * p.B + b) * D + h * 64 + c] = a * (vs * (1.0f / 256.0f));
+    } else if (tid < 64 * NSB + NSB) {
+        const int s = tid - 64 * NSB;
+        float l = 0.f, m = s_max[s * 8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) l += red_l[w];
-        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp) * 2;
-        ml[0] = mx; ml[1] = l;
-        if (slot >= 0) { p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l; }
+        for (int w = 0; w < 8; ++w) { l += red_l[s * 8 + w]; m = fmaxf(m, s_max[s * 8 + w]); }
+        float* ml = p.part_ml + (((size_t)b * p.H + h) * ATT_NS + sp0 + s) * 2;
+        ml[0] = m; ml[1] = l;
+        if (slot >= 0) { p.align_ml[(rowi * ATT_NS + sp0 + s) * 2] = m; p.align_ml[(rowi * ATT_NS + sp0 + s) * 2 + 1] = l; }
     }
 }
 
@@ -1769,7 +1795,11 @@ int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > C8U * CROSS8_GROUPS || !p.kv_scale) return CW_ERR_INVALID;
     if (p.n_keys < 1 || (ATT_NS - 1) * ((p.n_keys + ATT_NS - 1) / ATT_NS) >= p.n_keys) return CW_ERR_INVALID;   // a split without a key
     if (cross8_mfma(p.n_keys)) {
-        hipLaunchKernelGGL(attn_cross_mfma8_kernel, dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+        // CW_CROSS8_NSB=2 (A/B): two splits per block -- twice the bytes in flight per CU, measured equal (the memory system is the bound)
+        const int f = cw_sw::cw_switches().cross8_nsb;
+        if (ATT_NS % 2 == 0 && f == 2)
+            hipLaunchKernelGGL(attn_cross_mfma8_kernel<2>, dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
+        else hipLaunchKernelGGL(attn_cross_mfma8_kernel<1>, dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
         return CW_OK;
     }
     // two splits per block once the grid is several times what is resident (4 blocks of 512 threads per CU); A/B: CW_CROSS8_NSB=1|2
