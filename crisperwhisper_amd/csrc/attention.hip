@@ -1434,23 +1434,37 @@ __global__ __launch_bounds__(512) void kv_quant_fp8_kernel(const bf16_t* __restr
     const float inv = 1.0f / scale;
     if (threadIdx.x == 0) kv_scale[((size_t)b * H + h) * 2 + which] = scale;
     if (which == 1 && vfrag) {
+        // per key split: the rows are quantised from coalesced 16-byte reads and their bytes scattered into a transposed LDS
+        // image [dim 64][key 256 (+8)], from which every 8-byte unit of the fragment order is one aligned LDS read
+        __shared__ __attribute__((aligned(8))) unsigned char tr[64 * 264];
         unsigned char* dstf = V8 + ((size_t)b * H + h) * (ATT_NS * X8_SPLIT_BYTES);
         const int per = (S + ATT_NS - 1) / ATT_NS;
-        for (int u = threadIdx.x; u < ATT_NS * (X8_SPLIT_BYTES / 8); u += 512) {
-            const int dt = ((u >> 7) & 1) * 2 + (u & 1), ln = (u >> 1) & 63, w = (u >> 8) & 7, sp = u >> 11;
-            const int j = ln & 15, g = ln >> 4;
-            const int nk = min(S, (sp + 1) * per) - sp * per;
-            float v[8];
+        for (int sp = 0; sp < ATT_NS; ++sp) {
+            const int k0 = sp * per, nk = min(S, k0 + per) - k0;
+            __syncthreads();                                      // the previous split's image has been read
+            for (int i = threadIdx.x; i < 256 * 8; i += 512) {
+                const int k = i >> 3, o = i & 7;
+                unsigned lo = 0u, hi = 0u;                        // zeros behind the split's last key
+                if (k < nk) {
+                    float v[8];
+                    Row8<bf16_t>::ld(src + (size_t)(k0 + k) * 64 + o * 8, v);
+                    int t = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
+                    lo = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, t, true);
+                    t = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, 0, false);
+                    hi = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, t, true);
+                }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int ks = 32 * w + 8 * g + r;
-                v[r] = ks < nk ? bf16_to_f32(src[(size_t)(sp * per + ks) * 64 + 16 * dt + j]) * inv : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    tr[(8 * o + e) * 264 + k] = (unsigned char)(lo >> (8 * e));
+                    tr[(8 * o + 4 + e) * 264 + k] = (unsigned char)(hi >> (8 * e));
+                }
             }
-            int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
-            int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
-            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
-            *(uint2*)(dstf + (size_t)u * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+            __syncthreads();
+            for (int u = threadIdx.x; u < X8_SPLIT_BYTES / 8; u += 512) {
+                const int dt = ((u >> 7) & 1) * 2 + (u & 1), ln = (u >> 1) & 63, w = (u >> 8) & 7;
+                const int j = ln & 15, g = ln >> 4;
+                *(uint2*)(dstf + ((size_t)sp * (X8_SPLIT_BYTES / 8) + u) * 8) = *(const uint2*)&tr[(16 * dt + j) * 264 + 32 * w + 8 * g];
+            }
         }
         return;
     }
