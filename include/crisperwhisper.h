@@ -71,7 +71,8 @@ int32_t cw_check_weights(cw_ctx* ctx);
 int32_t cw_set_generation(cw_ctx* ctx, const cw_gen_cfg* cfg);
 /* Context options (before cw_encode).  "cross_kv_fp8" = 1: the cross-attention K/V cache is additionally stored in OCP
  * e4m3 with one scale per (chunk, head, K|V) and the decode step streams that copy (half the bytes of the dominant
- * stream; bf16 engine only; an accuracy-gated performance mode, BASELINE configs[3], not the parity path).
+ * stream; 16-bit engines only; an accuracy-gated performance mode, BASELINE configs[3], not the parity path).  The copy is
+ * read by v_mfma_f32_16x16x32_fp8_fp8 (K row-major, V in the fragment order of the B operand; csrc/attention.hip).
  * "encoder_gemm_fp8" = 1 (after the weights are loaded; 16-bit engines): e4m3 copies of the encoder's qkv / fc1 / fc2 and the
  * decoder's cross-K/V weights are made with one scale per output row, the LayerNorms in front of those GEMMs emit e4m3 rows with
  * one scale per row, and the GEMMs run on v_mfma_scale_f32_16x16x128_f8f6f4 -- the fp8 MFMA half of BASELINE configs[3];
