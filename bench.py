@@ -462,7 +462,7 @@ def main():
     # roofline of the decode-step kernels, HIP events on the engine's own stream
     roof = {}
     for which, kname in ((0, "gemv2_bf16_kernel<EPI_GELU_F32> (decoder fc1 + fused LayerNorm)"),
-                         (1, ("attn_cross_split_fp8_kernel (cross-attention over the e4m3 cache, 1500 frames, 6-way key split)" if a.cross_kv == "fp8" else
+                         (1, ("attn_cross_mfma8_kernel (cross-attention over the e4m3 cache on v_mfma_f32_16x16x32_fp8_fp8, 1500 frames, 6-way key split)" if a.cross_kv == "fp8" else
                               "attn_cross_split_kernel<bf16> (cross-attention, 1500 frames, 6-way key split; finishes the fused query)"))):
         ms, by = eng.time_kernel(which, B, a.kernel_iters)
         roof[which] = {"kernel": kname, "avg_ms": ms, "algo_bytes": by, "achieved": by / (ms * 1e-3) / 1e9}
@@ -502,7 +502,7 @@ def main():
             "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1) / C, 3) for k, val in stages.items()},
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
                          "frac": r["achieved"] / 8000.0,
-                         "traffic": pmc_traffic(("attn_cross_split_fp8" if a.cross_kv == "fp8" else "attn_cross_split_kernel") if dom == 1 else "gemv2_bf16_kernelILi7"),
+                         "traffic": pmc_traffic(("attn_cross_mfma8" if a.cross_kv == "fp8" else "attn_cross_split_kernel") if dom == 1 else "gemv2_bf16_kernelILi7"),
                          "traffic_source": f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction), not re-measured in this run",
                          "kernel": r["kernel"],
                          "avg_launch_ms": r["avg_ms"], "algorithmic_bytes_per_launch": r["algo_bytes"]},
