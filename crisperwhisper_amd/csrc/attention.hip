@@ -1388,6 +1388,12 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
         else hipLaunchKernelGGL((attn_cross_mfma_kernel<true>), grid, dim3(CROSS_THREADS), 0, st, p, p.kv_div);
         return CW_OK;
     }
+    // A/B (CW_CROSS_MFMA1=1): rows that share nothing (greedy, 17..64 rows) through the matrix-core kernel as well, one row per block
+    if (bf16 && p.kv_div <= 1 && cw_sw::cw_switches().cross_mfma1 && (p.n_keys + ATT_NS - 1) / ATT_NS <= 256) {
+        CrossSplitParams p1 = p; p1.kv_div = 1;
+        hipLaunchKernelGGL((attn_cross_mfma_kernel<true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p1, 1);
+        return CW_OK;
+    }
     const int nq = (p.kv_div > 1 && p.kv_div <= 6 && p.B % p.kv_div == 0 && !per_row) ? p.kv_div : 1;
     switch (nq) {
         case 2: launch_cross_split<2>(bf16, p, st); break;

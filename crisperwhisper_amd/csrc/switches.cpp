@@ -32,6 +32,7 @@ Switches read_switches() {
     s.cross_valu = flag("CW_CROSS_VALU");
     s.cross_no_tr = flag("CW_CROSS_NO_TR");
     s.cross8_valu = flag("CW_CROSS8_VALU");
+    s.cross_mfma1 = flag("CW_CROSS_MFMA1");
     s.cross_lds_pad = num("CW_CROSS_LDS_PAD", 0);
     s.cross8_nsb = num("CW_CROSS8_NSB", 0);
     s.no_glds = flag("CW_NO_GLDS");
