@@ -25,38 +25,63 @@ __device__ inline unsigned int xcc_id() { return __builtin_amdgcn_s_getreg(20 | 
 
 __device__ inline unsigned int ld_relaxed(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+template <int FENCES = 1>
 __device__ void barrier_flat(Bar* b, unsigned int gen, unsigned int nblocks) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __atomic_thread_fence(__ATOMIC_RELEASE);   // agent scope by default for device code
+        if (FENCES) __atomic_thread_fence(__ATOMIC_RELEASE);   // agent scope by default for device code
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int t = __hip_atomic_fetch_add(&b->flat_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == nblocks - 1) {
             __hip_atomic_store(&b->flat_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&b->flat_gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (FENCES) __hip_atomic_store(&b->flat_gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_store(&b->flat_gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             while (ld_relaxed(&b->flat_gen) != gen) __builtin_amdgcn_s_sleep(1);
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (FENCES) __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
 }
 
+template <int FENCES = 1>
 __device__ void barrier_xcd(Bar* b, unsigned int gen, unsigned int x, unsigned int members, unsigned int n_xcc) {
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (!FENCES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int t = __hip_atomic_fetch_add(&b->xcc_cnt[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == members - 1) {                                  // XCC leader: last arriver of this XCC
             __hip_atomic_store(&b->xcc_cnt[x][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __atomic_thread_fence(__ATOMIC_RELEASE);
+            if (FENCES) __atomic_thread_fence(__ATOMIC_RELEASE);
             const unsigned int u = __hip_atomic_fetch_add(&b->top_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (u == n_xcc - 1) {
                 __hip_atomic_store(&b->top_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                for (unsigned int k = 0; k < n_xcc; ++k) __hip_atomic_store(&b->xcc_gen[k][0], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (FENCES) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                for (unsigned int k = 0; k < n_xcc; ++k) __hip_atomic_store(&b->xcc_gen[k][0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         while (ld_relaxed(&b->xcc_gen[x][0]) != gen) __builtin_amdgcn_s_sleep(1);
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (FENCES) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+}
+
+// XCC-local: only the blocks that share one L2 meet (per-XCC counter + generation word, nothing chip-wide).  FENCES = 1: agent-scope
+// release / acquire fences around it (L2 write-back + invalidate, what a chip-wide hand-off needs); FENCES = 0: none -- the payload
+// travels in sc1 stores / loads that are performed at the shared L2 anyway, the wave only waits for its own stores to complete.
+template <int FENCES>
+__device__ void barrier_local(Bar* b, unsigned int gen, unsigned int x, unsigned int members) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (FENCES) __atomic_thread_fence(__ATOMIC_RELEASE); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(&b->xcc_cnt[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == members - 1) {
+            __hip_atomic_store(&b->xcc_cnt[x][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&b->xcc_gen[x][0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (ld_relaxed(&b->xcc_gen[x][0]) != gen) __builtin_amdgcn_s_sleep(1);
+        }
+        if (FENCES) __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
 }
@@ -75,14 +100,14 @@ __global__ __launch_bounds__(256) void bench_kernel(Bar* b, unsigned int gen0, i
     for (int it = 0; it < iters; ++it) {
         const unsigned int gen = gen0 + it + 1;
         if (PAYLOAD && threadIdx.x < 32) __hip_atomic_store(records + (size_t)me * 32 + threadIdx.x, gen * 1000u + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (KIND == 0) barrier_flat(b, gen, nb); else barrier_xcd(b, gen, x, members, n_xcc);
+        if (KIND == 0) barrier_flat(b, gen, nb); else if (KIND == 1) barrier_xcd(b, gen, x, members, n_xcc); else if (KIND == 4) barrier_flat<0>(b, gen, nb); else if (KIND == 5) barrier_xcd<0>(b, gen, x, members, n_xcc); else barrier_local<KIND == 2>(b, gen, x, members);
         if (PAYLOAD && threadIdx.x < 32) {
-            const unsigned int nbr = (me + 1) % nb;
+            const unsigned int nbr = (KIND == 2 || KIND == 3) ? (me + 8) % nb : (me + 1) % nb;   // XCC-local: a block of the same XCC (blocks are dealt round-robin)
             const unsigned int v = __hip_atomic_load(records + (size_t)nbr * 32 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v != gen * 1000u + nbr) ++bad;
         }
         if (PAYLOAD) {                                            // nobody overwrites a record before its reader has it
-            if (KIND == 0) barrier_flat(b, gen + 1000000u, nb); else barrier_xcd(b, gen + 1000000u, x, members, n_xcc);
+            if (KIND == 0) barrier_flat(b, gen + 1000000u, nb); else if (KIND == 1) barrier_xcd(b, gen + 1000000u, x, members, n_xcc); else if (KIND == 4) barrier_flat<0>(b, gen + 1000000u, nb); else if (KIND == 5) barrier_xcd<0>(b, gen + 1000000u, x, members, n_xcc); else barrier_local<KIND == 2>(b, gen + 1000000u, x, members);
         }
     }
     if (bad) atomicAdd(errors, bad);
@@ -123,6 +148,16 @@ int main() {
         const double f1 = run<0, 1>(d_bar, blocks, iters, rec, err, gen), x1 = run<1, 1>(d_bar, blocks, iters, rec, err, gen);
         unsigned int e = 0; CHECK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));
         printf("  us per barrier: flat %.2f  xcd %.2f | with a 128-byte record per block (write, barrier, read neighbour): flat %.2f  xcd %.2f | record errors %u\n", f0, x0, f1, x1, e);
+        CHECK(hipMemset(err, 0, 4));
+        const double l2 = run<2, 0>(d_bar, blocks, iters, rec, err, gen), l3 = run<3, 0>(d_bar, blocks, iters, rec, err, gen);
+        const double l2p = run<2, 1>(d_bar, blocks, iters, rec, err, gen), l3p = run<3, 1>(d_bar, blocks, iters, rec, err, gen);
+        CHECK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemset(err, 0, 4));
+        const double f4 = run<4, 0>(d_bar, blocks, iters, rec, err, gen), x5 = run<5, 0>(d_bar, blocks, iters, rec, err, gen);
+        const double f4p = run<4, 1>(d_bar, blocks, iters, rec, err, gen), x5p = run<5, 1>(d_bar, blocks, iters, rec, err, gen);
+        unsigned int e2 = 0; CHECK(hipMemcpy(&e2, err, 4, hipMemcpyDeviceToHost));
+        printf("  chip-wide WITHOUT fences (payload in sc1 stores / loads): flat %.2f  xcd %.2f | with record: flat %.2f  xcd %.2f | record errors %u\n", f4, x5, f4p, x5p, e2);
+        printf("  XCC-local (eight independent groups): agent fences %.2f  no fences %.2f | with record: agent fences %.2f  no fences %.2f | record errors %u\n", l2, l3, l2p, l3p, e);
     }
     return 0;
 }
