@@ -688,7 +688,9 @@ __global__ __launch_bounds__(256) void mlp_pair_kernel(MlpPairParams p) {
         s_ok = ok;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // no acquire fence: the slice is read with sc1 loads below, which are coherent at the memory side on their own; an agent-scope
+    // acquire here is an L2 invalidate (round 4, profiles/r04_grid_barrier.txt: the fences are 3 of a barrier's 5 us)
+    if (p.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // ---- fc2: the group's mid slice [Mb][D] -> LDS (agent-scope loads: written by blocks on other XCDs)
     {
         const unsigned long long* src = (const unsigned long long*)mid;

@@ -84,6 +84,7 @@ struct cw_ctx {
     float* d_rstats = nullptr;      // [max(D, F) / 16][64][2] per-block LayerNorm partial sums of the 17..64-row producers
     bool fuse6_enabled = true;      // CW_NO_FUSE6=1: eight launches per layer (A/B)
     bool fuse_mlp = false;          // CW_FUSE_MLP=1: also fuse cross out-projection + fc1 (six launches; measured slower, A/B)
+    bool mlp_pair_fence = false;    // CW_MLP_PAIR_FENCE=1: round-3 hand-over (agent-scope acquire fence behind the group barrier)
     bool mlp_pair = false;          // CW_MLP_PAIR=1: fc1 + fc2 in one launch with an in-kernel group barrier (A/B: 23 us against 12.8 for two launches)
     unsigned int* d_bar = nullptr; int* d_err = nullptr;   // group barriers of mlp_pair_kernel; "a block gave up waiting" flag
     int stack_nt3 = 0, stack_nt5 = 0;   // column tiles per block of the two stacked GEMVs (0 = launcher's choice; CW_STACK_NT3/5)
@@ -359,6 +360,7 @@ static int create_impl(cw_ctx* c) {
     c->fuse_mlp = sw.fuse_mlp;
     c->wpack_enabled = !sw.no_wpack;
     c->mlp_pair = sw.mlp_pair;
+    c->mlp_pair_fence = sw.mlp_pair_fence;
     c->stack_nt3 = sw.stack_nt3;
     c->stack_nt5 = sw.stack_nt5;
     c->prefetch = sw.prefetch;   // experiments builds only (refused above otherwise)
@@ -1157,7 +1159,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 }
                 if (c->mlp_pair && F % D == 0 && D % 32 == 0 && F / 32 <= 256 && F / D <= 32) {
                     // LN + fc1 + GELU, group barrier, fc2 + residual in one launch (decfuse.hip: mlp_pair_kernel)
-                    MlpPairParams mp{xalt, L.w1, L.b1, L.w2, L.b2, c->d_xfrag2, c->d_bar, c->d_err, nb, D, F, c->wpacked ? 1 : 0};
+                    MlpPairParams mp{xalt, L.w1, L.b1, L.w2, L.b2, c->d_xfrag2, c->d_bar, c->d_err, nb, D, F, c->wpacked ? 1 : 0, c->mlp_pair_fence ? 1 : 0};
                     CWCHK(c, KD(c, cw_launch_mlp_pair, mp, c->st));
                 } else {
                     // fc1 writes gelu(.) in the 16-bit type fc2 would round it to anyway (bit-identical): fc2's activation load halves

@@ -20,6 +20,7 @@ Switches read_switches() {
     s.fuse_mlp = flag("CW_FUSE_MLP");
     s.no_wpack = flag("CW_NO_WPACK");
     s.mlp_pair = flag("CW_MLP_PAIR");
+    s.mlp_pair_fence = flag("CW_MLP_PAIR_FENCE");
     s.skinny = num("CW_SKINNY", 0);
     s.prefetch = num("CW_PREFETCH", 0);
     s.prefetch_wide = num("CW_PREFETCH_WIDE", 0);
