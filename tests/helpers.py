@@ -155,3 +155,24 @@ def has_experiments() -> bool:
     switches") and the differential tests that hold them correct are available."""
     from crisperwhisper_amd import _native
     return bool(_native.load().cw_has_experiments())
+
+
+def e4m3_round(x):
+    """round-to-nearest-even onto the OCP e4m3 grid (|x| <= 448 saturating), numpy float64 in / out"""
+    x = np.asarray(x, np.float64)
+    a = np.abs(x)
+    e = np.floor(np.log2(np.maximum(a, 2.0 ** -9)))
+    e = np.maximum(e, -6.0)                                   # subnormals share the exponent of 2^-6
+    q = 2.0 ** (e - 3)
+    return np.sign(x) * np.minimum(np.round(a / q) * q, 448.0)
+
+
+def e4m3_split3(x):
+    """The three-term operand split of csrc/attention.hip: split3_e4m3 (x = t0 + t1 / 16 + t2 / 256, residuals in f32)."""
+    x = np.asarray(x, np.float32).astype(np.float64)
+    t0 = e4m3_round(x)
+    r1 = np.float32((x - t0) * 16.0).astype(np.float64)
+    t1 = e4m3_round(r1)
+    r2 = np.float32((r1 - t1) * 16.0).astype(np.float64)
+    t2 = e4m3_round(r2)
+    return t0, t1, t2

@@ -77,14 +77,7 @@ def test_gemm_256_tile_kernel(engines, M, N, K):
         eng.lib.cw_test_set_option(b"gemm256_min_tiles", 200)
 
 
-def _e4m3_round(x):
-    """round-to-nearest-even onto the OCP e4m3 grid (|x| <= 448), numpy"""
-    x = np.asarray(x, np.float64)
-    a = np.abs(x)
-    e = np.floor(np.log2(np.maximum(a, 2.0 ** -9)))
-    e = np.maximum(e, -6.0)                                   # subnormals share the exponent of 2^-6
-    q = 2.0 ** (e - 3)
-    return np.sign(x) * np.minimum(np.round(a / q) * q, 448.0)
+_e4m3_round = Hh.e4m3_round
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 512, 256), (777, 256, 1280), (1500, 768, 5120)])
