@@ -1,0 +1,406 @@
+// Persistent decoder-layer kernel of the 16-bit engine, batch rows <= 8 (TF modeling_whisper.py:448-505, the decoder layer's
+// forward): ONE 1024-thread workgroup per CU walks the dependent stages of a layer inside one launch.
+//
+// Why: a decoder layer at 8 rows is a chain of 7 all-to-all dependent stages that move 118 MB; as 7 launches
+// it takes 44 us against 18.7 us of streaming, because every launch starts its HBM streams only after its predecessor has
+// drained.  The one stream that is worth a layer's time -- the 61.5 MB of cross-attention K/V -- depends on NOTHING the layer
+// computes.  Here every CU requests its share of it (up to four (row, head, key split) items = 256 KB, held in the registers of
+// 16 waves: 64 VGPRs of payload per lane) at kernel entry, and the latency-bound chain in front of the cross-attention -- the
+// fused out-projection / cross-query stage of decfuse.hip -- runs underneath that stream on four "chain" waves whose own memory
+// queue stays short: their weights arrive by LDS-DMA (no payload registers), they hand their results to the other CUs as 8-byte
+// {tag, value} granules (one write-through store each: data and arrival flag travel together, no fence, no barrier, no separate
+// flag -- MI355X_MICROARCH.md, rows handoff-1to1 / allgather), and they poll for theirs.
+//
+// Arithmetic = gemv_stack_kernel<2, NSLOT, PER_LANE, 1> (decfuse.hip) followed by attn_cross_split_kernel<T, 1, true>
+// (attention.hip), operation for operation: same roundings, same summation orders, same key ownership per lane -- the two paths
+// are held BIT-IDENTICAL by tests/test_gpu_e2e.py::test_persistent_decoder_layer_is_bit_identical.
+//
+// Hand-off state: granule buffers live in HBM and are never cleared; a granule is valid when its tag equals
+// (epoch << 6 | layer), epoch = a device counter that set_pos_kernel / sample_kernel bump once per decoder forward (so it
+// survives graph replay: no per-launch argument changes).  Every spin is bounded and reports through `err`.
+#include "common.h"
+#include "kernels.h"
+#include <mutex>
+
+namespace CW_NS {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int dl_u32x4_t;
+typedef unsigned long long dl_u64_t;
+
+#define DL_THREADS 1024
+#define DL_SPIN_LIMIT (1 << 17)
+
+__device__ static inline void dl_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// workgroup barrier WITHOUT the workgroup-scope fence of __syncthreads(): that fence drains vmcnt, and twelve of the sixteen
+// waves carry 16 K/V loads each across every barrier of the chain.  LDS traffic is ordered by lgkmcnt alone.
+__device__ static inline void dl_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ static inline void dl_gran_st(dl_u64_t* g, unsigned tag, unsigned v) {
+    __hip_atomic_store(g, ((dl_u64_t)tag << 32) | (dl_u64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ static inline dl_u64_t dl_gran_ld(const dl_u64_t* g) {
+    return __hip_atomic_load((dl_u64_t*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ static inline float dl_row_ror8_add(float v) { return v + dpp_mov<0x128, 0xf>(0.f, v); }
+
+struct DlRaw8 {   // 8 consecutive 16-bit elements held raw so that the load is issued long before its use (attention.hip: Raw8)
+    uint4 a;
+    __device__ inline void ld(const bf16_t* p) {
+        const dl_u32x4_t t = CW_STREAM_LD((const dl_u32x4_t*)p);
+        a = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    __device__ inline void cvt(float* o) const { h16_unpack8(a, o); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// stage A: [W'q_c ; W'q_c Wo ; Wo] tile (chain waves) -> granules -> cross-attention items (all waves)
+// ---------------------------------------------------------------------------------------------------
+template <int NSLOT, int PER_LANE>
+__global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int K = p.D, Mb = p.Mb, H = p.H;
+    const int TD = K >> 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..15
+    const int grp = wave >> 3, gw = wave & 7, gt = tid & 511;       // 8-wave group = one attn_cross_split block
+    const bool chain = wave < 4;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int cu = blockIdx.x, G = gridDim.x;
+    const unsigned tag = (p.epoch[0] << 6) | (unsigned)p.layer;
+
+    // ---- LDS carve (one workgroup per CU: 160 KB are ours)
+    unsigned char* wS = dsm;                                         // [K/32][64 lanes][16 B] weight tile, fragment-major
+    float* xraw = (float*)(wS + (size_t)K * 32);                     // [8][K] f32 rows as they lie in HBM (+ pad to 1 KB)
+    const size_t xraw_bytes = (((size_t)8 * K * 4) + 1023) & ~(size_t)1023;
+    const int xs_stride = K + 8;
+    bf16_t* xs = (bf16_t*)((unsigned char*)xraw + xraw_bytes);       // [16][K+8]
+    float* red = (float*)((unsigned char*)xs + (size_t)16 * xs_stride * 2);   // [4 waves][4][64]
+    float* smean = red + 4 * 4 * 64;                                 // [16]
+    float* c_smax = smean + 16;                                      // [4 items][8 waves]
+    float* c_redl = c_smax + 32;                                     // [4][8]
+    float* c_q = c_redl + 32;                                        // [4][64] finished queries
+    float* c_red = c_q + 4 * 64;                                     // [4][8][64]
+
+    // ---- work of this CU: cross-attention items cu, cu + G, cu + 2G, cu + 3G (group 0: the first two); one tile, dealt from
+    // the END of the grid because the last CUs hold one item less
+    const int n_items = Mb * H * ATT_NS;
+    const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
+    int ib[2], ih[2], isp[2], ink[2], iklo[2];
+    bool iv[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int it = cu + G * (2 * grp + s);
+        iv[s] = it < n_items;
+        const int itc = iv[s] ? it : 0;
+        ih[s] = itc % H; ib[s] = (itc / H) % Mb; isp[s] = itc / (H * Mb);   // = blockIdx (x, y, z) of attn_cross_split_kernel
+        iklo[s] = isp[s] * per;
+        ink[s] = min(p.n_keys, iklo[s] + per) - iklo[s];
+    }
+    const int n_tiles = 3 * TD;
+    const int my_tile = G - 1 - cu;
+    const bool has_tile = my_tile < n_tiles;
+    const int si = has_tile ? my_tile / TD : 0;                      // segment: 0 qa = W'q x, 1 qb = (W'q Wo) a, 2 x1 = x + Wo a + bo
+    const int tl = has_tile ? my_tile - si * TD : 0;
+    const int steps = K >> 7, nvec = K >> 2;
+
+    // ---- (0) requests.  The chain waves' per-column constants first (a few bytes, but a memory round trip each if asked for
+    // where they are used); then the LDS-DMA of the tile (K * 32 bytes, contiguous in the fragment-major matrix) and of the activation rows
+    // first, spread over all sixteen waves; then the K/V rows of the two items of every non-chain wave's group
+    const float* __restrict__ bias = si == 0 ? p.qa_bias : (si == 2 ? p.bo : nullptr);
+    const float* __restrict__ wsum = si == 0 ? p.q_wsum : nullptr;
+    const int ncl = tl * 16 + l15;
+    float bias_v = 0.f, wsum_v = 0.f, resid_v = 0.f, qw1 = 0.f, qc1 = 0.f;
+    const int it_w = cu + G * wave;                                  // chain wave w finishes the query of item slot w
+    const int qh = (chain && it_w < n_items) ? it_w % H : 0, qb_row = (chain && it_w < n_items) ? (it_w / H) % Mb : 0;
+    if (chain) {
+        if (has_tile) {
+            bias_v = bias ? bias[ncl] : 0.f;
+            wsum_v = wsum ? wsum[ncl] : 0.f;
+            const int m = g * 4 + wave;
+            if (si == 2 && m < Mb) resid_v = p.x[(size_t)m * K + ncl];
+        }
+        qw1 = p.qw[(size_t)qh * 64 + lane]; qc1 = p.qbias[(size_t)qh * 64 + lane];
+    }
+    if (has_tile) {
+        const unsigned char* wsrc = (const unsigned char*)p.Ws + (size_t)my_tile * (K >> 5) * 1024;
+        for (int f = wave; f < (K >> 5); f += 16) dl_glds16(wsrc + (size_t)f * 1024 + lane * 16, wS + (size_t)f * 1024);
+        const unsigned char* xsrc = (const unsigned char*)(si == 0 ? p.x : p.a);
+        const int total = Mb * K * 4, nch = (total + 1023) >> 10;
+        for (int ch = wave; ch < nch; ch += 16)
+            dl_glds16(xsrc + min(ch * 1024 + lane * 16, total - 16), (unsigned char*)xraw + (size_t)ch * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int sub = gt & 7, kg = gt >> 3;                            // 8 lanes per key row, 64 key groups per item
+    DlRaw8 kr[2][4], vr[2][4];
+    const bf16_t* Kp[2];
+    const bf16_t* Vp[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const size_t o = (((size_t)ib[s] * H + ih[s]) * p.n_keys + iklo[s]) * 64 + sub * 8;
+        Kp[s] = (const bf16_t*)p.K + o;
+        Vp[s] = (const bf16_t*)p.V + o;
+    }
+    if (!chain) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kr[s][u].ld(Kp[s] + (size_t)min(kg + u * 64, ink[s] - 1) * 64);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vr[s][u].ld(Vp[s] + (size_t)min(kg + u * 64, ink[s] - 1) * 64);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the DMA was issued first and vector memory returns in order: at most the 16 K/V loads behind it remain
+    if (chain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    dl_barrier();
+
+    // ---- (1) chain waves: rows -> 16 bit -> LDS (gemv_stack_kernel: wave w owns rows w, w + 4; centred rounding of offset rows)
+    if (chain && has_tile) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = wave + 4 * i;
+            const int rc = row < Mb ? row : Mb - 1;
+            float4 xv[PER_LANE];
+#pragma unroll
+            for (int c = 0; c < PER_LANE; ++c) {
+                int v4 = lane + 64 * c;
+                v4 = v4 < nvec ? v4 : nvec - 1;
+                xv[c] = *(const float4*)(xraw + (size_t)rc * K + v4 * 4);
+            }
+            if (wsum) {
+                float sx = 0.f, sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < PER_LANE; ++c)
+                    if (lane + 64 * c < nvec) {
+                        sx += (xv[c].x + xv[c].y) + (xv[c].z + xv[c].w);
+                        sq += (xv[c].x * xv[c].x + xv[c].y * xv[c].y) + (xv[c].z * xv[c].z + xv[c].w * xv[c].w);
+                    }
+                float mu = wave_sum(sx) / (float)K;
+                if (2.f * mu * mu < wave_sum(sq) / (float)K) mu = 0.f;
+#pragma unroll
+                for (int c = 0; c < PER_LANE; ++c) { xv[c].x -= mu; xv[c].y -= mu; xv[c].z -= mu; xv[c].w -= mu; }
+                if (lane == 0) smean[row] = mu;
+            }
+#pragma unroll
+            for (int c = 0; c < PER_LANE; ++c) {
+                int v4 = lane + 64 * c;
+                v4 = v4 < nvec ? v4 : nvec - 1;
+                ushort4 o;
+                o.x = f32_to_bf16(xv[c].x); o.y = f32_to_bf16(xv[c].y); o.z = f32_to_bf16(xv[c].z); o.w = f32_to_bf16(xv[c].w);
+                *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
+            }
+        }
+    }
+    dl_barrier();
+    // ---- (2) MFMA over the wave's K steps w, w + 4, w + 8; B fragments straight from the DMA image
+    if (chain && has_tile) {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int step = wave + 4 * s;
+            if (step < steps) {
+                const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
+                    const bf16x8_t b = *(const bf16x8_t*)(wS + ((size_t)(step * 4 + j) * 64 + lane) * 16);
+                    acc = cw_mfma_16x16x32(a, b, acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    }
+    dl_barrier();
+    // ---- (3) epilogue: cross-wave sum in gemv_stack_kernel's order, results leave as granules (qa, qb, LayerNorm partial sums
+    // of x1) and as the plain residual rows x1 that later launches read
+    if (chain && has_tile) {
+        const int r = wave;
+        const float v = red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane] + red[(2 * 4 + r) * 64 + lane] + red[(3 * 4 + r) * 64 + lane];
+        const int m = g * 4 + r;
+        float ps1 = 0.f, ps2 = 0.f;
+        if (m < Mb) {
+            const size_t o = (size_t)m * K + ncl;
+            const float back = wsum ? smean[m] * wsum_v : 0.f;
+            if (si < 2) {
+                dl_gran_st(p.gq + ((size_t)si * 16 + m) * K + ncl, tag, __float_as_uint(v + bias_v + back));
+            } else {
+                const float rv = resid_v + resid_grid(v + bias_v);
+                p.x1[o] = rv;
+                ps1 += rv; ps2 += rv * rv;
+            }
+        }
+        if (si == 2) {
+#pragma unroll
+            for (int sft = 0; sft < 4; ++sft) {
+                ps1 += sft == 0 ? dpp_mov<0x111, 0xf>(0.f, ps1) : sft == 1 ? dpp_mov<0x112, 0xf>(0.f, ps1) : sft == 2 ? dpp_mov<0x114, 0xf>(0.f, ps1) : dpp_mov<0x118, 0xf>(0.f, ps1);
+                ps2 += sft == 0 ? dpp_mov<0x111, 0xf>(0.f, ps2) : sft == 1 ? dpp_mov<0x112, 0xf>(0.f, ps2) : sft == 2 ? dpp_mov<0x114, 0xf>(0.f, ps2) : dpp_mov<0x118, 0xf>(0.f, ps2);
+            }
+            if (l15 == 15) {   // rows >= Mb publish zeros like gemv_stack_kernel (never read)
+                dl_gran_st(p.gps + ((size_t)tl * 16 + m) * 2, tag, __float_as_uint(ps1));
+                dl_gran_st(p.gps + ((size_t)tl * 16 + m) * 2 + 1, tag, __float_as_uint(ps2));
+            }
+        }
+    }
+    // ---- (4) chain wave w finishes the query of item slot w (attn_cross_split_kernel<.., FUSED>: lane c = column c of the head):
+    //     q = rstd(x1) (qa + qb - mean(x1) qw) + qbias
+    // from the granules of the 8 tiles that hold the head's columns and of the TD tiles that hold the row's partial sums
+    if (chain) {
+        if (it_w < n_items) {
+            const int b = qb_row;
+            const size_t col = (size_t)qh * 64 + lane;
+            const dl_u64_t* ga = p.gq + ((size_t)0 * 16 + b) * K + col;
+            const dl_u64_t* gb = p.gq + ((size_t)1 * 16 + b) * K + col;
+            const dl_u64_t* g0 = p.gps + ((size_t)min(lane, TD - 1) * 16 + b) * 2;
+            const dl_u64_t* g1 = p.gps + ((size_t)min(lane + 64, TD - 1) * 16 + b) * 2;
+            dl_u64_t va, vb, v00, v01, v10, v11;
+            int spins = 0;
+            for (;;) {
+                va = dl_gran_ld(ga); vb = dl_gran_ld(gb);
+                v00 = dl_gran_ld(g0); v01 = dl_gran_ld(g0 + 1);
+                v10 = dl_gran_ld(g1); v11 = dl_gran_ld(g1 + 1);
+                const bool ok = (unsigned)(va >> 32) == tag && (unsigned)(vb >> 32) == tag && (unsigned)(v00 >> 32) == tag &&
+                                (unsigned)(v01 >> 32) == tag && (unsigned)(v10 >> 32) == tag && (unsigned)(v11 >> 32) == tag;
+                if (__all(ok)) break;
+                if (++spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            const float qa1 = __uint_as_float((unsigned)va), qb1 = __uint_as_float((unsigned)vb);
+            const float inv_d = 1.0f / (float)(H * 64);
+            const float ps1 = (lane < TD ? __uint_as_float((unsigned)v00) : 0.f) + (lane + 64 < TD ? __uint_as_float((unsigned)v10) : 0.f);
+            const float ps2 = (lane < TD ? __uint_as_float((unsigned)v01) : 0.f) + (lane + 64 < TD ? __uint_as_float((unsigned)v11) : 0.f);
+            const float mean = wave_sum(ps1) * inv_d;
+            const float var = fmaxf(wave_sum(ps2) * inv_d - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            c_q[wave * 64 + lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
+        }
+        // the chain waves' own share of the K/V rows goes out only now: their memory queue had to stay short for the polls
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kr[s][u].ld(Kp[s] + (size_t)min(kg + u * 64, ink[s] - 1) * 64);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vr[s][u].ld(Vp[s] + (size_t)min(kg + u * 64, ink[s] - 1) * 64);
+        }
+    }
+    dl_barrier();
+
+    // ---- (5) the items, one after the other per group, both groups in lockstep: attn_cross_split_kernel<T, 1, true> from its
+    // K pass on (gt / gw stand for its tid / wave)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int slot_i = 2 * grp + s;
+        const int nk = ink[s], h = ih[s], b0 = ib[s], sp = isp[s], k_lo = iklo[s];
+        float qv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = c_q[slot_i * 64 + sub * 8 + e];
+        float d[4], mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float kv[8];
+            kr[s][u].cvt(kv);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t = fmaf(qv[e], kv[e], t);
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+            d[u] = (kg + u * 64 < nk) ? t : -INFINITY;
+            mx = fmaxf(mx, d[u]);
+        }
+        mx = wave_max(mx);
+        if (lane == 0) c_smax[slot_i * 8 + gw] = mx;
+        dl_barrier();
+        {
+            float m = c_smax[slot_i * 8];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) m = fmaxf(m, c_smax[slot_i * 8 + w]);
+            mx = m;
+        }
+        const int aslot = (p.align_out && iv[s]) ? p.align_slot[h] : -1;
+        float acc[8];
+        float lsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kg + u * 64;
+            float vv[8];
+            vr[s][u].cvt(vv);
+            const float pk = (k < nk) ? expf(d[u] - mx) : 0.f;
+            if (sub == 0 && k < nk) {
+                lsum += pk;
+                if (aslot >= 0) {
+                    const size_t rowi = ((size_t)b0 * p.n_align + aslot) * p.align_rows + p.pos[b0];
+                    p.align_out[rowi * p.n_keys + k_lo + k] = pk;
+                }
+            }
+            if (k < nk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = xor32_sum(xor16_sum(dl_row_ror8_add(acc[e])));
+        lsum = wave_sum(lsum);
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c_red[(slot_i * 8 + gw) * 64 + sub * 8 + e] = acc[e];
+        }
+        if (lane == 0) c_redl[slot_i * 8 + gw] = lsum;
+        dl_barrier();
+        if (iv[s]) {
+            if (gt < 64) {
+                float r = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) r += c_red[(slot_i * 8 + w) * 64 + gt];
+                p.part_o[((size_t)sp * Mb + b0) * H * 64 + h * 64 + gt] = r;
+            }
+            if (gt == 64) {
+                float l = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) l += c_redl[slot_i * 8 + w];
+                float* ml = p.part_ml + (((size_t)b0 * H + h) * ATT_NS + sp) * 2;
+                ml[0] = mx; ml[1] = l;
+                if (aslot >= 0) {
+                    const size_t rowi = ((size_t)b0 * p.n_align + aslot) * p.align_rows + p.pos[b0];
+                    p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l;
+                }
+            }
+        }
+    }
+}
+
+size_t cw_dec_layer_lds(int D) {
+    const size_t xraw_bytes = (((size_t)8 * D * 4) + 1023) & ~(size_t)1023;
+    return (size_t)D * 32 + xraw_bytes + (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 16 + 32 + 32 + 4 * 64 + 4 * 8 * 64) * 4;
+}
+
+// grid: one workgroup per CU (every workgroup must be resident: they wait for each other's granules)
+int cw_launch_dec_layer(const DecLayerParams& p, int n_cu, hipStream_t st) {
+    const int D = p.D;
+    if (p.Mb < 1 || p.Mb > 8 || D % 128 || D > 1280 || p.H * 64 != D || n_cu < 1) return CW_ERR_INVALID;
+    if (3 * (D / 16) > n_cu || p.Mb * p.H * ATT_NS > 4 * n_cu || D / 16 > 128) return CW_ERR_INVALID;
+    if ((p.n_keys + ATT_NS - 1) / ATT_NS > 4 * 64 || p.n_keys < 1 || (ATT_NS - 1) * ((p.n_keys + ATT_NS - 1) / ATT_NS) >= p.n_keys) return CW_ERR_INVALID;
+    if (!p.gq || !p.gps || !p.epoch || !p.err || !p.Ws || !p.qw || !p.qbias) return CW_ERR_INVALID;
+    const size_t lds = cw_dec_layer_lds(D);
+    if (lds > 160 * 1024) return CW_ERR_INVALID;
+#define DL_LAUNCH(NS, PL)                                                                                                        \
+    do {                                                                                                                         \
+        static std::once_flag attr;                                                                                              \
+        std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)dec_layer_a_kernel<NS, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+        hipLaunchKernelGGL((dec_layer_a_kernel<NS, PL>), dim3(n_cu), dim3(DL_THREADS), lds, st, p);                              \
+    } while (0)
+    if (D <= 256) DL_LAUNCH(1, 1);
+    else if (D <= 768) DL_LAUNCH(2, 3);
+    else DL_LAUNCH(3, 5);
+#undef DL_LAUNCH
+    return CW_OK;
+}
+
+}  // namespace CW_NS

@@ -153,11 +153,12 @@ __global__ void embed_kernel(const int* __restrict__ ids, int ids_stride, int t,
     }
 }
 
-__global__ void set_pos_kernel(int* pos, int value, int B) {
+__global__ void set_pos_kernel(int* pos, int value, int B, unsigned int* epoch) {
     if ((int)threadIdx.x < B) pos[threadIdx.x] = value;
+    if (epoch && threadIdx.x == 0) *epoch += 1u;   // one decoder forward follows (declayer.hip: granule tags)
 }
-int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st) {
-    hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(64), 0, st, pos, value, B);
+int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st, unsigned int* epoch) {
+    hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(64), 0, st, pos, value, B, epoch);
     return CW_OK;
 }
 
@@ -283,7 +284,10 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(SampleParams p, Sam
         __syncthreads();
         acc_t = block_sum(acc_t, s_f);
     }
-    if (tid == 0 && b == 0 && sl == 0) *p.n_unfinished = 0;     // stage 2 (a later launch) counts the running rows into it
+    if (tid == 0 && b == 0 && sl == 0) {
+        *p.n_unfinished = 0;                                     // stage 2 (a later launch) counts the running rows into it
+        if (p.epoch) *p.epoch += 1u;                             // the next decoder forward tags its granules with a fresh epoch (declayer.hip)
+    }
     if (tid == 0) {
         SamplePart o; o.bt_v = bt.v; o.bt_i = bt.i; o.bs_v = bs.v; o.bs_i = bs.i; o.ts_sum = acc; o.pad[0] = acc_t; o.pad[1] = o.pad[2] = 0.f;
         part[(size_t)b * SAMPLE_NS + sl] = o;

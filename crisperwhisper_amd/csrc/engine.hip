@@ -87,6 +87,11 @@ struct cw_ctx {
     bool mlp_pair_fence = false;    // CW_MLP_PAIR_FENCE=1: round-3 hand-over (agent-scope acquire fence behind the group barrier)
     bool mlp_pair = false;          // CW_MLP_PAIR=1: fc1 + fc2 in one launch with an in-kernel group barrier (A/B: 23 us against 12.8 for two launches)
     unsigned int* d_bar = nullptr; int* d_err = nullptr;   // group barriers of mlp_pair_kernel; "a block gave up waiting" flag
+    // persistent decoder-layer kernel (declayer.hip), rows <= 8: granule buffers, the epoch counter their tags carry, CU count
+    bool declayer = true;           // CW_NO_DECLAYER=1: seven launches per layer (A/B and the differential test)
+    unsigned long long *d_gq = nullptr, *d_gps = nullptr;
+    unsigned int* d_epoch = nullptr;
+    int n_cu = 0;
     int stack_nt3 = 0, stack_nt5 = 0;   // column tiles per block of the two stacked GEMVs (0 = launcher's choice; CW_STACK_NT3/5)
     bool ln_folded = false;         // decoder LN-GEMVs run plain normalisation (affine part is inside W / bias)
     bool fold_enabled = true;       // CW_NO_LN_FOLD=1: keep gamma / beta in the kernels
@@ -361,6 +366,7 @@ static int create_impl(cw_ctx* c) {
     c->wpack_enabled = !sw.no_wpack;
     c->mlp_pair = sw.mlp_pair;
     c->mlp_pair_fence = sw.mlp_pair_fence;
+    c->declayer = !sw.no_declayer;
     c->stack_nt3 = sw.stack_nt3;
     c->stack_nt5 = sw.stack_nt5;
     c->prefetch = sw.prefetch;   // experiments builds only (refused above otherwise)
@@ -506,6 +512,15 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_u1, (size_t)Bm * F * 4)); CWCHK(c, dmalloc(c, &c->d_pstats, (size_t)128 * 16 * 2 * 4));
     CWCHK(c, dmalloc(c, &c->d_rstats, (size_t)((D > F ? D : F) / 16 + 1) * 64 * 2 * 4));
     CWCHK(c, dmalloc(c, &c->d_bar, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_err, 4));
+    {   // declayer.hip: granules are valid by tag only (never cleared); epoch 0 is never used
+        CWCHK(c, dmalloc(c, &c->d_gq, (size_t)2 * 16 * D * 8)); CWCHK(c, dmalloc(c, &c->d_gps, (size_t)(D / 16) * 16 * 2 * 8));
+        CWCHK(c, dmalloc(c, &c->d_epoch, 4));
+        const unsigned int one = 1;
+        HIPCHK(c, hipMemcpy(c->d_epoch, &one, 4, hipMemcpyHostToDevice));
+        hipDeviceProp_t prop;
+        HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+        c->n_cu = prop.multiProcessorCount;
+    }
     CWCHK(c, dmalloc(c, &c->d_xfrag, (size_t)64 * 5120 * 2));
     if (Bm > 16) {   // four K slices of the widest LayerNorm projection for 64 rows (5.2 MB at large-v3)
         c->planes_cap = (size_t)4 * 64 * (3 * D > F ? 3 * D : F);
@@ -1131,6 +1146,23 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         if (fuse) {
             const int TD = D / 16, TF = F / 16;
             const int nt3 = c->stack_nt3 > 0 ? c->stack_nt3 : 1;   // column tiles per X1 block (3 * TD blocks at 1: 240 at large-v3)
+            // rows <= 8: X1 and the cross-attention as ONE persistent launch (declayer.hip): the K/V rows are requested at kernel
+            // entry and stream under the GEMV tile; qa / qb / the partial sums cross CUs as granules.  Bit-identical to the two launches.
+            const bool dl = c->declayer && !c->fuse_mlp && nt3 == 1 && c->wpacked && nb <= 8 && 3 * TD <= c->n_cu &&
+                            nb * H * ATT_NS <= 4 * c->n_cu && TD <= 128 && KD(c, cw_dec_layer_lds, D) <= (size_t)160 * 1024;
+            if (dl) {
+                DecLayerParams dp;
+                memset(&dp, 0, sizeof(dp));
+                dp.Ws = L.ws3; dp.x = xin; dp.a = c->dattn; dp.qa_bias = L.qa_bias; dp.q_wsum = c->stack_center ? L.q_wsum : nullptr;
+                dp.bo = L.bo; dp.x1 = xalt;
+                dp.K = L.ck; dp.V = L.cv; dp.n_keys = CW_N_CTX; dp.part_o = c->d_part_o; dp.part_ml = c->d_part_ml;
+                dp.align_out = c->d.n_align > 0 ? c->d_align : nullptr; dp.align_ml = c->d_align_ml;
+                dp.align_slot = c->d_align_slot + (size_t)l * H; dp.pos = c->d_pos; dp.n_align = c->d.n_align; dp.align_rows = TGT;
+                dp.qw = L.q_wsum; dp.qbias = L.bq_c;
+                dp.gq = c->d_gq; dp.gps = c->d_gps; dp.epoch = c->d_epoch; dp.layer = l; dp.err = c->d_err;
+                dp.Mb = nb; dp.D = D; dp.H = H;
+                CWCHK(c, KD(c, cw_launch_dec_layer, dp, c->n_cu, c->st));
+            } else
             {   // X1 over [W'q_c ; W'q_c Wo ; Wo]:  qa = W'q_c x + W'q_c bo,  qb = (W'q_c Wo) a,  x1 = x + Wo a + bo
                 StackParams sp;
                 memset(&sp, 0, sizeof(sp));
@@ -1151,7 +1183,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             p.qa = c->d_qa; p.qb = c->d_qb; p.qw = L.q_wsum; p.qbias = L.bq_c;
             p.pstats = c->d_pstats; p.n_pstats = (TD + nt3 - 1) / nt3;
             if (!c->fuse_mlp) {
-                CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
+                if (!dl) CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
                 {   // out-projection combines the key-split partials; x2 = x1 + Wo_c a_c + bo_c in place
                     EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.bo_c; ep.ldo = D;
                     CombineParams cb{c->d_part_ml, H, nb * D};
@@ -1298,6 +1330,7 @@ static int launch_sample(cw_ctx* c, int nb, bool forced) {
     sp.embed = c->embed; sp.pos_embed = c->dec_pos; sp.x_out = c->dx; sp.d = c->d.d_model; sp.embed_bf16 = c->bf16 ? 1 : 0;
     sp.partials = c->d_sample_part;
     if (c->score_tokens) { sp.lp_sum = c->d_lp_sum; sp.lp_cnt = c->d_lp_cnt; }
+    sp.epoch = c->d_epoch;
     (void)forced;
     return KD(c, cw_launch_sample, sp, c->st);
 }
@@ -1357,11 +1390,11 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
 
     // prompt positions 0 .. n_prompt-2: forward only (their alignment rows are recorded, :254-256)
     for (int pos = 0; pos + 1 < n_prompt; ++pos) {
-        CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, pos, nb, c->st));
+        CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, pos, nb, c->st, c->d_epoch));
         CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
         CWCHK(c, decode_step(c, nb, false));
     }
-    CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, n_prompt - 1, nb, c->st));
+    CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, n_prompt - 1, nb, c->st, c->d_epoch));
     CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, n_prompt - 1, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
     int t = n_prompt, step = 0;
     // Host/device overlap: the "rows still running" counter of step s lands in its own pinned slot and is only
@@ -1458,7 +1491,7 @@ int32_t cw_no_speech_probs(cw_ctx* c, int32_t nb, int32_t sot_token, float* out)
     for (int b = 0; b < nb; ++b) ids[(size_t)b * TGT] = sot_token;
     HIPCHK(c, hipMemcpyAsync(c->d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
-    CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 0, nb, c->st));
+    CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 0, nb, c->st, c->d_epoch));
     CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, 0, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
     CWCHK(c, decode_step(c, nb, true));
     KCHK(c);

@@ -43,6 +43,7 @@ struct SampleParams {
     // log-probability of generation_whisper.py:1958-1974 (logprob_threshold)
     float* lp_sum;             // [B]
     int* lp_cnt;               // [B]
+    unsigned int* epoch;       // optional: device counter of decoder forwards, bumped by block 0 (declayer.hip tags its granules with it)
 };
 // beam search (elementwise.hip): per row the n_cand best processed log-probabilities of the next token
 // (log_softmax of the raw logits, then the same processors as the greedy path) ...
@@ -220,6 +221,38 @@ struct SkinnyFinishParams {
     EpiParams ep;          // destination + folded bias; EPI_STORE_F32 / EPI_QKV_CACHE / EPI_GELU_FRAG
 };
 
+// declayer.hip: persistent decoder-layer kernel (one 1024-thread workgroup per CU), rows <= 8.  Stage A = the fused
+// out-projection / cross-query stage (StackParams with NT = 1, fragment-major weights) + the key-split cross-attention
+// (CrossSplitParams, FUSED) in ONE launch: the cross-attention K/V rows are requested at kernel entry and stream while the
+// GEMV tile runs; results cross CUs as 8-byte {tag, value} granules.
+struct DecLayerParams {
+    const void* Ws;            // [3 D][D] 16-bit fragment-major [W'q_c ; W'q_c Wo ; Wo]
+    const float* x;            // [Mb][D] residual rows entering the stage
+    const float* a;            // [Mb][D] self-attention output
+    const float* qa_bias;      // [D] W'q_c bo
+    const float* q_wsum;       // [D] W'q_c 1 for the centred rounding of x (null: x is rounded as it is)
+    const float* bo;           // [D]
+    float* x1;                 // [Mb][D] out: x + grid(Wo a + bo)
+    const void* K;             // [Mb][H][n_keys][64] cross-attention cache
+    const void* V;
+    int n_keys;
+    float* part_o;             // as CrossSplitParams
+    float* part_ml;
+    float* align_out;
+    float* align_ml;
+    const int* align_slot;
+    const int* pos;
+    int n_align, align_rows;
+    const float* qw;           // [D] W'q_c 1
+    const float* qbias;        // [D] b'q_c
+    unsigned long long* gq;    // [2][16][D] granules: qa, qb
+    unsigned long long* gps;   // [D / 16][16][2] granules: per-tile (sum, sum of squares) of the rows of x1
+    const unsigned int* epoch; // device counter, bumped once per decoder forward (set_pos_kernel / sample_kernel)
+    int layer;
+    int* err;                  // set to 1 when a poll gave up (results are then invalid; the engine reports it)
+    int Mb, D, H;
+};
+
 // mel.hip
 struct MelTables {
     const double* cos_t;  // [400]
@@ -256,6 +289,8 @@ struct MelTables {
     int cw_launch_fold_product(const float* A, const float* s, float scale, const float* B, int N, int J, int K, void* C16, hipStream_t st); \
     int cw_launch_fold_rowvec(const float* A, const float* s, float scale, const float* v, const void* W16, int N, int J, float* c_out, float* w_out, hipStream_t st); \
     int cw_launch_gemv_stack(const StackParams& p, int nt, hipStream_t st); \
+    int cw_launch_dec_layer(const DecLayerParams& p, int n_cu, hipStream_t st); \
+    size_t cw_dec_layer_lds(int D); \
     int cw_launch_gemv_fc2x(const Fc2xParams& p, hipStream_t st); \
     int cw_launch_mlp_pair(const MlpPairParams& p, hipStream_t st); \
     int cw_launch_gemv_rows(int epi, bool produce, const RowsParams& p, hipStream_t st); \
@@ -273,7 +308,7 @@ struct MelTables {
     void cw_beam_topk_set_1block(int on); \
     int cw_launch_beam_advance(const BeamAdvanceParams& p, hipStream_t st); \
     int cw_launch_align_gather(const float* align, const int* row_of_pos, int n_items, int n_align, int align_rows, int L, int n_keys, float* out, hipStream_t st); \
-    int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st); \
+    int cw_launch_set_pos(int* pos, int value, int B, hipStream_t st, unsigned int* epoch = nullptr); \
     int cw_launch_embed(const int* ids, int ids_stride, int t, const void* embed, int embed_bf16, const float* pos_embed, float* x_out, int B, int d, hipStream_t st); \
     int cw_launch_attn_encoder(bool bf16, const void* Q, const void* K, const void* V, void* out, int B, int H, int S, int S_pad, hipStream_t st); \
     int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st); \

@@ -1218,6 +1218,58 @@ def test_logits_projection_persistent_column_loop_is_bit_identical(dt, rows):
         eng.close()
 
 
+@pytest.mark.parametrize("rows,dt", [(8, "bf16"), (8, "f16"), (5, "bf16"), (1, "bf16")])
+def test_persistent_decoder_layer_is_bit_identical(rows, dt):
+    """csrc/declayer.hip: the fused out-projection / cross-query stage and the cross-attention as ONE persistent launch (one
+    1024-thread workgroup per CU, K/V requested at kernel entry, qa / qb / LayerNorm partial sums handed across CUs as 8-byte
+    {tag, value} granules) against the same engine with CW_NO_DECLAYER=1 (the two launches it replaces).  Same arithmetic in the
+    same order, so EVERYTHING must be bit-identical: the logits of the captured steps, every token of > 2000 consecutive
+    free-running decoder forwards (five generate calls of 440 positions, graph replay -- the granule tags come from a device
+    counter), the alignment rows and the token timestamps.  A missed or stale hand-off changes bits here, not words."""
+    import os
+    g, v = syn.large_v3_geometry()
+    g.enc_layers, g.dec_layers = 1, 4
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(4) for h in (0, 3, 7, 19)][:15]
+    W = syn.random_weights(g, seed=21)
+    TGT = g.max_target_positions
+    T = TGT - 4
+    clips = [syn.synth_audio(700 + i, 480000 - 20000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
+    prompt = np.tile(np.array([[v.sot, v.lang_id("en"), v.transcribe]], np.int32), (rows, 1))
+    res = {}
+    for mode in ("persistent", "launches"):
+        if mode == "launches":
+            os.environ["CW_NO_DECLAYER"] = "1"
+        try:
+            eng = Engine(spec, dtype=dt, max_batch=rows)
+        finally:
+            os.environ.pop("CW_NO_DECLAYER", None)
+        try:
+            eng.load_state_dict(W)
+            out = []
+            for call in range(5):
+                eng.mel(clips[call % rows:] + clips[:call % rows])
+                eng.encode(list(range(rows)), [0] * rows, [3000] * rows)
+                cap = eng.capture_logits(rows, 24) if call in (0, 3) else None     # calls 1, 2, 4 replay the captured hipGraph
+                seqs, lens, _ = eng.decode(prompt, max_length=T, min_new_tokens=T - 3)
+                if cap is not None:
+                    eng.stop_capture()
+                out.append((seqs[:, :T].copy(), None if cap is None else cap[:24].copy(), eng.alignment(rows, T - 1).copy(),
+                            eng.token_timestamps(rows, T - 1, 3, [3000] * rows).copy()))
+            res[mode] = out
+        finally:
+            eng.close()
+    steps = 0
+    for (sa, ca, aa, ta), (sb, cb, ab, tb) in zip(res["persistent"], res["launches"]):
+        assert np.array_equal(sa, sb), int((sa != sb).sum())
+        if ca is not None:
+            assert np.array_equal(ca, cb), float(np.abs(ca - cb).max())
+        assert np.array_equal(aa, ab)
+        assert np.array_equal(ta, tb)
+        steps += sa.shape[1] - 3
+    assert steps > 2000
+
+
 @pytest.mark.parametrize("rows", [3, 8, 12])
 def test_fused_decoder_stage_tracks_eight_launch_layer(rows):
     """csrc/decfuse.hip: the out-projection + cross-query stage applied through the load-time product matrix (7 launches per

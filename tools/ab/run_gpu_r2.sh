@@ -1,7 +1,7 @@
 #!/bin/bash
 # One box visit: GPU test suite, default bench line (with the reference cpu_baseline + longform leg), A/B bench lines for
 # the env toggles given as arguments ("CW_NO_FUSE_SELF=1" ...), and a rocprofv3 kernel trace of the bench step.
-# usage: tests/run_gpu_r2.sh <tag> [ENV=VAL ...]
+# usage: tools/ab/run_gpu_r2.sh <tag> [ENV=VAL ...]
 TAG=${1:-r02}; shift
 mkdir -p gpurun_out/prof_$TAG
 export PYTHONUNBUFFERED=1

@@ -10,4 +10,4 @@ print({k:(round(v.get("frac_of_8TBps", v.get("frac_of_2500TFps", 0)),4)) for k,v
 print(d["longform"]["wall_s"], d["longform"]["words"]); print(d["cpu_baseline"]["value"], d["cpu_baseline"].get("rtf"))
 print({m: (round(v["ms_per_step"],1), v["golden_clips_identical_text"]) for m, v in d["config3"]["modes"].items()})
 P
-bash tests/run_gpu_pmc.sh gpurun_out/r03_pmc_traffic_B8.json > /dev/null 2>&1; head -c 1500 gpurun_out/r03_pmc_traffic_B8.json
+bash tools/ab/run_gpu_pmc.sh gpurun_out/r03_pmc_traffic_B8.json > /dev/null 2>&1; head -c 1500 gpurun_out/r03_pmc_traffic_B8.json

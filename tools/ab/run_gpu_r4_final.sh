@@ -18,7 +18,7 @@ prof() {  # TAG, bench args...
 prof r04_B8 --batch 8 --tokens 128
 prof r04_B64 --batch 64 --tokens 128
 prof r04_beam5 --batch 8 --tokens 128 --num-beams 5
-bash tests/run_gpu_pmc.sh gpurun_out/r04_pmc_traffic_B8.json > /dev/null 2>&1
+bash tools/ab/run_gpu_pmc.sh gpurun_out/r04_pmc_traffic_B8.json > /dev/null 2>&1
 python - <<'PY'
 import json
 d=json.loads(open("gpurun_out/r04_final_bench.json").read().strip().splitlines()[-1])
