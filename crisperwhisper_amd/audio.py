@@ -78,8 +78,23 @@ def parse_wav(data: bytes):
 
 
 import os as _os
-# upper bound on what a single compressed file may expand to (enforced inside the decoder's frame loop); CW_MAX_AUDIO_SECONDS
-MAX_DECODED_SECONDS = int(_os.environ.get("CW_MAX_AUDIO_SECONDS", 2 * 3600))
+
+
+# Upper bound on what one compressed file may expand to, in seconds (enforced inside the decoder's frame loop: a few hundred bytes
+# of CONSTANT frames would otherwise expand without bound).  24 h: long-form transcription is a supported workload and the
+# reference's ffmpeg_read has no cap.  CW_MAX_AUDIO_SECONDS overrides it, read at every call; a value that is not a positive
+# integer is ignored.
+MAX_DECODED_SECONDS = 24 * 3600
+
+
+def _max_decoded_seconds() -> int:
+    try:
+        v = int(_os.environ.get("CW_MAX_AUDIO_SECONDS", ""))
+        if v > 0:
+            return v
+    except ValueError:
+        pass
+    return int(MAX_DECODED_SECONDS)
 
 
 def decode_flac(data: bytes):
@@ -97,16 +112,19 @@ def decode_flac(data: bytes):
     # one decoding pass when STREAMINFO states the length (it is verified against the frames); a stream of unknown length
     # (total = 0) is sized by a first pass.  Either way the decoded audio is capped: a few hundred bytes of CONSTANT frames
     # would otherwise expand without bound.
-    max_frames = MAX_DECODED_SECONDS * max(int(sr.value), 1)
+    # the cap is in decoded sample frames at 16 kHz-equivalent duration, so a stream that declares a 655 kHz rate cannot buy 40x
+    # the host memory: frames <= seconds * min(rate, 48 kHz)
+    limit_s = _max_decoded_seconds()
+    max_frames = limit_s * min(max(int(sr.value), 1), 48000)
     if total.value > max_frames:
-        raise ValueError(f"FLAC stream declares {total.value} sample frames: more than the {MAX_DECODED_SECONDS} s this path accepts")
+        raise ValueError(f"FLAC stream declares {total.value} sample frames: more than the {limit_s} s this path accepts (raise CW_MAX_AUDIO_SECONDS)")
     cap = int(total.value)
     if cap <= 0:
         if lib.cw_flac_decode(ptr, len(buf), None, max_frames, C.byref(n)) != 0:
             raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
         cap = int(n.value)
         if cap > max_frames:
-            raise ValueError(f"FLAC stream decodes to {cap} sample frames: more than the {MAX_DECODED_SECONDS} s this path accepts")
+            raise ValueError(f"FLAC stream decodes to {cap} sample frames: more than the {limit_s} s this path accepts (raise CW_MAX_AUDIO_SECONDS)")
     out = np.empty((cap, int(ch.value)), dtype=np.int32)
     if lib.cw_flac_decode(ptr, len(buf), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)) != 0:
         raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())

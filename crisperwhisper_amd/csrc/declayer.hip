@@ -61,7 +61,116 @@ struct DlRaw8 {   // 8 consecutive 16-bit elements held raw so that the load is 
 // ---------------------------------------------------------------------------------------------------
 // stage A: [W'q_c ; W'q_c Wo ; Wo] tile (chain waves) -> granules -> cross-attention items (all waves)
 // ---------------------------------------------------------------------------------------------------
-template <int NSLOT, int PER_LANE>
+// Barrier among the four chain waves only (the other twelve are inside their K/V issue loop and must not be waited for):
+// a monotonic arrival counter in LDS.  k = 1, 2, 3 ... in program order.
+__device__ static inline void dl_chain_sync(unsigned* cb, int k, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(4 * k)) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+struct DlItem { int b, h, sp, nk, klo, aslot, arow; bool valid; };   // aslot: alignment slot of the head (or -1); arow: alignment row (= pos[b])
+
+// The two items of a group, one after the other, both groups in lockstep (hardware barriers): attn_cross_split_kernel<T, 1, true>
+// from its K pass on (gt / gw stand for its tid / wave).  Instantiated once per wave role so that each role's vmcnt bookkeeping
+// is exact: item 0 starts when ITS rows have landed, item 1's land underneath it.
+__device__ __forceinline__ void dl_cross_items(const DecLayerParams& p, const DlItem (&it)[2], DlRaw8 (&kr)[2][4], DlRaw8 (&vr)[2][4],
+                                               int grp, int gw, int gt, int lane, const float* c_q, float* c_smax, float* c_redl,
+                                               float* c_red) {
+    const int sub = gt & 7, kg = gt >> 3;
+    const int Mb = p.Mb, H = p.H;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int slot_i = 2 * grp + s;
+        const int nk = it[s].nk, h = it[s].h, b0 = it[s].b, sp = it[s].sp, k_lo = it[s].klo;
+        float qv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = c_q[slot_i * 64 + sub * 8 + e];
+        float d[4], mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float kv[8];
+            kr[s][u].cvt(kv);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t = fmaf(qv[e], kv[e], t);
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+            d[u] = (kg + u * 64 < nk) ? t : -INFINITY;
+            mx = fmaxf(mx, d[u]);
+        }
+        mx = wave_max(mx);
+        if (lane == 0) c_smax[slot_i * 8 + gw] = mx;
+        dl_barrier();
+        {
+            float m = c_smax[slot_i * 8];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) m = fmaxf(m, c_smax[slot_i * 8 + w]);
+            mx = m;
+        }
+        const int aslot = it[s].aslot;                  // fetched at kernel entry: a load issued here would sit BEHIND the K/V rows (in-order return)
+        float acc[8];
+        float lsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kg + u * 64;
+            float vv[8];
+            vr[s][u].cvt(vv);
+            const float pk = (k < nk) ? expf(d[u] - mx) : 0.f;
+            if (sub == 0 && k < nk) {
+                lsum += pk;
+                if (aslot >= 0) {
+                    const size_t rowi = ((size_t)b0 * p.n_align + aslot) * p.align_rows + it[s].arow;
+                    p.align_out[rowi * p.n_keys + k_lo + k] = pk;
+                }
+            }
+            if (k < nk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = xor32_sum(xor16_sum(dl_row_ror8_add(acc[e])));
+        lsum = wave_sum(lsum);
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c_red[(slot_i * 8 + gw) * 64 + sub * 8 + e] = acc[e];
+        }
+        if (lane == 0) c_redl[slot_i * 8 + gw] = lsum;
+        dl_barrier();
+        if (it[s].valid) {
+            if (gt < 64) {
+                float r = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) r += c_red[(slot_i * 8 + w) * 64 + gt];
+                p.part_o[((size_t)sp * Mb + b0) * H * 64 + h * 64 + gt] = r;
+            }
+            if (gt == 64) {
+                float l = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) l += c_redl[slot_i * 8 + w];
+                float* ml = p.part_ml + (((size_t)b0 * H + h) * ATT_NS + sp) * 2;
+                ml[0] = mx; ml[1] = l;
+                if (aslot >= 0) {
+                    const size_t rowi = ((size_t)b0 * p.n_align + aslot) * p.align_rows + it[s].arow;
+                    p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l;
+                }
+            }
+        }
+    }
+}
+
+// K/V row load number `idx` (0..15) of a lane: item idx / 8, K before V, four rows each -- the order the items consume them in
+#define DL_KV_LOAD(idx)                                                                                                      \
+    do {                                                                                                                      \
+        constexpr int s_ = (idx) >> 3, v_ = ((idx) >> 2) & 1, u_ = (idx) & 3;                                                \
+        const size_t ro_ = (size_t)min(kg + u_ * 64, it[s_].nk - 1) * 64;                                                    \
+        if (v_) vr[s_][u_].ld(Vp[s_] + ro_); else kr[s_][u_].ld(Kp[s_] + ro_);                                              \
+    } while (0)
+
+template <int NSLOT, int PER_LANE, int DEPTH>
 __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     const int K = p.D, Mb = p.Mb, H = p.H;
@@ -86,21 +195,23 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
     float* c_redl = c_smax + 32;                                     // [4][8]
     float* c_q = c_redl + 32;                                        // [4][64] finished queries
     float* c_red = c_q + 4 * 64;                                     // [4][8][64]
+    unsigned* cb = (unsigned*)(c_red + 4 * 8 * 64);                  // arrival counter of the chain waves
 
     // ---- work of this CU: cross-attention items cu, cu + G, cu + 2G, cu + 3G (group 0: the first two); one tile, dealt from
     // the END of the grid because the last CUs hold one item less
     const int n_items = Mb * H * ATT_NS;
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
-    int ib[2], ih[2], isp[2], ink[2], iklo[2];
-    bool iv[2];
+    DlItem it[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int it = cu + G * (2 * grp + s);
-        iv[s] = it < n_items;
-        const int itc = iv[s] ? it : 0;
-        ih[s] = itc % H; ib[s] = (itc / H) % Mb; isp[s] = itc / (H * Mb);   // = blockIdx (x, y, z) of attn_cross_split_kernel
-        iklo[s] = isp[s] * per;
-        ink[s] = min(p.n_keys, iklo[s] + per) - iklo[s];
+        const int i = cu + G * (2 * grp + s);
+        it[s].valid = i < n_items;
+        const int ic = it[s].valid ? i : 0;
+        it[s].h = ic % H; it[s].b = (ic / H) % Mb; it[s].sp = ic / (H * Mb);   // = blockIdx (x, y, z) of attn_cross_split_kernel
+        it[s].klo = it[s].sp * per;
+        it[s].nk = min(p.n_keys, it[s].klo + per) - it[s].klo;
+        it[s].aslot = (p.align_out && it[s].valid) ? p.align_slot[it[s].h] : -1;
+        it[s].arow = p.pos[it[s].b];
     }
     const int n_tiles = 3 * TD;
     const int my_tile = G - 1 - cu;
@@ -108,64 +219,67 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
     const int si = has_tile ? my_tile / TD : 0;                      // segment: 0 qa = W'q x, 1 qb = (W'q Wo) a, 2 x1 = x + Wo a + bo
     const int tl = has_tile ? my_tile - si * TD : 0;
     const int steps = K >> 7, nvec = K >> 2;
-
-    // ---- (0) requests.  The chain waves' per-column constants first (a few bytes, but a memory round trip each if asked for
-    // where they are used); then the LDS-DMA of the tile (K * 32 bytes, contiguous in the fragment-major matrix) and of the activation rows
-    // first, spread over all sixteen waves; then the K/V rows of the two items of every non-chain wave's group
-    const float* __restrict__ bias = si == 0 ? p.qa_bias : (si == 2 ? p.bo : nullptr);
-    const float* __restrict__ wsum = si == 0 ? p.q_wsum : nullptr;
-    const int ncl = tl * 16 + l15;
-    float bias_v = 0.f, wsum_v = 0.f, resid_v = 0.f, qw1 = 0.f, qc1 = 0.f;
-    const int it_w = cu + G * wave;                                  // chain wave w finishes the query of item slot w
-    const int qh = (chain && it_w < n_items) ? it_w % H : 0, qb_row = (chain && it_w < n_items) ? (it_w / H) % Mb : 0;
-    if (chain) {
-        if (has_tile) {
-            bias_v = bias ? bias[ncl] : 0.f;
-            wsum_v = wsum ? wsum[ncl] : 0.f;
-            const int m = g * 4 + wave;
-            if (si == 2 && m < Mb) resid_v = p.x[(size_t)m * K + ncl];
-        }
-        qw1 = p.qw[(size_t)qh * 64 + lane]; qc1 = p.qbias[(size_t)qh * 64 + lane];
-    }
-    if (has_tile) {
-        const unsigned char* wsrc = (const unsigned char*)p.Ws + (size_t)my_tile * (K >> 5) * 1024;
-        for (int f = wave; f < (K >> 5); f += 16) dl_glds16(wsrc + (size_t)f * 1024 + lane * 16, wS + (size_t)f * 1024);
-        const unsigned char* xsrc = (const unsigned char*)(si == 0 ? p.x : p.a);
-        const int total = Mb * K * 4, nch = (total + 1023) >> 10;
-        for (int ch = wave; ch < nch; ch += 16)
-            dl_glds16(xsrc + min(ch * 1024 + lane * 16, total - 16), (unsigned char*)xraw + (size_t)ch * 1024);
-    }
-    __builtin_amdgcn_sched_barrier(0);
     const int sub = gt & 7, kg = gt >> 3;                            // 8 lanes per key row, 64 key groups per item
     DlRaw8 kr[2][4], vr[2][4];
     const bf16_t* Kp[2];
     const bf16_t* Vp[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const size_t o = (((size_t)ib[s] * H + ih[s]) * p.n_keys + iklo[s]) * 64 + sub * 8;
+        const size_t o = (((size_t)it[s].b * H + it[s].h) * p.n_keys + it[s].klo) * 64 + sub * 8;
         Kp[s] = (const bf16_t*)p.K + o;
         Vp[s] = (const bf16_t*)p.V + o;
     }
-    if (!chain) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) kr[s][u].ld(Kp[s] + (size_t)min(kg + u * 64, ink[s] - 1) * 64);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) vr[s][u].ld(Vp[s] + (size_t)min(kg + u * 64, ink[s] - 1) * 64);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // the DMA was issued first and vector memory returns in order: at most the 16 K/V loads behind it remain
-    if (chain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (tid == 0) *cb = 0u;
     dl_barrier();
 
-    // ---- (1) chain waves: rows -> 16 bit -> LDS (gemv_stack_kernel: wave w owns rows w, w + 4; centred rounding of offset rows)
-    if (chain && has_tile) {
+    if (!chain) {
+        // ---- the twelve K/V waves: 16 rows of 16 B per lane, at most DEPTH of them in flight per wave.  A CU takes in ~25-45 GB/s
+        // however much it has asked for; what a deeper queue buys is only a longer wait for the chain waves' polls
+        // and DMA behind it (MI355X_MICROARCH.md, row gather-pass: "thin the loader while its CU gathers").
+#define DL_STEP(idx)                                                                                                          \
+        do {                                                                                                                  \
+            if ((idx) >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");                              \
+            DL_KV_LOAD(idx);                                                                                                  \
+        } while (0)
+        DL_STEP(0); DL_STEP(1); DL_STEP(2); DL_STEP(3); DL_STEP(4); DL_STEP(5); DL_STEP(6); DL_STEP(7);
+        DL_STEP(8); DL_STEP(9); DL_STEP(10); DL_STEP(11); DL_STEP(12); DL_STEP(13); DL_STEP(14); DL_STEP(15);
+#undef DL_STEP
+        dl_barrier();                                               // queries are in c_q
+        dl_cross_items(p, it, kr, vr, grp, gw, gt, lane, c_q, c_smax, c_redl, c_red);
+        return;
+    }
+
+    // ================= chain waves =================
+    // ---- (0) requests: per-column constants first (a few bytes, but a memory round trip each if asked for where they are used),
+    // then the LDS-DMA of the tile (K * 32 bytes, contiguous in the fragment-major matrix) and of the activation rows
+    const float* __restrict__ bias = si == 0 ? p.qa_bias : (si == 2 ? p.bo : nullptr);
+    const float* __restrict__ wsum = si == 0 ? p.q_wsum : nullptr;
+    const int ncl = tl * 16 + l15;
+    float bias_v = 0.f, wsum_v = 0.f, resid_v = 0.f;
+    const int it_w = cu + G * wave;                                  // chain wave w finishes the query of item slot w
+    const bool q_mine = it_w < n_items;
+    const int qh = q_mine ? it_w % H : 0, qb_row = q_mine ? (it_w / H) % Mb : 0;
+    if (has_tile) {
+        bias_v = bias ? bias[ncl] : 0.f;
+        wsum_v = wsum ? wsum[ncl] : 0.f;
+        const int m = g * 4 + wave;
+        if (si == 2 && m < Mb) resid_v = p.x[(size_t)m * K + ncl];
+    }
+    const float qw1 = p.qw[(size_t)qh * 64 + lane], qc1 = p.qbias[(size_t)qh * 64 + lane];
+    if (has_tile) {
+        const unsigned char* wsrc = (const unsigned char*)p.Ws + (size_t)my_tile * (K >> 5) * 1024;
+        for (int f = wave; f < (K >> 5); f += 4) dl_glds16(wsrc + (size_t)f * 1024 + lane * 16, wS + (size_t)f * 1024);
+        const unsigned char* xsrc = (const unsigned char*)(si == 0 ? p.x : p.a);
+        const int total = Mb * K * 4, nch = (total + 1023) >> 10;
+        for (int ch = wave; ch < nch; ch += 4)
+            dl_glds16(xsrc + min(ch * 1024 + lane * 16, total - 16), (unsigned char*)xraw + (size_t)ch * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dl_chain_sync(cb, 1, lane);
+
+        // ---- (1) rows -> 16 bit -> LDS (gemv_stack_kernel: wave w owns rows w, w + 4; centred rounding of offset rows)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int row = wave + 4 * i;
+            const int row = wave + 4 * i;
             const int rc = row < Mb ? row : Mb - 1;
             float4 xv[PER_LANE];
 #pragma unroll
@@ -197,81 +311,95 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
                 *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
             }
         }
-    }
-    dl_barrier();
-    // ---- (2) MFMA over the wave's K steps w, w + 4, w + 8; B fragments straight from the DMA image
-    if (chain && has_tile) {
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        dl_chain_sync(cb, 2, lane);
+        // ---- (2) MFMA over the wave's K steps w, w + 4, w + 8; B fragments straight from the DMA image
+        {
+            f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            const int step = wave + 4 * s;
-            if (step < steps) {
-                const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
+            for (int s = 0; s < NSLOT; ++s) {
+                const int step = wave + 4 * s;
+                if (step < steps) {
+                    const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
-                    const bf16x8_t b = *(const bf16x8_t*)(wS + ((size_t)(step * 4 + j) * 64 + lane) * 16);
-                    acc = cw_mfma_16x16x32(a, b, acc);
+                    for (int j = 0; j < 4; ++j) {
+                        const bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
+                        const bf16x8_t b = *(const bf16x8_t*)(wS + ((size_t)(step * 4 + j) * 64 + lane) * 16);
+                        acc = cw_mfma_16x16x32(a, b, acc);
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
-    }
-    dl_barrier();
-    // ---- (3) epilogue: cross-wave sum in gemv_stack_kernel's order, results leave as granules (qa, qb, LayerNorm partial sums
-    // of x1) and as the plain residual rows x1 that later launches read
-    if (chain && has_tile) {
-        const int r = wave;
-        const float v = red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane] + red[(2 * 4 + r) * 64 + lane] + red[(3 * 4 + r) * 64 + lane];
-        const int m = g * 4 + r;
-        float ps1 = 0.f, ps2 = 0.f;
-        if (m < Mb) {
-            const size_t o = (size_t)m * K + ncl;
-            const float back = wsum ? smean[m] * wsum_v : 0.f;
-            if (si < 2) {
-                dl_gran_st(p.gq + ((size_t)si * 16 + m) * K + ncl, tag, __float_as_uint(v + bias_v + back));
-            } else {
-                const float rv = resid_v + resid_grid(v + bias_v);
-                p.x1[o] = rv;
-                ps1 += rv; ps2 += rv * rv;
-            }
+            for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
         }
-        if (si == 2) {
-#pragma unroll
-            for (int sft = 0; sft < 4; ++sft) {
-                ps1 += sft == 0 ? dpp_mov<0x111, 0xf>(0.f, ps1) : sft == 1 ? dpp_mov<0x112, 0xf>(0.f, ps1) : sft == 2 ? dpp_mov<0x114, 0xf>(0.f, ps1) : dpp_mov<0x118, 0xf>(0.f, ps1);
-                ps2 += sft == 0 ? dpp_mov<0x111, 0xf>(0.f, ps2) : sft == 1 ? dpp_mov<0x112, 0xf>(0.f, ps2) : sft == 2 ? dpp_mov<0x114, 0xf>(0.f, ps2) : dpp_mov<0x118, 0xf>(0.f, ps2);
+        dl_chain_sync(cb, 3, lane);
+        // ---- (3) epilogue: cross-wave sum in gemv_stack_kernel's order, results leave as granules (qa, qb, LayerNorm partial
+        // sums of x1) and as the plain residual rows x1 that later launches read
+        {
+            const int r = wave;
+            const float v = red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane] + red[(2 * 4 + r) * 64 + lane] + red[(3 * 4 + r) * 64 + lane];
+            const int m = g * 4 + r;
+            float ps1 = 0.f, ps2 = 0.f;
+            if (m < Mb) {
+                const size_t o = (size_t)m * K + ncl;
+                const float back = wsum ? smean[m] * wsum_v : 0.f;
+                if (si < 2) {
+                    dl_gran_st(p.gq + ((size_t)si * 16 + m) * K + ncl, tag, __float_as_uint(v + bias_v + back));
+                } else {
+                    const float rv = resid_v + resid_grid(v + bias_v);
+                    p.x1[o] = rv;
+                    ps1 += rv; ps2 += rv * rv;
+                }
             }
-            if (l15 == 15) {   // rows >= Mb publish zeros like gemv_stack_kernel (never read)
-                dl_gran_st(p.gps + ((size_t)tl * 16 + m) * 2, tag, __float_as_uint(ps1));
-                dl_gran_st(p.gps + ((size_t)tl * 16 + m) * 2 + 1, tag, __float_as_uint(ps2));
+            if (si == 2) {
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft) {
+                    ps1 += sft == 0 ? dpp_mov<0x111, 0xf>(0.f, ps1) : sft == 1 ? dpp_mov<0x112, 0xf>(0.f, ps1) : sft == 2 ? dpp_mov<0x114, 0xf>(0.f, ps1) : dpp_mov<0x118, 0xf>(0.f, ps1);
+                    ps2 += sft == 0 ? dpp_mov<0x111, 0xf>(0.f, ps2) : sft == 1 ? dpp_mov<0x112, 0xf>(0.f, ps2) : sft == 2 ? dpp_mov<0x114, 0xf>(0.f, ps2) : dpp_mov<0x118, 0xf>(0.f, ps2);
+                }
+                if (l15 == 15) {   // rows >= Mb publish zeros like gemv_stack_kernel (never read)
+                    dl_gran_st(p.gps + ((size_t)tl * 16 + m) * 2, tag, __float_as_uint(ps1));
+                    dl_gran_st(p.gps + ((size_t)tl * 16 + m) * 2 + 1, tag, __float_as_uint(ps2));
+                }
             }
         }
     }
     // ---- (4) chain wave w finishes the query of item slot w (attn_cross_split_kernel<.., FUSED>: lane c = column c of the head):
     //     q = rstd(x1) (qa + qb - mean(x1) qw) + qbias
-    // from the granules of the 8 tiles that hold the head's columns and of the TD tiles that hold the row's partial sums
-    if (chain) {
-        if (it_w < n_items) {
-            const int b = qb_row;
-            const size_t col = (size_t)qh * 64 + lane;
-            const dl_u64_t* ga = p.gq + ((size_t)0 * 16 + b) * K + col;
-            const dl_u64_t* gb = p.gq + ((size_t)1 * 16 + b) * K + col;
-            const dl_u64_t* g0 = p.gps + ((size_t)min(lane, TD - 1) * 16 + b) * 2;
-            const dl_u64_t* g1 = p.gps + ((size_t)min(lane + 64, TD - 1) * 16 + b) * 2;
-            dl_u64_t va, vb, v00, v01, v10, v11;
-            int spins = 0;
-            for (;;) {
-                va = dl_gran_ld(ga); vb = dl_gran_ld(gb);
-                v00 = dl_gran_ld(g0); v01 = dl_gran_ld(g0 + 1);
-                v10 = dl_gran_ld(g1); v11 = dl_gran_ld(g1 + 1);
-                const bool ok = (unsigned)(va >> 32) == tag && (unsigned)(vb >> 32) == tag && (unsigned)(v00 >> 32) == tag &&
-                                (unsigned)(v01 >> 32) == tag && (unsigned)(v10 >> 32) == tag && (unsigned)(v11 >> 32) == tag;
-                if (__all(ok)) break;
-                if (++spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }
-                __builtin_amdgcn_s_sleep(4);
-            }
+    // from the granules of the 8 tiles that hold the head's columns and of the TD tiles that hold the row's partial sums.  Its own
+    // K/V rows go out four at a time BETWEEN the polls (vector memory returns in order: a poll behind 16 rows would wait for all
+    // of them), so most of them are in by the time the query is.
+    {
+        const size_t col = (size_t)qh * 64 + lane;
+        const dl_u64_t* ga = p.gq + ((size_t)0 * 16 + qb_row) * K + col;
+        const dl_u64_t* gb = p.gq + ((size_t)1 * 16 + qb_row) * K + col;
+        const dl_u64_t* g0 = p.gps + ((size_t)min(lane, TD - 1) * 16 + qb_row) * 2;
+        const dl_u64_t* g1 = p.gps + ((size_t)min(lane + 64, TD - 1) * 16 + qb_row) * 2;
+        dl_u64_t va = 0, vb = 0, v00 = 0, v01 = 0, v10 = 0, v11 = 0;
+        bool ready = !q_mine;
+#define DL_POLL()                                                                                                             \
+        do {                                                                                                                  \
+            va = dl_gran_ld(ga); vb = dl_gran_ld(gb);                                                                         \
+            v00 = dl_gran_ld(g0); v01 = dl_gran_ld(g0 + 1);                                                                   \
+            v10 = dl_gran_ld(g1); v11 = dl_gran_ld(g1 + 1);                                                                   \
+            const bool ok_ = (unsigned)(va >> 32) == tag && (unsigned)(vb >> 32) == tag && (unsigned)(v00 >> 32) == tag &&    \
+                             (unsigned)(v01 >> 32) == tag && (unsigned)(v10 >> 32) == tag && (unsigned)(v11 >> 32) == tag;    \
+            ready = __all(ok_);                                                                                               \
+        } while (0)
+        DL_KV_LOAD(0); DL_KV_LOAD(1); DL_KV_LOAD(2); DL_KV_LOAD(3);
+        if (!ready) DL_POLL();
+        DL_KV_LOAD(4); DL_KV_LOAD(5); DL_KV_LOAD(6); DL_KV_LOAD(7);
+        if (!ready) DL_POLL();
+        DL_KV_LOAD(8); DL_KV_LOAD(9); DL_KV_LOAD(10); DL_KV_LOAD(11);
+        if (!ready) DL_POLL();
+        DL_KV_LOAD(12); DL_KV_LOAD(13); DL_KV_LOAD(14); DL_KV_LOAD(15);
+#pragma unroll 1
+        for (int spins = 0; !ready; ++spins) {
+            if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }
+            if (spins) __builtin_amdgcn_s_sleep(4);
+            DL_POLL();
+        }
+#undef DL_POLL
+        if (q_mine) {
             const float qa1 = __uint_as_float((unsigned)va), qb1 = __uint_as_float((unsigned)vb);
             const float inv_d = 1.0f / (float)(H * 64);
             const float ps1 = (lane < TD ? __uint_as_float((unsigned)v00) : 0.f) + (lane + 64 < TD ? __uint_as_float((unsigned)v10) : 0.f);
@@ -281,104 +409,15 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
             const float rstd = 1.0f / sqrtf(var + 1e-5f);
             c_q[wave * 64 + lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
         }
-        // the chain waves' own share of the K/V rows goes out only now: their memory queue had to stay short for the polls
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) kr[s][u].ld(Kp[s] + (size_t)min(kg + u * 64, ink[s] - 1) * 64);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) vr[s][u].ld(Vp[s] + (size_t)min(kg + u * 64, ink[s] - 1) * 64);
-        }
     }
     dl_barrier();
-
-    // ---- (5) the items, one after the other per group, both groups in lockstep: attn_cross_split_kernel<T, 1, true> from its
-    // K pass on (gt / gw stand for its tid / wave)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int slot_i = 2 * grp + s;
-        const int nk = ink[s], h = ih[s], b0 = ib[s], sp = isp[s], k_lo = iklo[s];
-        float qv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[e] = c_q[slot_i * 64 + sub * 8 + e];
-        float d[4], mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float kv[8];
-            kr[s][u].cvt(kv);
-            float t = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t = fmaf(qv[e], kv[e], t);
-            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
-            d[u] = (kg + u * 64 < nk) ? t : -INFINITY;
-            mx = fmaxf(mx, d[u]);
-        }
-        mx = wave_max(mx);
-        if (lane == 0) c_smax[slot_i * 8 + gw] = mx;
-        dl_barrier();
-        {
-            float m = c_smax[slot_i * 8];
-#pragma unroll
-            for (int w = 1; w < 8; ++w) m = fmaxf(m, c_smax[slot_i * 8 + w]);
-            mx = m;
-        }
-        const int aslot = (p.align_out && iv[s]) ? p.align_slot[h] : -1;
-        float acc[8];
-        float lsum = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = kg + u * 64;
-            float vv[8];
-            vr[s][u].cvt(vv);
-            const float pk = (k < nk) ? expf(d[u] - mx) : 0.f;
-            if (sub == 0 && k < nk) {
-                lsum += pk;
-                if (aslot >= 0) {
-                    const size_t rowi = ((size_t)b0 * p.n_align + aslot) * p.align_rows + p.pos[b0];
-                    p.align_out[rowi * p.n_keys + k_lo + k] = pk;
-                }
-            }
-            if (k < nk) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = xor32_sum(xor16_sum(dl_row_ror8_add(acc[e])));
-        lsum = wave_sum(lsum);
-        if (lane < 8) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) c_red[(slot_i * 8 + gw) * 64 + sub * 8 + e] = acc[e];
-        }
-        if (lane == 0) c_redl[slot_i * 8 + gw] = lsum;
-        dl_barrier();
-        if (iv[s]) {
-            if (gt < 64) {
-                float r = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) r += c_red[(slot_i * 8 + w) * 64 + gt];
-                p.part_o[((size_t)sp * Mb + b0) * H * 64 + h * 64 + gt] = r;
-            }
-            if (gt == 64) {
-                float l = 0.f;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) l += c_redl[slot_i * 8 + w];
-                float* ml = p.part_ml + (((size_t)b0 * H + h) * ATT_NS + sp) * 2;
-                ml[0] = mx; ml[1] = l;
-                if (aslot >= 0) {
-                    const size_t rowi = ((size_t)b0 * p.n_align + aslot) * p.align_rows + p.pos[b0];
-                    p.align_ml[(rowi * ATT_NS + sp) * 2] = mx; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l;
-                }
-            }
-        }
-    }
+    dl_cross_items(p, it, kr, vr, grp, gw, gt, lane, c_q, c_smax, c_redl, c_red);
 }
+#undef DL_KV_LOAD
 
 size_t cw_dec_layer_lds(int D) {
     const size_t xraw_bytes = (((size_t)8 * D * 4) + 1023) & ~(size_t)1023;
-    return (size_t)D * 32 + xraw_bytes + (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 16 + 32 + 32 + 4 * 64 + 4 * 8 * 64) * 4;
+    return (size_t)D * 32 + xraw_bytes + (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 16 + 32 + 32 + 4 * 64 + 4 * 8 * 64 + 4) * 4;
 }
 
 // grid: one workgroup per CU (every workgroup must be resident: they wait for each other's granules)
@@ -390,15 +429,21 @@ int cw_launch_dec_layer(const DecLayerParams& p, int n_cu, hipStream_t st) {
     if (!p.gq || !p.gps || !p.epoch || !p.err || !p.Ws || !p.qw || !p.qbias) return CW_ERR_INVALID;
     const size_t lds = cw_dec_layer_lds(D);
     if (lds > 160 * 1024) return CW_ERR_INVALID;
-#define DL_LAUNCH(NS, PL)                                                                                                        \
+#define DL_LAUNCH(NS, PL, DP)                                                                                                    \
     do {                                                                                                                         \
         static std::once_flag attr;                                                                                              \
-        std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)dec_layer_a_kernel<NS, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
-        hipLaunchKernelGGL((dec_layer_a_kernel<NS, PL>), dim3(n_cu), dim3(DL_THREADS), lds, st, p);                              \
+        std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)dec_layer_a_kernel<NS, PL, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+        hipLaunchKernelGGL((dec_layer_a_kernel<NS, PL, DP>), dim3(n_cu), dim3(DL_THREADS), lds, st, p);                          \
     } while (0)
-    if (D <= 256) DL_LAUNCH(1, 1);
-    else if (D <= 768) DL_LAUNCH(2, 3);
-    else DL_LAUNCH(3, 5);
+    // K/V rows in flight per lane of the twelve K/V waves (A/B: CW_DL_DEPTH = 2 | 4 | 6 | 8 | 16; 16 = everything at kernel entry)
+    const int depth = cw_sw::cw_switches().dl_depth;
+    if (D <= 256) DL_LAUNCH(1, 1, 4);
+    else if (D <= 768) DL_LAUNCH(2, 3, 4);
+    else if (depth == 2) DL_LAUNCH(3, 5, 2);
+    else if (depth == 6) DL_LAUNCH(3, 5, 6);
+    else if (depth == 8) DL_LAUNCH(3, 5, 8);
+    else if (depth == 16) DL_LAUNCH(3, 5, 16);
+    else DL_LAUNCH(3, 5, 4);
 #undef DL_LAUNCH
     return CW_OK;
 }

@@ -308,6 +308,20 @@ __global__ __launch_bounds__(256) void prefetch_kernel(PrefetchRanges r, unsigne
 
 #endif
 
+// Device buffers of a test / bench hook: everything allocated through `get` is freed when the scope ends, on every exit path
+// (the hooks return through HIPCHK / CWCHK from many places; tools call them in loops).
+struct DevScope {
+    std::vector<void*> ptrs;
+    template <typename P> hipError_t get(P** p, size_t bytes) {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, bytes ? bytes : 1);
+        if (e == hipSuccess) ptrs.push_back(q);
+        *p = (P*)q;
+        return e;
+    }
+    ~DevScope() { for (void* q : ptrs) hipFree(q); }
+};
+
 extern "C" {
 
 int32_t cw_abi_version(void) { return 1; }
@@ -336,9 +350,11 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipEventCreate(&c->ev1));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_step[0], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_step[1], hipEventDisableTiming));
+#ifdef CW_EXPERIMENTS   // side stream of the rejected run-ahead prefetch (CW_PREFETCH)
     HIPCHK(c, hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[0], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[1], hipEventDisableTiming));
+#endif
     HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
     if (d.dtype != CW_DTYPE_F32 && d.dtype != CW_DTYPE_BF16 && d.dtype != CW_DTYPE_F16) return fail(c, CW_ERR_INVALID, "unknown dtype %d", d.dtype);
     c->f16 = d.dtype == CW_DTYPE_F16;
@@ -522,11 +538,13 @@ static int create_impl(cw_ctx* c) {
         c->n_cu = prop.multiProcessorCount;
     }
     CWCHK(c, dmalloc(c, &c->d_xfrag, (size_t)64 * 5120 * 2));
-    if (Bm > 16) {   // four K slices of the widest LayerNorm projection for 64 rows (5.2 MB at large-v3)
+#ifdef CW_EXPERIMENTS   // skinny.hip planes (rejected A/B, CW_SKINNY): four K slices of the widest LayerNorm projection for 64 rows (5.2 MB at large-v3)
+    if (Bm > 16) {
         c->planes_cap = (size_t)4 * 64 * (3 * D > F ? 3 * D : F);
         CWCHK(c, dmalloc(c, &c->d_planes, c->planes_cap * 4, false));
         CWCHK(c, dmalloc(c, &c->d_sk_stats, (size_t)16 * 64 * 2 * 4));
     }
+#endif
     CWCHK(c, dmalloc(c, &c->d_xfrag2, (size_t)64 * 5120 * 2));
     c->Vpad = (V + 3) & ~3;
     CWCHK(c, dmalloc(c, &c->dlogits, (size_t)Bm * c->Vpad * 4));
@@ -534,7 +552,9 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_argmax, (size_t)Bm * TGT * 4));
     CWCHK(c, dmalloc(c, &c->d_last_ts, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_finished, Bm * 4));
     CWCHK(c, dmalloc(c, &c->d_nunf, 4));
+#ifdef CW_EXPERIMENTS
     CWCHK(c, dmalloc(c, &c->d_pf_sink, 4));
+#endif
     CWCHK(c, dmalloc(c, &c->d_pos, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_cfg, 4 * 4));
     CWCHK(c, dmalloc(c, &c->d_mask, (size_t)V + 16));
     CWCHK(c, dmalloc(c, &c->d_sample_part, (size_t)Bm * 16 * 32));
@@ -1074,10 +1094,11 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     // 17..64 rows without preparation launches (decfuse.hip: gemv_rows_kernel): the residual GEMVs own whole columns and leave
     // the stream in f32, its 16-bit fragment-major copy in d_xfrag and LayerNorm partial sums in d_rstats; the LayerNorm
     // GEMVs read that copy and normalise their outputs.  d_xfrag2 carries attention outputs and the GELU'd MLP rows.
-    // 17..64 rows, default: the LayerNorm projections (q/k/v, cross-attention query, fc1) as skinny-M GEMMs (skinny.hip): f32 rows
-    // -> K-split partial planes, finished (statistics, bias, cache / GELU epilogue) by one light launch -- no preparation launch.
-    // The residual projections stay on the 16-column K-split GEMV: their cost is the f32 atomics (7 ps each, measured), which
-    // a wider tile with more K slices multiplies (profiles/r04_skinny_ablation.txt).
+    // 17..64 rows, DEFAULT (skinny_mode 0): the round-3 path -- gemv_prep_kernel (LayerNorm / combine -> fragment-major rows) +
+    // gemv_mt_kernel per projection.  A/B only (-DCW_EXPERIMENTS builds, CW_SKINNY=1|2; measured slower in the step,
+    // profiles/r04_b64_skinny_planes_rejected_*): the LayerNorm projections as skinny-M GEMMs (skinny.hip): f32 rows -> K-split
+    // partial planes, finished (statistics, bias, cache / GELU epilogue) by one light launch.  The residual projections stay on
+    // the 16-column K-split GEMV either way: their cost is the f32 atomics (7 ps each), which a wider tile with more K slices multiplies.
     const bool sk_ok = frag && c->wpacked && c->ln_folded && c->rows_ln_ready && c->d_planes;
     const bool skinny = sk_ok && c->skinny_mode >= 2;
     // greedy rows over the 16-bit cache: one cross-attention block per (row, head) over all keys writes the out-projection's
@@ -2241,11 +2262,12 @@ int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K
     const size_t wbytes = (size_t)N * K * 2;
     int ncopy = 1;
     if (reps > 0) { ncopy = (int)((size_t)320 * 1024 * 1024 / wbytes) + 1; if (ncopy > 64) ncopy = 64; }
+    DevScope mem;
     float *dx = nullptr, *dB = nullptr, *dO = nullptr, *dws = nullptr, *dP = nullptr, *dst = nullptr; void *dW = nullptr, *dWp = nullptr, *dxf = nullptr, *dfr = nullptr;
-    HIPCHK(c, hipMalloc((void**)&dst, (size_t)64 * 64 * 2 * 4));
-    HIPCHK(c, hipMalloc((void**)&dx, (size_t)Mb * K * 4)); HIPCHK(c, hipMalloc(&dW, wbytes)); HIPCHK(c, hipMalloc(&dWp, wbytes * ncopy));
-    HIPCHK(c, hipMalloc((void**)&dO, (size_t)Mb * N * 4)); HIPCHK(c, hipMalloc((void**)&dB, (size_t)N * 4)); HIPCHK(c, hipMalloc((void**)&dws, (size_t)N * 4));
-    HIPCHK(c, hipMalloc((void**)&dP, (size_t)S * Mb * N * 4)); HIPCHK(c, hipMalloc(&dxf, (size_t)MT * 16 * K * 2)); HIPCHK(c, hipMalloc(&dfr, (size_t)MT * 16 * N * 2));
+    HIPCHK(c, mem.get(&dst, (size_t)64 * 64 * 2 * 4));
+    HIPCHK(c, mem.get(&dx, (size_t)Mb * K * 4)); HIPCHK(c, mem.get(&dW, wbytes)); HIPCHK(c, mem.get(&dWp, wbytes * ncopy));
+    HIPCHK(c, mem.get(&dO, (size_t)Mb * N * 4)); HIPCHK(c, mem.get(&dB, (size_t)N * 4)); HIPCHK(c, mem.get(&dws, (size_t)N * 4));
+    HIPCHK(c, mem.get(&dP, (size_t)S * Mb * N * 4)); HIPCHK(c, mem.get(&dxf, (size_t)MT * 16 * K * 2)); HIPCHK(c, mem.get(&dfr, (size_t)MT * 16 * N * 2));
     HIPCHK(c, hipMemcpy(dx, x, (size_t)Mb * K * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemset(dB, 0, (size_t)N * 4));
     if (bias) HIPCHK(c, hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
@@ -2270,7 +2292,7 @@ int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K
     fp.planes = dP; fp.S = S; fp.Mb = Mb; fp.N = N; fp.x = dx; fp.K = K; fp.wsum = dws; fp.ep = epi0();
     fp.ep.bias = dB; fp.ep.outf = dO; fp.ep.out = dfr; fp.ep.ldo = N;
     if (slice_stats && mode != 2) {
-        if (S > 16) { hipFree(dst); return fail(c, CW_ERR_INVALID, "cw_test_skinny: slice statistics need S <= 16"); }
+        if (S > 16) { return fail(c, CW_ERR_INVALID, "cw_test_skinny: slice statistics need S <= 16"); }
         sp.stats = dst; fp.stats = dst;
     }
     const int epi = mode == 1 ? EPI_GELU_FRAG : EPI_STORE_F32;
@@ -2324,16 +2346,16 @@ int32_t cw_test_skinny(cw_ctx* c, int32_t mode, int32_t Mb, int32_t N, int32_t K
         }
         if (r != CW_OK) fail(c, r, "cw_test_skinny: timing graph failed");
     }
-    hipFree(dx); hipFree(dW); hipFree(dWp); hipFree(dO); hipFree(dB); hipFree(dws); hipFree(dP); hipFree(dxf); hipFree(dfr); hipFree(dst);
     return r;
 }
 
 int32_t cw_test_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, const float* q, const float* k, const float* v, float* out) {
     const int S_pad = (S + 63) & ~63;
     const size_t e = c->esz, nh = (size_t)B * H * S_pad * 64;
+    DevScope mem;
     void *dq = nullptr, *dk = nullptr, *dv = nullptr, *dout = nullptr;
-    HIPCHK(c, hipMalloc(&dq, nh * e)); HIPCHK(c, hipMalloc(&dk, nh * e)); HIPCHK(c, hipMalloc(&dv, nh * e));
-    HIPCHK(c, hipMalloc(&dout, (size_t)B * S * H * 64 * e));
+    HIPCHK(c, mem.get(&dq, nh * e)); HIPCHK(c, mem.get(&dk, nh * e)); HIPCHK(c, mem.get(&dv, nh * e));
+    HIPCHK(c, mem.get(&dout, (size_t)B * S * H * 64 * e));
     HIPCHK(c, hipMemset(dq, 0, nh * e)); HIPCHK(c, hipMemset(dk, 0, nh * e)); HIPCHK(c, hipMemset(dv, 0, nh * e));
     for (int bh = 0; bh < B * H; ++bh) {   // inputs are [B][H][S][64]
         CWCHK(c, upload_T(c, dq, (size_t)bh * S_pad * 64, q + (size_t)bh * S * 64, (size_t)S * 64));
@@ -2357,7 +2379,6 @@ int32_t cw_test_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, const floa
         }
     }
     if (r == CW_OK) r = download_T(c, dout, 0, out, (size_t)B * S * H * 64);
-    hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout);
     return r;
 }
 
@@ -2371,10 +2392,11 @@ int32_t cw_test_cross_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, int3
     const size_t nkv = (size_t)Bk * H * S * 64;
     float *dq = nullptr, *dpo = nullptr, *dml = nullptr, *dal = nullptr, *daml = nullptr; void *dk = nullptr, *dv = nullptr;
     int *dslot = nullptr, *dpos = nullptr;
-    HIPCHK(c, hipMalloc((void**)&dq, (size_t)B * D * 4)); HIPCHK(c, hipMalloc(&dk, nkv * c->esz)); HIPCHK(c, hipMalloc(&dv, nkv * c->esz));
-    HIPCHK(c, hipMalloc((void**)&dpo, (size_t)ATT_NS * B * D * 4)); HIPCHK(c, hipMalloc((void**)&dml, (size_t)B * H * ATT_NS * 2 * 4));
-    HIPCHK(c, hipMalloc((void**)&dal, (size_t)B * S * 4)); HIPCHK(c, hipMalloc((void**)&daml, (size_t)B * ATT_NS * 2 * 4));
-    HIPCHK(c, hipMalloc((void**)&dslot, (size_t)H * 4)); HIPCHK(c, hipMalloc((void**)&dpos, (size_t)B * 4));
+    DevScope mem;
+    HIPCHK(c, mem.get(&dq, (size_t)B * D * 4)); HIPCHK(c, mem.get(&dk, nkv * c->esz)); HIPCHK(c, mem.get(&dv, nkv * c->esz));
+    HIPCHK(c, mem.get(&dpo, (size_t)ATT_NS * B * D * 4)); HIPCHK(c, mem.get(&dml, (size_t)B * H * ATT_NS * 2 * 4));
+    HIPCHK(c, mem.get(&dal, (size_t)B * S * 4)); HIPCHK(c, mem.get(&daml, (size_t)B * ATT_NS * 2 * 4));
+    HIPCHK(c, mem.get(&dslot, (size_t)H * 4)); HIPCHK(c, mem.get(&dpos, (size_t)B * 4));
     std::vector<int> slot(H, -1); slot[align_head] = 0;
     HIPCHK(c, hipMemcpy(dslot, slot.data(), (size_t)H * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemset(dpos, 0, (size_t)B * 4)); HIPCHK(c, hipMemset(dal, 0, (size_t)B * S * 4));
@@ -2387,10 +2409,10 @@ int32_t cw_test_cross_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, int3
     void *dk8 = nullptr, *dv8 = nullptr; float* dkvs = nullptr;
     const bool fp8 = g_test_cross_fp8 && c->bf16;
     if (fp8) {
-        HIPCHK(c, hipMalloc(&dk8, nkv)); HIPCHK(c, hipMalloc(&dv8, (size_t)Bk * cw_bf16::cw_kv8_v_bytes(H, S)));
-        HIPCHK(c, hipMalloc((void**)&dkvs, (size_t)Bk * H * 2 * 4));
+        HIPCHK(c, mem.get(&dk8, nkv)); HIPCHK(c, mem.get(&dv8, (size_t)Bk * cw_bf16::cw_kv8_v_bytes(H, S)));
+        HIPCHK(c, mem.get(&dkvs, (size_t)Bk * H * 2 * 4));
         int rq = KD(c, cw_launch_kv_quant_fp8, dk, dv, dk8, dv8, dkvs, Bk, H, S, c->st);
-        if (rq != CW_OK) { hipFree(dk8); hipFree(dv8); hipFree(dkvs); return fail(c, rq, "test_cross_attention: quantiser rejected S=%d", S); }
+        if (rq != CW_OK) { return fail(c, rq, "test_cross_attention: quantiser rejected S=%d", S); }
         p.K = dk8; p.V = dv8; p.kv_scale = dkvs;
     }
     auto launch = [&]() { return fp8 ? KD(c, cw_launch_attn_cross_split_fp8, p, c->st) : KD(c, cw_launch_attn_cross_split, c->bf16, p, c->st); };
@@ -2415,8 +2437,6 @@ int32_t cw_test_cross_attention(cw_ctx* c, int32_t B, int32_t H, int32_t S, int3
                        hipMemcpy(align, dal, (size_t)B * S * 4, hipMemcpyDeviceToHost) != hipSuccess ||
                        hipMemcpy(align_ml, daml, (size_t)B * ATT_NS * 2 * 4, hipMemcpyDeviceToHost) != hipSuccess))
         r = fail(c, CW_ERR_HIP, "test_cross_attention copy");
-    hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dpo); hipFree(dml); hipFree(dal); hipFree(daml); hipFree(dslot); hipFree(dpos);
-    if (dk8) hipFree(dk8); if (dv8) hipFree(dv8); if (dkvs) hipFree(dkvs);
     return r;
 }
 

@@ -172,7 +172,7 @@ struct MlpPairParams {
     int* err;              // set to 1 when a block gave up waiting at the barrier (never expected; results are then invalid)
     int Mb, D, F;
     int wpk;               // W1 / W2 are fragment-major
-    int fence;             // 1: agent-scope acquire fence behind the group barrier (round-3 behaviour, A/B: CW_MLP_PAIR=2)
+    int fence;             // 1: agent-scope acquire fence behind the group barrier (round-3 behaviour, A/B: CW_MLP_PAIR_FENCE=1)
 };
 
 // decfuse.hip: decode GEMV for 17..64 rows (beam search: items x hypotheses) without the per-GEMV preparation launch.

@@ -37,6 +37,7 @@ Switches read_switches() {
     s.cross_mfma1 = flag("CW_CROSS_MFMA1");
     s.cross_lds_pad = num("CW_CROSS_LDS_PAD", 0);
     s.cross8_nsb = num("CW_CROSS8_NSB", 0);
+    s.dl_depth = num("CW_DL_DEPTH", 4);
     s.no_glds = flag("CW_NO_GLDS");
     s.no_gemm256 = flag("CW_NO_GEMM256");
     s.no_gemm_pp = flag("CW_NO_GEMM_PP");
@@ -52,6 +53,16 @@ Switches read_switches() {
     s.mel_dbg = num("CW_MEL_DBG", 0);
     s.test_gemm_reps = num("CW_TEST_GEMM_REPS", 0);
     s.test_attn_reps = num("CW_TEST_ATTN_REPS", 0);
+    // numeric switches are divisors / sizes in the launchers: keep them in the range the launch code is written for
+    if (s.gemv_loop_cap < 1) s.gemv_loop_cap = 1;
+    if (s.fc2_ksplit < 0) s.fc2_ksplit = 0;
+    if (s.cross_lds_pad < 0) s.cross_lds_pad = 0;
+    if (s.cross_lds_pad > 150 * 1024) s.cross_lds_pad = 150 * 1024;
+    if (s.stack_nt3 < 0 || s.stack_nt3 > 3) s.stack_nt3 = 0;
+    if (s.stack_nt5 < 0 || s.stack_nt5 > 3) s.stack_nt5 = 0;
+    if (s.prefetch < 0) s.prefetch = 0;
+    if (s.test_gemm_reps < 0) s.test_gemm_reps = 0;
+    if (s.test_attn_reps < 0) s.test_attn_reps = 0;
     return s;
 }
 

@@ -1,5 +1,8 @@
-// A/B switches of the kernel launchers and the engine.  The launchers read them ONCE per process (first use), a context
-// reads its own when it is created (cw_create) -- no launch path calls getenv.  Every switch defaults to the fast path; DESIGN.md "A/B switches" lists what each
+// A/B switches of the kernel launchers and the engine.  TWO LIFETIMES, by group (see the struct): the "engine" group is read when a
+// context is created (cw_create -> read_switches()): setting the environment before Engine() selects it per context, which is how
+// the differential tests build two engines in one process.  Every other group is read by the kernel launchers ONCE per process
+// (cw_switches(), first use) and a later change of the environment is ignored -- the tests flip those in-process through
+// cw_test_set_option instead.  No launch path calls getenv.  Every switch defaults to the fast path; DESIGN.md "A/B switches" lists what each
 // one selects and the profile that measured it.
 #pragma once
 
@@ -11,7 +14,7 @@ struct Switches {
     int skinny, prefetch, prefetch_wide, prefetch_what, stack_nt3, stack_nt5;
     // attention launchers
     bool attn_v1, anc_attn_v1, cross_per_row, cross_valu, cross_no_tr, cross8_valu, cross_mfma1;
-    int cross_lds_pad, cross8_nsb;
+    int cross_lds_pad, cross8_nsb, dl_depth;
     // GEMM / GEMV launchers
     bool no_glds, no_gemm256, no_gemm_pp, no_gemm_8ph, gemm_w128, no_gemv_loop, comb_nt2, mt_no_prea;
     int gemv_loop_cap, fc2_ksplit;

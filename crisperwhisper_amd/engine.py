@@ -142,14 +142,28 @@ class Engine:
         if getattr(self, "_enc_fp8", False):
             self.set_encoder_gemm_fp8(self._enc_fp8)
 
-    def set_encoder_gemm_fp8(self, on):
+    _ENC8_BITS = {"qkv": 1, "fc1": 2, "fc2": 4, "cross_kv": 8}
+
+    def set_encoder_gemm_fp8(self, on, mask: Optional[int] = None):
         """(Re)build the e4m3 copies of the resident encoder / cross-K/V weights and switch the encoder GEMMs to them, or back.
-        ``on``: True = every GEMM; a str of names out of "qkv", "fc1", "fc2", "cross_kv" joined by "+" (or an int mask: 1 q/k/v, 2 fc1,
-        4 fc2, 8 cross-K/V projection) = that subset.  "fc1+fc2" is the subset that reproduces every reference clip of the batch-64
-        workload (profiles/r04_fp8_sweep.txt)."""
-        if isinstance(on, str):
-            on = sum({"qkv": 1, "fc1": 2, "fc2": 4, "cross_kv": 8}[t] for t in on.split("+") if t)
-        value = (1 if on else 0) if isinstance(on, bool) else (16 + int(on) if int(on) > 0 else 0)
+        ``on``: True (or the legacy int 1) = every GEMM, False / 0 = none; a str of names out of "qkv", "fc1", "fc2", "cross_kv"
+        joined by "+" = that subset.  ``mask`` (keyword) gives the subset as bits instead: 1 q/k/v, 2 fc1, 4 fc2, 8 cross-K/V
+        projection.  "fc1" (together with the e4m3 cross-attention cache) is the largest subset that reproduces every reference
+        clip of the batch-64 workload (profiles/r04_fp8_sweep.txt: 64 / 64; "fc1+fc2" is at 62-63 / 64)."""
+        if mask is not None:
+            if isinstance(mask, bool) or not 0 <= int(mask) <= 15:
+                raise ValueError(f"mask must be a bit mask in 0..15 (1 q/k/v, 2 fc1, 4 fc2, 8 cross-K/V), not {mask!r}")
+            value = 16 + int(mask) if int(mask) > 0 else 0
+        elif isinstance(on, str):
+            names = [t for t in on.split("+") if t]
+            unknown = [t for t in names if t not in self._ENC8_BITS]
+            if unknown or not names:
+                raise ValueError(f"unknown encoder GEMM name(s) {unknown or on!r}: choose from {sorted(self._ENC8_BITS)} joined by '+'")
+            value = 16 + sum(self._ENC8_BITS[t] for t in set(names))
+        elif isinstance(on, (bool, np.bool_)) or on in (0, 1):
+            value = 1 if on else 0
+        else:
+            raise ValueError(f"set_encoder_gemm_fp8({on!r}): pass True / False, a '+'-joined name list, or mask=<bits>")
         self._chk(self.lib.cw_set_option(self.ctx, b"encoder_gemm_fp8", value))
 
     def check_weights(self):

@@ -44,7 +44,7 @@ def main():
             eng.load_state_dict(W)
             if mask:
                 eng.check_weights()
-                eng.set_encoder_gemm_fp8(int(mask))
+                eng.set_encoder_gemm_fp8(True, mask=int(mask))
             nf = eng.upload_pcm(clips)
 
             def one():
