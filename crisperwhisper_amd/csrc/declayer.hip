@@ -30,9 +30,41 @@ typedef unsigned long long dl_u64_t;
 #define DL_THREADS 1024
 #define DL_SPIN_LIMIT (1 << 17)
 
+// Development aid (make EXTRA=-DCW_PHASE_TIMING, tools/dl_phase_probe.py): lane 0 of waves 0 (chain), 4 and 8 (K/V waves of the two
+// groups) of every workgroup stamps the 100 MHz wall clock at the phase boundaries; cw_debug_dl_phases copies the stamps out.
+#if defined(CW_PHASE_TIMING) && !defined(CW_F16)
+__device__ unsigned long long g_dl_phase[256 * 3 * 16];
+#define DLPH(i)                                                                                                     \
+    do {                                                                                                            \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {                                                          \
+            const int w_ = threadIdx.x >> 6;                                                                        \
+            if (w_ == 0 || w_ == 4 || w_ == 8) g_dl_phase[(blockIdx.x * 3 + (w_ >> 2)) * 16 + (i)] = wall_clock64(); \
+        }                                                                                                           \
+    } while (0)
+extern "C" int cw_debug_dl_phases(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dl_phase), sizeof(unsigned long long) * 256 * 3 * 16);
+}
+#define DLPHV(i, v)                                                                                                 \
+    do {                                                                                                            \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && (threadIdx.x >> 6) == 0) g_dl_phase[(blockIdx.x * 3) * 16 + (i)] = (unsigned long long)(v); \
+    } while (0)
+#else
+#define DLPH(i) do { } while (0)
+#define DLPHV(i, v) do { } while (0)
+#endif
+
 __device__ static inline void dl_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// The same request in inline assembly, invisible to hipcc: its waitcnt pass cannot count LDS-DMA issued in a loop and answers every
+// later LDS read ("may alias the DMA destination") with s_waitcnt vmcnt(0) -- which here would drain the sixteen K/V loads the
+// wave carries across the barrier.  The caller orders the destination by its own vmcnt wait + barrier.  lds_wave_base: wave-uniform.
+__device__ static inline void dl_glds16_asm(const void* gsrc, void* lds_wave_base) {
+    unsigned keep;
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(m0v) : "memory");
 }
 // workgroup barrier WITHOUT the workgroup-scope fence of __syncthreads(): that fence drains vmcnt, and twelve of the sixteen
 // waves carry 16 K/V loads each across every barrier of the chain.  LDS traffic is ordered by lgkmcnt alone.
@@ -140,6 +172,7 @@ __device__ __forceinline__ void dl_cross_items(const DecLayerParams& p, const Dl
         }
         if (lane == 0) c_redl[slot_i * 8 + gw] = lsum;
         dl_barrier();
+        DLPH(11 + s);
         if (it[s].valid) {
             if (gt < 64) {
                 float r = 0.f;
@@ -170,6 +203,18 @@ __device__ __forceinline__ void dl_cross_items(const DecLayerParams& p, const Dl
         if (v_) vr[s_][u_].ld(Vp[s_] + ro_); else kr[s_][u_].ld(Kp[s_] + ro_);                                              \
     } while (0)
 
+__device__ static inline DlItem dl_item(const DecLayerParams& p, int i, int n_items, int per) {
+    DlItem t;
+    t.valid = i < n_items;
+    const int ic = t.valid ? i : 0;
+    t.h = ic % p.H; t.b = (ic / p.H) % p.Mb; t.sp = ic / (p.H * p.Mb);   // = blockIdx (x, y, z) of attn_cross_split_kernel
+    t.klo = t.sp * per;
+    t.nk = min(p.n_keys, t.klo + per) - t.klo;
+    t.aslot = (p.align_out && t.valid) ? p.align_slot[t.h] : -1;
+    t.arow = p.pos[t.b];
+    return t;
+}
+
 template <int NSLOT, int PER_LANE, int DEPTH>
 __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -179,23 +224,24 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..15
     const int grp = wave >> 3, gw = wave & 7, gt = tid & 511;       // 8-wave group = one attn_cross_split block
     const bool chain = wave < 4;
+    // the chain waves' vector-memory instructions go first: the K/V waves keep the CU's memory queue full from entry to exit, and
+    // an instruction of equal priority waits its turn among sixteen waves (phase stamps: 2.9 us to ISSUE 20 requests)
+    if (chain) __builtin_amdgcn_s_setprio(3);
     const int l15 = lane & 15, g = lane >> 4;
     const int cu = blockIdx.x, G = gridDim.x;
     const unsigned tag = (p.epoch[0] << 6) | (unsigned)p.layer;
 
     // ---- LDS carve (one workgroup per CU: 160 KB are ours)
-    unsigned char* wS = dsm;                                         // [K/32][64 lanes][16 B] weight tile, fragment-major
-    float* xraw = (float*)(wS + (size_t)K * 32);                     // [8][K] f32 rows as they lie in HBM (+ pad to 1 KB)
-    const size_t xraw_bytes = (((size_t)8 * K * 4) + 1023) & ~(size_t)1023;
     const int xs_stride = K + 8;
-    bf16_t* xs = (bf16_t*)((unsigned char*)xraw + xraw_bytes);       // [16][K+8]
-    float* red = (float*)((unsigned char*)xs + (size_t)16 * xs_stride * 2);   // [4 waves][4][64]
+    bf16_t* xs = (bf16_t*)dsm;                                       // [16][K+8] activation rows of the tile, 16 bit
+    float* red = (float*)(dsm + (size_t)16 * xs_stride * 2);         // [4 waves][4][64]
     float* smean = red + 4 * 4 * 64;                                 // [16]
     float* c_smax = smean + 16;                                      // [4 items][8 waves]
     float* c_redl = c_smax + 32;                                     // [4][8]
     float* c_q = c_redl + 32;                                        // [4][64] finished queries
     float* c_red = c_q + 4 * 64;                                     // [4][8][64]
-    unsigned* cb = (unsigned*)(c_red + 4 * 8 * 64);                  // arrival counter of the chain waves
+    unsigned* cb = (unsigned*)(c_red + 4 * 8 * 64);                  // arrival counter of the chain waves (+ pad to 16 B)
+    unsigned char* kvL = (unsigned char*)(cb + 4);                   // [4 chain waves][16 rows][64 lanes][16 B]: their share of K/V
 
     // ---- work of this CU: cross-attention items cu, cu + G, cu + 2G, cu + 3G (group 0: the first two); one tile, dealt from
     // the END of the grid because the last CUs hold one item less
@@ -203,16 +249,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
     DlItem it[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int i = cu + G * (2 * grp + s);
-        it[s].valid = i < n_items;
-        const int ic = it[s].valid ? i : 0;
-        it[s].h = ic % H; it[s].b = (ic / H) % Mb; it[s].sp = ic / (H * Mb);   // = blockIdx (x, y, z) of attn_cross_split_kernel
-        it[s].klo = it[s].sp * per;
-        it[s].nk = min(p.n_keys, it[s].klo + per) - it[s].klo;
-        it[s].aslot = (p.align_out && it[s].valid) ? p.align_slot[it[s].h] : -1;
-        it[s].arow = p.pos[it[s].b];
-    }
+    for (int s = 0; s < 2; ++s) it[s] = dl_item(p, cu + G * (2 * grp + s), n_items, per);
     const int n_tiles = 3 * TD;
     const int my_tile = G - 1 - cu;
     const bool has_tile = my_tile < n_tiles;
@@ -221,21 +258,37 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
     const int steps = K >> 7, nvec = K >> 2;
     const int sub = gt & 7, kg = gt >> 3;                            // 8 lanes per key row, 64 key groups per item
     DlRaw8 kr[2][4], vr[2][4];
-    const bf16_t* Kp[2];
-    const bf16_t* Vp[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const size_t o = (((size_t)it[s].b * H + it[s].h) * p.n_keys + it[s].klo) * 64 + sub * 8;
-        Kp[s] = (const bf16_t*)p.K + o;
-        Vp[s] = (const bf16_t*)p.V + o;
-    }
+    DLPH(0);
     if (tid == 0) *cb = 0u;
     dl_barrier();
+    DLPH(1);
 
     if (!chain) {
-        // ---- the twelve K/V waves: 16 rows of 16 B per lane, at most DEPTH of them in flight per wave.  A CU takes in ~25-45 GB/s
-        // however much it has asked for; what a deeper queue buys is only a longer wait for the chain waves' polls
-        // and DMA behind it (MI355X_MICROARCH.md, row gather-pass: "thin the loader while its CU gathers").
+        // ================= the twelve K/V waves =================
+        // (a) the chain waves' share of group 0's rows goes to LDS by DMA, requested here and FIRST: a chain wave that carried
+        // these 16 requests itself would find every poll queued behind them (vector memory returns in order)
+        {
+            const DlItem ga_ = dl_item(p, cu, n_items, per), gb_ = dl_item(p, cu + G, n_items, per);
+            for (int n = wave - 4; n < 64; n += 12) {
+                const int w = n >> 4, idx = n & 15;                 // row `idx` of chain wave w
+                const int s_ = idx >> 3, v_ = (idx >> 2) & 1, u_ = idx & 3;
+                const int cgt = w * 64 + lane, csub = cgt & 7, ckg = cgt >> 3;
+                const int gb0 = s_ ? gb_.b : ga_.b, gh0 = s_ ? gb_.h : ga_.h, gk0 = s_ ? gb_.klo : ga_.klo, gn0 = s_ ? gb_.nk : ga_.nk;
+                const size_t o = (((size_t)gb0 * H + gh0) * p.n_keys + gk0 + min(ckg + u_ * 64, gn0 - 1)) * 64 + csub * 8;
+                dl_glds16_asm((const bf16_t*)(v_ ? p.V : p.K) + o, kvL + (size_t)n * 1024);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (b) their own 16 rows of 16 B per lane, at most DEPTH in flight (A/B: the depth does not matter, the CU's memory queue
+        // is full either way -- profiles/r05_declayer_phases.txt)
+        const bf16_t* Kp[2];
+        const bf16_t* Vp[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const size_t o = (((size_t)it[s].b * H + it[s].h) * p.n_keys + it[s].klo) * 64 + sub * 8;
+            Kp[s] = (const bf16_t*)p.K + o;
+            Vp[s] = (const bf16_t*)p.V + o;
+        }
 #define DL_STEP(idx)                                                                                                          \
         do {                                                                                                                  \
             if ((idx) >= DEPTH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");                              \
@@ -244,14 +297,18 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
         DL_STEP(0); DL_STEP(1); DL_STEP(2); DL_STEP(3); DL_STEP(4); DL_STEP(5); DL_STEP(6); DL_STEP(7);
         DL_STEP(8); DL_STEP(9); DL_STEP(10); DL_STEP(11); DL_STEP(12); DL_STEP(13); DL_STEP(14); DL_STEP(15);
 #undef DL_STEP
-        dl_barrier();                                               // queries are in c_q
+        DLPH(2);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // the DMA (issued first, returned first) is in LDS
+        dl_barrier();                                               // queries are in c_q, the chain waves may read their rows
+        DLPH(10);
         dl_cross_items(p, it, kr, vr, grp, gw, gt, lane, c_q, c_smax, c_redl, c_red);
         return;
     }
 
     // ================= chain waves =================
-    // ---- (0) requests: per-column constants first (a few bytes, but a memory round trip each if asked for where they are used),
-    // then the LDS-DMA of the tile (K * 32 bytes, contiguous in the fragment-major matrix) and of the activation rows
+    // ---- (0) the tile exactly as gemv_stack_kernel takes it: per-column constants, activation rows, weight fragments -> registers,
+    // every load unconditional and in flight before the first wait
     const float* __restrict__ bias = si == 0 ? p.qa_bias : (si == 2 ? p.bo : nullptr);
     const float* __restrict__ wsum = si == 0 ? p.q_wsum : nullptr;
     const int ncl = tl * 16 + l15;
@@ -259,60 +316,72 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
     const int it_w = cu + G * wave;                                  // chain wave w finishes the query of item slot w
     const bool q_mine = it_w < n_items;
     const int qh = q_mine ? it_w % H : 0, qb_row = q_mine ? (it_w / H) % Mb : 0;
+    const float qw1 = p.qw[(size_t)qh * 64 + lane], qc1 = p.qbias[(size_t)qh * 64 + lane];
     if (has_tile) {
         bias_v = bias ? bias[ncl] : 0.f;
         wsum_v = wsum ? wsum[ncl] : 0.f;
         const int m = g * 4 + wave;
         if (si == 2 && m < Mb) resid_v = p.x[(size_t)m * K + ncl];
-    }
-    const float qw1 = p.qw[(size_t)qh * 64 + lane], qc1 = p.qbias[(size_t)qh * 64 + lane];
-    if (has_tile) {
-        const unsigned char* wsrc = (const unsigned char*)p.Ws + (size_t)my_tile * (K >> 5) * 1024;
-        for (int f = wave; f < (K >> 5); f += 4) dl_glds16(wsrc + (size_t)f * 1024 + lane * 16, wS + (size_t)f * 1024);
-        const unsigned char* xsrc = (const unsigned char*)(si == 0 ? p.x : p.a);
-        const int total = Mb * K * 4, nch = (total + 1023) >> 10;
-        for (int ch = wave; ch < nch; ch += 4)
-            dl_glds16(xsrc + min(ch * 1024 + lane * 16, total - 16), (unsigned char*)xraw + (size_t)ch * 1024);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        dl_chain_sync(cb, 1, lane);
-
-        // ---- (1) rows -> 16 bit -> LDS (gemv_stack_kernel: wave w owns rows w, w + 4; centred rounding of offset rows)
+        const float* __restrict__ x = si == 0 ? p.x : p.a;
+        float4 xv[2][PER_LANE];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = wave + 4 * i;
-            const int rc = row < Mb ? row : Mb - 1;
-            float4 xv[PER_LANE];
+            int row = wave + 4 * i;
+            row = row < Mb ? row : Mb - 1;
 #pragma unroll
             for (int c = 0; c < PER_LANE; ++c) {
                 int v4 = lane + 64 * c;
                 v4 = v4 < nvec ? v4 : nvec - 1;
-                xv[c] = *(const float4*)(xraw + (size_t)rc * K + v4 * 4);
+                xv[i][c] = *(const float4*)(x + (size_t)row * K + v4 * 4);
             }
-            if (wsum) {
+        }
+        dl_u32x4_t wq[NSLOT][4];
+        const bf16_t* __restrict__ W = (const bf16_t*)p.Ws;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int step = wave + 4 * s;
+            step = step < steps ? step : steps - 1;
+            const dl_u32x4_t* wp = (const dl_u32x4_t*)(W + ((((size_t)my_tile * (K >> 5)) + step * 4) * 64 + lane) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        DLPH(2);
+        // ---- (1) rows -> 16 bit -> LDS (wave w owns rows w, w + 4; centred rounding of offset rows)
+        if (wsum) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
                 float sx = 0.f, sq = 0.f;
 #pragma unroll
                 for (int c = 0; c < PER_LANE; ++c)
                     if (lane + 64 * c < nvec) {
-                        sx += (xv[c].x + xv[c].y) + (xv[c].z + xv[c].w);
-                        sq += (xv[c].x * xv[c].x + xv[c].y * xv[c].y) + (xv[c].z * xv[c].z + xv[c].w * xv[c].w);
+                        sx += (xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w);
+                        sq += (xv[i][c].x * xv[i][c].x + xv[i][c].y * xv[i][c].y) + (xv[i][c].z * xv[i][c].z + xv[i][c].w * xv[i][c].w);
                     }
                 float mu = wave_sum(sx) / (float)K;
                 if (2.f * mu * mu < wave_sum(sq) / (float)K) mu = 0.f;
 #pragma unroll
-                for (int c = 0; c < PER_LANE; ++c) { xv[c].x -= mu; xv[c].y -= mu; xv[c].z -= mu; xv[c].w -= mu; }
-                if (lane == 0) smean[row] = mu;
+                for (int c = 0; c < PER_LANE; ++c) { xv[i][c].x -= mu; xv[i][c].y -= mu; xv[i][c].z -= mu; xv[i][c].w -= mu; }
+                if (lane == 0) smean[wave + 4 * i] = mu;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave + 4 * i;
 #pragma unroll
             for (int c = 0; c < PER_LANE; ++c) {
                 int v4 = lane + 64 * c;
                 v4 = v4 < nvec ? v4 : nvec - 1;
+                const float4 v = xv[i][c];
                 ushort4 o;
-                o.x = f32_to_bf16(xv[c].x); o.y = f32_to_bf16(xv[c].y); o.z = f32_to_bf16(xv[c].z); o.w = f32_to_bf16(xv[c].w);
+                o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
                 *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
             }
         }
-        dl_chain_sync(cb, 2, lane);
-        // ---- (2) MFMA over the wave's K steps w, w + 4, w + 8; B fragments straight from the DMA image
+        DLPH(3);
+        dl_chain_sync(cb, 1, lane);
+        DLPH(5);
+        // ---- (2) MFMA over the wave's K steps w, w + 4, w + 8
         {
             f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -323,15 +392,15 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
-                        const bf16x8_t b = *(const bf16x8_t*)(wS + ((size_t)(step * 4 + j) * 64 + lane) * 16);
-                        acc = cw_mfma_16x16x32(a, b, acc);
+                        acc = cw_mfma_16x16x32(a, __builtin_bit_cast(bf16x8_t, wq[s][j]), acc);
                     }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
         }
-        dl_chain_sync(cb, 3, lane);
+        dl_chain_sync(cb, 2, lane);
+        DLPH(6);
         // ---- (3) epilogue: cross-wave sum in gemv_stack_kernel's order, results leave as granules (qa, qb, LayerNorm partial
         // sums of x1) and as the plain residual rows x1 that later launches read
         {
@@ -363,11 +432,11 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
             }
         }
     }
+    DLPH(7);
     // ---- (4) chain wave w finishes the query of item slot w (attn_cross_split_kernel<.., FUSED>: lane c = column c of the head):
     //     q = rstd(x1) (qa + qb - mean(x1) qw) + qbias
-    // from the granules of the 8 tiles that hold the head's columns and of the TD tiles that hold the row's partial sums.  Its own
-    // K/V rows go out four at a time BETWEEN the polls (vector memory returns in order: a poll behind 16 rows would wait for all
-    // of them), so most of them are in by the time the query is.
+    // from the granules of the 8 tiles that hold the head's columns and of the TD tiles that hold the row's partial sums.  The
+    // wave's own memory queue is empty while it polls.
     {
         const size_t col = (size_t)qh * 64 + lane;
         const dl_u64_t* ga = p.gq + ((size_t)0 * 16 + qb_row) * K + col;
@@ -376,29 +445,18 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
         const dl_u64_t* g1 = p.gps + ((size_t)min(lane + 64, TD - 1) * 16 + qb_row) * 2;
         dl_u64_t va = 0, vb = 0, v00 = 0, v01 = 0, v10 = 0, v11 = 0;
         bool ready = !q_mine;
-#define DL_POLL()                                                                                                             \
-        do {                                                                                                                  \
-            va = dl_gran_ld(ga); vb = dl_gran_ld(gb);                                                                         \
-            v00 = dl_gran_ld(g0); v01 = dl_gran_ld(g0 + 1);                                                                   \
-            v10 = dl_gran_ld(g1); v11 = dl_gran_ld(g1 + 1);                                                                   \
-            const bool ok_ = (unsigned)(va >> 32) == tag && (unsigned)(vb >> 32) == tag && (unsigned)(v00 >> 32) == tag &&    \
-                             (unsigned)(v01 >> 32) == tag && (unsigned)(v10 >> 32) == tag && (unsigned)(v11 >> 32) == tag;    \
-            ready = __all(ok_);                                                                                               \
-        } while (0)
-        DL_KV_LOAD(0); DL_KV_LOAD(1); DL_KV_LOAD(2); DL_KV_LOAD(3);
-        if (!ready) DL_POLL();
-        DL_KV_LOAD(4); DL_KV_LOAD(5); DL_KV_LOAD(6); DL_KV_LOAD(7);
-        if (!ready) DL_POLL();
-        DL_KV_LOAD(8); DL_KV_LOAD(9); DL_KV_LOAD(10); DL_KV_LOAD(11);
-        if (!ready) DL_POLL();
-        DL_KV_LOAD(12); DL_KV_LOAD(13); DL_KV_LOAD(14); DL_KV_LOAD(15);
+        int npoll = 0;
 #pragma unroll 1
         for (int spins = 0; !ready; ++spins) {
             if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }
-            if (spins) __builtin_amdgcn_s_sleep(4);
-            DL_POLL();
+            va = dl_gran_ld(ga); vb = dl_gran_ld(gb);
+            v00 = dl_gran_ld(g0); v01 = dl_gran_ld(g0 + 1);
+            v10 = dl_gran_ld(g1); v11 = dl_gran_ld(g1 + 1);
+            const bool ok = (unsigned)(va >> 32) == tag && (unsigned)(vb >> 32) == tag && (unsigned)(v00 >> 32) == tag &&
+                            (unsigned)(v01 >> 32) == tag && (unsigned)(v10 >> 32) == tag && (unsigned)(v11 >> 32) == tag;
+            ready = __all(ok); ++npoll;
+            if (spins == 0) DLPH(8);
         }
-#undef DL_POLL
         if (q_mine) {
             const float qa1 = __uint_as_float((unsigned)va), qb1 = __uint_as_float((unsigned)vb);
             const float inv_d = 1.0f / (float)(H * 64);
@@ -409,15 +467,23 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
             const float rstd = 1.0f / sqrtf(var + 1e-5f);
             c_q[wave * 64 + lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
         }
+        DLPHV(13, npoll);
     }
+    DLPH(9);
     dl_barrier();
+    DLPH(10);
+    // the wave's rows of group 0's two items: out of LDS, into the registers the items read them from
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) {
+        const uint4 t = *(const uint4*)(kvL + ((size_t)(wave * 16 + idx) * 64 + lane) * 16);
+        if ((idx >> 2) & 1) vr[idx >> 3][idx & 3].a = t; else kr[idx >> 3][idx & 3].a = t;
+    }
     dl_cross_items(p, it, kr, vr, grp, gw, gt, lane, c_q, c_smax, c_redl, c_red);
 }
 #undef DL_KV_LOAD
 
 size_t cw_dec_layer_lds(int D) {
-    const size_t xraw_bytes = (((size_t)8 * D * 4) + 1023) & ~(size_t)1023;
-    return (size_t)D * 32 + xraw_bytes + (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 16 + 32 + 32 + 4 * 64 + 4 * 8 * 64 + 4) * 4;
+    return (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 16 + 32 + 32 + 4 * 64 + 4 * 8 * 64 + 4) * 4 + (size_t)4 * 16 * 1024;
 }
 
 // grid: one workgroup per CU (every workgroup must be resident: they wait for each other's granules)
@@ -435,15 +501,13 @@ int cw_launch_dec_layer(const DecLayerParams& p, int n_cu, hipStream_t st) {
         std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)dec_layer_a_kernel<NS, PL, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL((dec_layer_a_kernel<NS, PL, DP>), dim3(n_cu), dim3(DL_THREADS), lds, st, p);                          \
     } while (0)
-    // K/V rows in flight per lane of the twelve K/V waves (A/B: CW_DL_DEPTH = 2 | 4 | 6 | 8 | 16; 16 = everything at kernel entry)
-    const int depth = cw_sw::cw_switches().dl_depth;
-    if (D <= 256) DL_LAUNCH(1, 1, 4);
-    else if (D <= 768) DL_LAUNCH(2, 3, 4);
-    else if (depth == 2) DL_LAUNCH(3, 5, 2);
-    else if (depth == 6) DL_LAUNCH(3, 5, 6);
+    // K/V rows in flight per lane of the twelve K/V waves (A/B: CW_DL_DEPTH = 4 | 8 | 16; 16 = everything at kernel entry, the default)
+    const int depth = cw_sw::cw_switches().dl_depth;   // default 16
+    if (D <= 256) DL_LAUNCH(1, 1, 16);
+    else if (D <= 768) DL_LAUNCH(2, 3, 16);
+    else if (depth == 4) DL_LAUNCH(3, 5, 4);
     else if (depth == 8) DL_LAUNCH(3, 5, 8);
-    else if (depth == 16) DL_LAUNCH(3, 5, 16);
-    else DL_LAUNCH(3, 5, 4);
+    else DL_LAUNCH(3, 5, 16);
 #undef DL_LAUNCH
     return CW_OK;
 }
