@@ -482,6 +482,348 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
 }
 #undef DL_KV_LOAD
 
+// ---------------------------------------------------------------------------------------------------
+// q/k/v projection + self-attention in ONE launch (rows <= 8): grid = 3 D / 16 tiles, 512 threads.
+//   waves 0..3 of block t: the LayerNorm + GEMV tile t of gemv2_bf16_kernel<EPI_QKV_CACHE, 2, false, false, NSLOT, PER_LANE>
+//   (gemm.hip), operation for operation; the epilogue appends k / v to the self-attention cache as before AND publishes the
+//   tile as granules (q: one f32 per granule; k, v: two 16-bit cache values per granule);
+//   all 8 waves of block i < rows x heads: attn_decode_kernel<T, false> (attention.hip) for (head i % H, row i / H): the K / V
+//   rows of the history are requested at kernel entry (they depend on nothing), the query and THIS step's key / value row come
+//   from the granules of the 12 tiles of the head, polled by wave 4 (whose memory queue holds nothing else by then).
+// Unlike stage A above the hand-off happens on a quiet memory system: every block has taken in its 80 KB before anybody polls.
+// Producers never wait, consumers wait only after they have produced: no residency requirement beyond "every block gets a slot
+// eventually".
+// ---------------------------------------------------------------------------------------------------
+#define QS_THREADS 512
+#define QS_GROUPS (QS_THREADS / 8)
+#define QS_PRE 2
+
+template <int NSLOT, int PER_LANE>
+__global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qsm[];
+    const int K = p.D, Mb = p.Mb, H = p.H, N = 3 * K, cap = p.cap;
+    const int xs_stride = K + 8;
+    bf16_t* xs = (bf16_t*)qsm;                                       // [16][K+8]
+    float* red = (float*)(qsm + (size_t)16 * xs_stride * 2);         // [4 waves][4][64]
+    float* s_q = red + 4 * 4 * 64;                                   // [64] query of the item
+    bf16_t* s_kn = (bf16_t*)(s_q + 64);                              // [64] this step's key row, [64] value row
+    bf16_t* s_vn = s_kn + 64;
+    float* dsm = (float*)(s_vn + 64);                                // attn_decode_kernel's scratch: scores [cap rounded] | red [64][64] | scratch [64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bid = blockIdx.x;
+    const unsigned tag = (p.epoch[0] << 6) | (unsigned)p.layer;
+    const int n0 = bid * 16;
+    const int steps = K >> 7, nvec = K >> 2;
+    const int nn = n0 + l15, ncl = nn < N ? nn : N - 1;
+
+    // ---- self-attention item of this block (if any): history rows first into the queue?  No: the tile's loads go first, they
+    // are the critical path of every OTHER block's item as well
+    const int n_items = Mb * H;
+    const bool has_item = bid < n_items;
+    const int ih = has_item ? bid % H : 0, ib = has_item ? bid / H : 0;
+    const int sub = tid & 7, grp = tid >> 3;
+    const bf16_t* Kh = (const bf16_t*)p.sk + ((size_t)ib * H + ih) * cap * 64;
+    const bf16_t* Vh = (const bf16_t*)p.sv + ((size_t)ib * H + ih) * cap * 64;
+
+    float bias_v = 0.f;
+    float4 xv[2][PER_LANE];
+    dl_u32x4_t wq[NSLOT][4];
+    if (wave < 4) {
+        bias_v = p.bias ? p.bias[ncl] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = wave + 4 * i;
+            row = row < Mb ? row : Mb - 1;
+#pragma unroll
+            for (int c = 0; c < PER_LANE; ++c) {
+                int v4 = lane + 64 * c;
+                v4 = v4 < nvec ? v4 : nvec - 1;
+                xv[i][c] = *(const float4*)(p.x + (size_t)row * K + v4 * 4);
+            }
+        }
+        const bf16_t* __restrict__ W = (const bf16_t*)p.W;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int step = wave + 4 * s;
+            step = step < steps ? step : steps - 1;
+            const dl_u32x4_t* wp = (const dl_u32x4_t*)(W + ((((size_t)(ncl >> 4) * (K >> 5)) + step * 4) * 64 + g * 16 + (ncl & 15)) * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * 64];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    DlRaw8 kpre[QS_PRE], vpre[QS_PRE];
+#pragma unroll
+    for (int u = 0; u < QS_PRE; ++u) kpre[u].ld(Kh + (size_t)min(grp + u * QS_GROUPS, cap - 1) * 64 + sub * 8);
+#pragma unroll
+    for (int u = 0; u < QS_PRE; ++u) vpre[u].ld(Vh + (size_t)min(grp + u * QS_GROUPS, cap - 1) * 64 + sub * 8);
+    const int n_keys = p.pos[ib] + 1;
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- tile: LayerNorm (gamma / beta folded into W / bias), rows -> 16 bit -> LDS, MFMA, cross-wave sum
+    if (wave < 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float sx = 0.f;
+#pragma unroll
+            for (int c = 0; c < PER_LANE; ++c) {
+                const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+                sx += ok * ((xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w));
+            }
+            const float mean = wave_sum(sx) / (float)K;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < PER_LANE; ++c) {
+                const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+                const float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
+                q += ok * ((a * a + b * b) + (cc * cc + d * d));
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+            const int row = wave + 4 * i;
+#pragma unroll
+            for (int c = 0; c < PER_LANE; ++c) {
+                int v4 = lane + 64 * c;
+                v4 = v4 < nvec ? v4 : nvec - 1;
+                ushort4 o;
+                o.x = f32_to_bf16((xv[i][c].x - mean) * rstd); o.y = f32_to_bf16((xv[i][c].y - mean) * rstd);
+                o.z = f32_to_bf16((xv[i][c].z - mean) * rstd); o.w = f32_to_bf16((xv[i][c].w - mean) * rstd);
+                *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
+            }
+        }
+    }
+    dl_barrier();
+    if (wave < 4) {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int step = wave + 4 * s;
+            if (step < steps) {
+                const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
+                    acc = cw_mfma_16x16x32(a, __builtin_bit_cast(bf16x8_t, wq[s][j]), acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    }
+    dl_barrier();
+    if (wave < 4) {
+        const int r = wave;
+        const float v = (red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane] + red[(2 * 4 + r) * 64 + lane] + red[(3 * 4 + r) * 64 + lane]) + bias_v;
+        const int m = g * 4 + r;
+        // EPI_QKV_CACHE: which == 0 -> the query (f32), 1 / 2 -> row pos[m] of the self-attention cache (16 bit)
+        const int which = nn / K, rc = nn - which * K;
+        unsigned h16 = 0;
+        if (which != 0) h16 = f32_to_bf16(v);
+        const unsigned other = (unsigned)__shfl_xor((int)h16, 1, 64);          // the neighbouring column's 16 bits
+        if (m < Mb && nn < N) {
+            if (which == 0) {
+                dl_gran_st(p.gq + (size_t)m * K + rc, tag, __float_as_uint(v));
+            } else {
+                const int hh = rc >> 6, dd = rc & 63;
+                bf16_t* base = (bf16_t*)(which == 1 ? p.sk : p.sv);
+                base[(((size_t)m * H + hh) * cap + p.pos[m]) * 64 + dd] = (bf16_t)h16;
+                if (!(l15 & 1)) dl_gran_st(p.gkv + ((size_t)(which - 1) * 16 + m) * (K >> 1) + (rc >> 1), tag, h16 | (other << 16));
+            }
+        }
+    }
+    if (!has_item) return;                                            // (no barrier follows for the block as a whole)
+
+    // ---- the item: wave 4 gathers the query and this step's key / value row of (row ib, head ih)
+    if (wave == 4) {
+        const dl_u64_t* gqp = p.gq + (size_t)ib * K + ih * 64 + lane;
+        const dl_u64_t* gkp = p.gkv + ((size_t)(lane >> 5) * 16 + ib) * (K >> 1) + ih * 32 + (lane & 31);
+        dl_u64_t vq = 0, vk = 0;
+        bool ready = false;
+#pragma unroll 1
+        for (int spins = 0; !ready; ++spins) {
+            if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }
+            vq = dl_gran_ld(gqp); vk = dl_gran_ld(gkp);
+            ready = __all((unsigned)(vq >> 32) == tag && (unsigned)(vk >> 32) == tag);
+        }
+        s_q[lane] = __uint_as_float((unsigned)vq);
+        ((unsigned*)s_kn)[lane] = (unsigned)vk;                      // lanes 0..31: key pairs, 32..63: value pairs (s_vn follows s_kn)
+    }
+    dl_barrier();
+    // ---- attn_decode_kernel<T, false> from here on, with the row at n_keys - 1 taken from LDS instead of the cache (another
+    // CU wrote it a microsecond ago with plain stores: not visible to this CU's loads)
+    float* sc = dsm;
+    float* redd = dsm + ((cap + 63) & ~63);
+    float* scratch = redd + QS_GROUPS * 64;
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = s_q[sub * 8 + e];
+    const int kn = n_keys - 1;
+    const uint4 kn_raw = *(const uint4*)(s_kn + sub * 8), vn_raw = *(const uint4*)(s_vn + sub * 8);
+#pragma unroll
+    for (int u = 0; u < QS_PRE; ++u)
+        if (grp + u * QS_GROUPS == kn) { kpre[u].a = kn_raw; vpre[u].a = vn_raw; }
+
+    if (n_keys <= QS_PRE * QS_GROUPS) {
+        float* s_max = scratch;
+        float* red8 = redd;
+        float d[QS_PRE], mxl = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < QS_PRE; ++u) {
+            float kv[8];
+            kpre[u].cvt(kv);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t = fmaf(qv[e], kv[e], t);
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+            d[u] = (grp + u * QS_GROUPS < n_keys) ? t : -INFINITY;
+            mxl = fmaxf(mxl, d[u]);
+        }
+        mxl = wave_max(mxl);
+        if (lane == 0) s_max[wave] = mxl;
+        dl_barrier();
+        mxl = s_max[0];
+#pragma unroll
+        for (int w = 1; w < QS_THREADS / 64; ++w) mxl = fmaxf(mxl, s_max[w]);
+        float acc[8] = {};
+        float lsum = 0.f;
+#pragma unroll
+        for (int u = 0; u < QS_PRE; ++u) {
+            if (grp + u * QS_GROUPS < n_keys) {
+                const float pk = expf(d[u] - mxl);
+                if (sub == 0) lsum += pk;
+                float vv[8];
+                vpre[u].cvt(vv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[e] + dpp_mov<0x128, 0xf>(0.f, acc[e]);
+            acc[e] = xor32_sum(xor16_sum(v));
+        }
+        lsum = wave_sum(lsum);
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red8[wave * 64 + sub * 8 + e] = acc[e];
+        }
+        if (lane == 0) red8[8 * 64 + wave] = lsum;
+        dl_barrier();
+        if (tid < 64) {
+            float r = 0.f, l = 0.f;
+#pragma unroll
+            for (int w = 0; w < QS_THREADS / 64; ++w) { r += red8[w * 64 + tid]; l += red8[8 * 64 + w]; }
+            r *= 1.0f / l;
+            p.out[(size_t)ib * H * 64 + ih * 64 + tid] = r;
+        }
+        return;
+    }
+
+    // long history (> 128 keys): scores through LDS, the remaining rows four at a time
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < QS_PRE; ++u) {
+        const int k = grp + u * QS_GROUPS;
+        float kv[8];
+        kpre[u].cvt(kv);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[e], d);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if (k < n_keys) {
+            if (sub == 0) sc[k] = d;
+            mx = fmaxf(mx, d);
+        }
+    }
+    for (int k0 = grp + QS_PRE * QS_GROUPS; k0 < n_keys; k0 += 4 * QS_GROUPS) {
+        float kv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + u * QS_GROUPS, n_keys - 1);
+            uint4 raw = *(const uint4*)(Kh + (size_t)k * 64 + sub * 8);
+            if (k == kn) raw = kn_raw;
+            h16_unpack8(raw, kv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * QS_GROUPS;
+            if (k < n_keys) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(qv[e], kv[u][e], d);
+                d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+                if (sub == 0) sc[k] = d;
+                mx = fmaxf(mx, d);
+            }
+        }
+    }
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int k = tid; k < n_keys; k += QS_THREADS) { float e = expf(sc[k] - mx); sc[k] = e; sum += e; }
+    sum = block_sum(sum, scratch);
+    const float inv = 1.0f / sum;
+    float acc[8] = {};
+#pragma unroll
+    for (int u = 0; u < QS_PRE; ++u) {
+        const int k = grp + u * QS_GROUPS;
+        float vv[8];
+        vpre[u].cvt(vv);
+        const float pk = (k < n_keys) ? sc[k] * inv : 0.f;
+        if (k < n_keys) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+        }
+    }
+    for (int k0 = grp + QS_PRE * QS_GROUPS; k0 < n_keys; k0 += 4 * QS_GROUPS) {
+        float vv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + u * QS_GROUPS, n_keys - 1);
+            uint4 raw = *(const uint4*)(Vh + (size_t)k * 64 + sub * 8);
+            if (k == kn) raw = vn_raw;
+            h16_unpack8(raw, vv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * QS_GROUPS;
+            if (k < n_keys) {
+                const float pk = sc[k] * inv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[u][e], acc[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) redd[grp * 64 + sub * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        float r = 0.f;
+        for (int gI = 0; gI < QS_GROUPS; ++gI) r += redd[gI * 64 + tid];
+        p.out[(size_t)ib * H * 64 + ih * 64 + tid] = r;
+    }
+}
+
+int cw_launch_qkv_self(const QkvSelfParams& p, hipStream_t st) {
+    const int D = p.D;
+    if (p.Mb < 1 || p.Mb > 8 || D % 128 || D > 1280 || p.H * 64 != D || p.cap < 1 || p.cap > 512) return CW_ERR_INVALID;
+    if (p.Mb * p.H > 3 * (D / 16) || !p.gq || !p.gkv || !p.epoch || !p.err || !p.W || !p.x || !p.pos) return CW_ERR_INVALID;
+    const size_t lds = (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 64) * 4 + 2 * 64 * 2 +
+                       ((size_t)((p.cap + 63) & ~63) + QS_GROUPS * 64 + 64) * 4;
+    const dim3 grid(3 * (D / 16));
+#define QS_LAUNCH(NS, PL)                                                                                                   \
+    do {                                                                                                                     \
+        static std::once_flag attr;                                                                                          \
+        std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)qkv_self_kernel<NS, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); }); \
+        hipLaunchKernelGGL((qkv_self_kernel<NS, PL>), grid, dim3(QS_THREADS), lds, st, p);                                   \
+    } while (0)
+    if (D <= 256) QS_LAUNCH(1, 1);
+    else if (D <= 768) QS_LAUNCH(2, 3);
+    else QS_LAUNCH(3, 5);
+#undef QS_LAUNCH
+    return CW_OK;
+}
+
 size_t cw_dec_layer_lds(int D) {
     return (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 16 + 32 + 32 + 4 * 64 + 4 * 8 * 64 + 4) * 4 + (size_t)4 * 16 * 1024;
 }

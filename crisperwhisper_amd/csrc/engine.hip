@@ -88,8 +88,10 @@ struct cw_ctx {
     bool mlp_pair = false;          // CW_MLP_PAIR=1: fc1 + fc2 in one launch with an in-kernel group barrier (A/B: 23 us against 12.8 for two launches)
     unsigned int* d_bar = nullptr; int* d_err = nullptr;   // group barriers of mlp_pair_kernel; "a block gave up waiting" flag
     // persistent decoder-layer kernel (declayer.hip), rows <= 8: granule buffers, the epoch counter their tags carry, CU count
-    bool declayer = true;           // CW_NO_DECLAYER=1: seven launches per layer (A/B and the differential test)
-    unsigned long long *d_gq = nullptr, *d_gps = nullptr;
+    bool declayer = false;          // CW_DECLAYER=1: stage A of declayer.hip (fused stage + cross-attention in one persistent launch; bit-identical,
+                                    // measured SLOWER: 22-24 us against 18.4 for the two launches -- A/B and differential test only)
+    bool qkv_self = true;           // q/k/v projection + self-attention in one launch (declayer.hip: qkv_self_kernel); CW_NO_QKV_SELF=1: two launches
+    unsigned long long *d_gq = nullptr, *d_gps = nullptr, *d_gq2 = nullptr, *d_gkv = nullptr;
     unsigned int* d_epoch = nullptr;
     int n_cu = 0;
     int stack_nt3 = 0, stack_nt5 = 0;   // column tiles per block of the two stacked GEMVs (0 = launcher's choice; CW_STACK_NT3/5)
@@ -382,7 +384,8 @@ static int create_impl(cw_ctx* c) {
     c->wpack_enabled = !sw.no_wpack;
     c->mlp_pair = sw.mlp_pair;
     c->mlp_pair_fence = sw.mlp_pair_fence;
-    c->declayer = !sw.no_declayer;
+    c->declayer = sw.declayer;
+    c->qkv_self = !sw.no_qkv_self;
     c->stack_nt3 = sw.stack_nt3;
     c->stack_nt5 = sw.stack_nt5;
     c->prefetch = sw.prefetch;   // experiments builds only (refused above otherwise)
@@ -530,6 +533,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_bar, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_err, 4));
     {   // declayer.hip: granules are valid by tag only (never cleared); epoch 0 is never used
         CWCHK(c, dmalloc(c, &c->d_gq, (size_t)2 * 16 * D * 8)); CWCHK(c, dmalloc(c, &c->d_gps, (size_t)(D / 16) * 16 * 2 * 8));
+        CWCHK(c, dmalloc(c, &c->d_gq2, (size_t)16 * D * 8)); CWCHK(c, dmalloc(c, &c->d_gkv, (size_t)2 * 16 * (D / 2) * 8));
         CWCHK(c, dmalloc(c, &c->d_epoch, 4));
         const unsigned int one = 1;
         HIPCHK(c, hipMemcpy(c->d_epoch, &one, 4, hipMemcpyHostToDevice));
@@ -1168,6 +1172,16 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_pf[0], 0));
             CWCHK(c, launch_prefetch_layer(c, l + 1, nb));
         }
+        // rows <= 8, 16-bit engines: LN + q/k/v projection + self-attention as ONE launch (declayer.hip: qkv_self_kernel; the tiles
+        // reach the attention blocks as granules, the history rows of the cache are requested at kernel entry); bit-identical
+        const bool qs = c->qkv_self && c->bf16 && c->ln_folded && c->wpacked && nb <= 8 && c->beam_K == 0 && D <= 1280 && nb * H <= 3 * (D / 16) && TGT <= 512;
+        if (qs) {
+            QkvSelfParams qp;
+            memset(&qp, 0, sizeof(qp));
+            qp.x = xin; qp.W = L.wqkv; qp.bias = L.bqkv; qp.sk = L.sk; qp.sv = L.sv; qp.cap = TGT; qp.pos = c->d_pos; qp.out = c->dattn;
+            qp.gq = c->d_gq2; qp.gkv = c->d_gkv; qp.epoch = c->d_epoch; qp.layer = l; qp.err = c->d_err; qp.Mb = nb; qp.D = D; qp.H = H;
+            CWCHK(c, KD(c, cw_launch_qkv_self, qp, c->st));
+        } else {
         {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
             EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
             ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
@@ -1180,6 +1194,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             if (frag) p.out_frag = (unsigned short*)c->d_xfrag2;
             if (c->beam_K > 0) p.anc = c->d_anc;
             CWCHK(c, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
+        }
         }
         if (fuse) {
             const int TD = D / 16, TF = F / 16;

@@ -253,6 +253,25 @@ struct DecLayerParams {
     int Mb, D, H;
 };
 
+// declayer.hip: LayerNorm + q/k/v projection + self-attention of rows <= 8 in ONE launch (gemv2_bf16_kernel<EPI_QKV_CACHE> tiles,
+// then attn_decode_kernel per (row, head) in the first rows x heads blocks; the tiles reach the attention as granules)
+struct QkvSelfParams {
+    const float* x;            // [Mb][D] residual rows (LayerNorm gamma / beta folded into W / bias)
+    const void* W;             // [3 D][D] 16-bit fragment-major
+    const float* bias;         // [3 D]
+    void* sk;                  // self-attention cache [Mb][H][cap][64]: row pos[b] is appended, rows 0..pos[b] are attended over
+    void* sv;
+    int cap;
+    const int* pos;            // [Mb] device
+    float* out;                // [Mb][D] attention output
+    unsigned long long* gq;    // [16][D] granules: query
+    unsigned long long* gkv;   // [2][16][D / 2] granules: this step's key / value rows, two 16-bit values each
+    const unsigned int* epoch;
+    int layer;
+    int* err;
+    int Mb, D, H;
+};
+
 // mel.hip
 struct MelTables {
     const double* cos_t;  // [400]
@@ -290,6 +309,7 @@ struct MelTables {
     int cw_launch_fold_rowvec(const float* A, const float* s, float scale, const float* v, const void* W16, int N, int J, float* c_out, float* w_out, hipStream_t st); \
     int cw_launch_gemv_stack(const StackParams& p, int nt, hipStream_t st); \
     int cw_launch_dec_layer(const DecLayerParams& p, int n_cu, hipStream_t st); \
+    int cw_launch_qkv_self(const QkvSelfParams& p, hipStream_t st); \
     size_t cw_dec_layer_lds(int D); \
     int cw_launch_gemv_fc2x(const Fc2xParams& p, hipStream_t st); \
     int cw_launch_mlp_pair(const MlpPairParams& p, hipStream_t st); \

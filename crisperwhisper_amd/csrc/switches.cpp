@@ -21,7 +21,8 @@ Switches read_switches() {
     s.no_wpack = flag("CW_NO_WPACK");
     s.mlp_pair = flag("CW_MLP_PAIR");
     s.mlp_pair_fence = flag("CW_MLP_PAIR_FENCE");
-    s.no_declayer = flag("CW_NO_DECLAYER");
+    s.declayer = flag("CW_DECLAYER");
+    s.no_qkv_self = flag("CW_NO_QKV_SELF");
     s.skinny = num("CW_SKINNY", 0);
     s.prefetch = num("CW_PREFETCH", 0);
     s.prefetch_wide = num("CW_PREFETCH_WIDE", 0);

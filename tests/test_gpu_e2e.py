@@ -1218,14 +1218,17 @@ def test_logits_projection_persistent_column_loop_is_bit_identical(dt, rows):
         eng.close()
 
 
-@pytest.mark.parametrize("rows,dt", [(8, "bf16"), (8, "f16"), (5, "bf16"), (1, "bf16")])
-def test_persistent_decoder_layer_is_bit_identical(rows, dt):
-    """csrc/declayer.hip: the fused out-projection / cross-query stage and the cross-attention as ONE persistent launch (one
-    1024-thread workgroup per CU, K/V requested at kernel entry, qa / qb / LayerNorm partial sums handed across CUs as 8-byte
-    {tag, value} granules) against the same engine with CW_NO_DECLAYER=1 (the two launches it replaces).  Same arithmetic in the
-    same order, so EVERYTHING must be bit-identical: the logits of the captured steps, every token of > 2000 consecutive
-    free-running decoder forwards (five generate calls of 440 positions, graph replay -- the granule tags come from a device
-    counter), the alignment rows and the token timestamps.  A missed or stale hand-off changes bits here, not words."""
+@pytest.mark.parametrize("feature,rows,dt", [("qkv_self", 8, "bf16"), ("qkv_self", 8, "f16"), ("qkv_self", 5, "bf16"), ("qkv_self", 1, "bf16"),
+                                             ("declayer", 8, "bf16"), ("declayer", 8, "f16"), ("declayer", 3, "bf16")])
+def test_persistent_decoder_layer_is_bit_identical(feature, rows, dt):
+    """csrc/declayer.hip: decoder stages that hand their results across CUs INSIDE a launch as 8-byte {tag, value} granules.
+    qkv_self: LayerNorm + q/k/v projection + self-attention in one launch (default) against CW_NO_QKV_SELF=1 (two launches);
+    declayer: fused out-projection / cross-query stage + cross-attention in one persistent launch (CW_DECLAYER=1, one 1024-thread
+    workgroup per CU; measured slower, A/B only) against the two launches.  Same arithmetic in the same order, so EVERYTHING must
+    be bit-identical: the logits of the captured steps, every token of > 2000 consecutive free-running decoder forwards (five
+    generate calls of 440 positions -- history longer than the 128 keys of the attention's register path -- through graph replay:
+    the granule tags come from a device counter), the alignment rows and the token timestamps.  A missed or stale hand-off changes
+    bits here, not words."""
     import os
     g, v = syn.large_v3_geometry()
     g.enc_layers, g.dec_layers = 1, 4
@@ -1236,14 +1239,15 @@ def test_persistent_decoder_layer_is_bit_identical(rows, dt):
     T = TGT - 4
     clips = [syn.synth_audio(700 + i, 480000 - 20000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
     prompt = np.tile(np.array([[v.sot, v.lang_id("en"), v.transcribe]], np.int32), (rows, 1))
+    envs = {"qkv_self": ({}, {"CW_NO_QKV_SELF": "1"}), "declayer": ({"CW_DECLAYER": "1", "CW_NO_QKV_SELF": "1"}, {"CW_NO_QKV_SELF": "1"})}[feature]
     res = {}
-    for mode in ("persistent", "launches"):
-        if mode == "launches":
-            os.environ["CW_NO_DECLAYER"] = "1"
+    for mode, env in zip(("fused", "launches"), envs):
+        os.environ.update(env)
         try:
             eng = Engine(spec, dtype=dt, max_batch=rows)
         finally:
-            os.environ.pop("CW_NO_DECLAYER", None)
+            for k_ in env:
+                os.environ.pop(k_, None)
         try:
             eng.load_state_dict(W)
             out = []
@@ -1260,7 +1264,7 @@ def test_persistent_decoder_layer_is_bit_identical(rows, dt):
         finally:
             eng.close()
     steps = 0
-    for (sa, ca, aa, ta), (sb, cb, ab, tb) in zip(res["persistent"], res["launches"]):
+    for (sa, ca, aa, ta), (sb, cb, ab, tb) in zip(res["fused"], res["launches"]):
         assert np.array_equal(sa, sb), int((sa != sb).sum())
         if ca is not None:
             assert np.array_equal(ca, cb), float(np.abs(ca - cb).max())
