@@ -147,6 +147,19 @@ __device__ inline float gelu_erf(float x) {  // nn.functional.gelu default (exac
 // two VALU ops per output element and no extra traffic or synchronisation.
 __device__ inline float resid_grid(float v) { return rintf(v * 4096.0f) * (1.0f / 4096.0f); }
 
+// Sum of four squares of the LayerNorm variance, a^2 + b^2 + c^2 + d^2, with the roundings spelled out:
+//     fma(a, a, rn(b b)) + fma(c, c, rn(d d)).
+// Left to hipcc (-ffp-contract=fast) the expression (a*a + b*b) + (c*c + d*d) is contracted differently from one inlining
+// context to the next -- in one and the same kernel the first 256-column chunk of a row got v_pk_mul + v_add, the others two
+// v_fmac -- so two copies of one source line are NOT bit-identical (found by the differential test of declayer.hip: one
+// last-place difference in a variance at decoder position 313).  Every decode-time LayerNorm goes through this helper.
+__device__ inline float cw_sumsq4(float a, float b, float c, float d) {
+#pragma clang fp contract(off)
+    const float bb = b * b, dd = d * d;
+    const float ab = __builtin_fmaf(a, a, bb), cd = __builtin_fmaf(c, c, dd);
+    return ab + cd;
+}
+
 // Wave-wide reductions on the DPP path (VALU cross-lane moves, a few cycles each).  __shfl_xor compiles to
 // ds_bpermute_b32 -- an LDS-crossbar round trip of ~100+ cycles per step, 6 dependent steps per reduction: measured
 // 1.2-1.5 us for the four reductions of a fused LayerNorm, which sat on the critical path of every decode GEMV.

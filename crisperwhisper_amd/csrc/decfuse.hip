@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
             for (int c = 0; c < PER_LANE; ++c)
                 if (lane + 64 * c < nvec) {
                     sx += (xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w);
-                    sq += (xv[i][c].x * xv[i][c].x + xv[i][c].y * xv[i][c].y) + (xv[i][c].z * xv[i][c].z + xv[i][c].w * xv[i][c].w);
+                    sq += cw_sumsq4(xv[i][c].x, xv[i][c].y, xv[i][c].z, xv[i][c].w);
                 }
             float mu = wave_sum(sx) / (float)K;
             if (2.f * mu * mu < wave_sum(sq) / (float)K) mu = 0.f;    // |mean| < std  <=>  2 mean^2 < E[x^2]
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void gemv_fc2x_kernel(Fc2xParams p) {
         for (int c = 0; c < 5; ++c) {
             const float ok = (lane + 64 * c < dvec) ? 1.f : 0.f;
             const float a = sv[i][c].x - mu, b = sv[i][c].y - mu, cc = sv[i][c].z - mu, d = sv[i][c].w - mu;
-            sq += ok * ((a * a + b * b) + (cc * cc + d * d));
+            sq += ok * cw_sumsq4(a, b, cc, d);
         }
         const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)p.D + 1e-5f);
         if (lane == 0) { s_stat[2 * (wave + 4 * i)] = mu; s_stat[2 * (wave + 4 * i) + 1] = rs; }
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void mlp_pair_kernel(MlpPairParams p) {
         for (int c = 0; c < PER_LANE; ++c) {
             const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
             const float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
-            sq += ok * ((a * a + b * b) + (cc * cc + d * d));
+            sq += ok * cw_sumsq4(a, b, cc, d);
         }
         const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-5f);
         const int row = wave + 4 * i;

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
                 for (int c = 0; c < PER_LANE; ++c)
                     if (lane + 64 * c < nvec) {
                         sx += (xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w);
-                        sq += (xv[i][c].x * xv[i][c].x + xv[i][c].y * xv[i][c].y) + (xv[i][c].z * xv[i][c].z + xv[i][c].w * xv[i][c].w);
+                        sq += cw_sumsq4(xv[i][c].x, xv[i][c].y, xv[i][c].z, xv[i][c].w);
                     }
                 float mu = wave_sum(sx) / (float)K;
                 if (2.f * mu * mu < wave_sum(sq) / (float)K) mu = 0.f;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
             for (int c = 0; c < PER_LANE; ++c) {
                 const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
                 const float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
-                q += ok * ((a * a + b * b) + (cc * cc + d * d));
+                q += ok * cw_sumsq4(a, b, cc, d);
             }
             const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
             const int row = wave + 4 * i;
@@ -624,6 +624,7 @@ __global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
         if (m < Mb && nn < N) {
             if (which == 0) {
                 dl_gran_st(p.gq + (size_t)m * K + rc, tag, __float_as_uint(v));
+                if (p.q_plain) p.q_plain[(size_t)m * K + rc] = v;
             } else {
                 const int hh = rc >> 6, dd = rc & 63;
                 bf16_t* base = (bf16_t*)(which == 1 ? p.sk : p.sv);
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
             }
         }
     }
-    if (!has_item) return;                                            // (no barrier follows for the block as a whole)
+    if (!has_item || p.no_attn) return;                               // (no barrier follows for the block as a whole)
 
     // ---- the item: wave 4 gathers the query and this step's key / value row of (row ib, head ih)
     if (wave == 4) {

@@ -1180,7 +1180,13 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             memset(&qp, 0, sizeof(qp));
             qp.x = xin; qp.W = L.wqkv; qp.bias = L.bqkv; qp.sk = L.sk; qp.sv = L.sv; qp.cap = TGT; qp.pos = c->d_pos; qp.out = c->dattn;
             qp.gq = c->d_gq2; qp.gkv = c->d_gkv; qp.epoch = c->d_epoch; qp.layer = l; qp.err = c->d_err; qp.Mb = nb; qp.D = D; qp.H = H;
+            const int dbg = cw_sw::cw_switches().qkv_self_dbg;   // 1: tiles fused, attention by attn_decode_kernel behind it (bisecting aid)
+            if (dbg) { qp.q_plain = c->dq; qp.no_attn = 1; }
             CWCHK(c, KD(c, cw_launch_qkv_self, qp, c->st));
+            if (dbg) {
+                DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
+                CWCHK(c, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
+            }
         } else {
         {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
             EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;

@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
             for (int c = 0; c < PER_LANE; ++c) {
                 const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
                 float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
-                q += ok * ((a * a + b * b) + (cc * cc + d * d));
+                q += ok * cw_sumsq4(a, b, cc, d);
             }
             const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
             if (ln_affine) {
@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(256) void gemv_loop_kernel(const float* __restrict_
         for (int c = 0; c < PER_LANE; ++c) {
             const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
             float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
-            q += ok * ((a * a + b * b) + (cc * cc + d * d));
+            q += ok * cw_sumsq4(a, b, cc, d);
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
         const int row = wave + 4 * i;

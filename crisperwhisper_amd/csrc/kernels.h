@@ -264,6 +264,8 @@ struct QkvSelfParams {
     int cap;
     const int* pos;            // [Mb] device
     float* out;                // [Mb][D] attention output
+    float* q_plain;            // optional: the query also as plain f32 rows [Mb][D] (debugging: attn_decode_kernel can run behind this launch)
+    int no_attn;               // debugging: tiles only
     unsigned long long* gq;    // [16][D] granules: query
     unsigned long long* gkv;   // [2][16][D / 2] granules: this step's key / value rows, two 16-bit values each
     const unsigned int* epoch;
