@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-PMC_FILE = "r04_pmc_traffic_B8.json"     # latest committed PMC pass (tools/ab/run_gpu_pmc.sh + profiles/summarize_pmc.py)
+PMC_FILE = "r05_pmc_traffic_B8.json"     # latest committed PMC pass (tools/ab/run_gpu_pmc.sh + profiles/summarize_pmc.py)
 
 
 def parse():
@@ -459,13 +459,20 @@ def main():
                     # digest of the merged output (text + every word with its timestamps): the same at every rank count
                     "output_sha1": hashlib.sha1(json.dumps([res["text"], [[c["text"], list(c["timestamp"])] for c in res["chunks"]]]).encode()).hexdigest(),
                     "scaling": "strong", "n_gpus": world}
-    # roofline of the decode-step kernels, HIP events on the engine's own stream
-    roof = {}
-    for which, kname in ((0, "gemv2_bf16_kernel<EPI_GELU_F32> (decoder fc1 + fused LayerNorm)"),
-                         (1, ("attn_cross_mfma8_kernel (cross-attention over the e4m3 cache on v_mfma_f32_16x16x32_fp8_fp8, 1500 frames, 6-way key split)" if a.cross_kv == "fp8" else
-                              "attn_cross_split_kernel<bf16> (cross-attention, 1500 frames, 6-way key split; finishes the fused query)"))):
-        ms, by = eng.time_kernel(which, B, a.kernel_iters)
-        roof[which] = {"kernel": kname, "avg_ms": ms, "algo_bytes": by, "achieved": by / (ms * 1e-3) / 1e9}
+    # roofline of the decode step: EVERY launch of the decoder layer as the step issues it at this batch (cw_time_decode_stage runs
+    # the step's own launch code one stage at a time) + the logits projection, HIP events on the engine's own stream
+    roof = []
+    if a.num_beams == 1:
+        for st in eng.time_decode_stages(B, a.kernel_iters):
+            roof.append({"kernel": st["kernel"], "stage": st["stage"], "avg_ms": st["avg_ms"], "algo_bytes": st["algo_bytes"], "per_step": g.dec_layers})
+        ms, by = eng.time_kernel(7, B, a.kernel_iters)
+        roof.append({"kernel": "LayerNorm + logits projection (gemv_loop_kernel)", "stage": 100, "avg_ms": ms, "algo_bytes": by, "per_step": 1})
+    else:   # beam rows: the two kernels of the greedy layer that dominate it (the beam layer's own launches are in the rocprofv3 table)
+        for which, kname in ((0, "LayerNorm + fc1 + GELU"), (1, "cross-attention")):
+            ms, by = eng.time_kernel(which, B, a.kernel_iters)
+            roof.append({"kernel": kname, "stage": which, "avg_ms": ms, "algo_bytes": by, "per_step": g.dec_layers})
+    for r_ in roof:
+        r_["achieved"] = r_["algo_bytes"] / (r_["avg_ms"] * 1e-3) / 1e9 if r_["avg_ms"] > 0 else 0.0
 
     def pmc_traffic(kernel_substr):
         """HBM bytes per launch of the kernel from the committed rocprofv3 PMC pass (profiles/, same batch)."""
@@ -482,10 +489,22 @@ def main():
 
     if rank == 0:
         total_audio = audio_s * world * a.steps
-        # dominant kernel = largest share of the step in the rocprofv3 table (profiles/): the cross-attention
-        # streamer at B >= 4; for tiny batches the weight GEMV takes over
-        dom = 1 if roof[1]["avg_ms"] >= roof[0]["avg_ms"] else 0
-        r = roof[dom]
+        # dominant kernel = the launch with the largest MEASURED share of the decode step (avg launch time x launches per step)
+        singles = [r_ for r_ in roof if r_["stage"] >= 0]
+        dec_ms, dec_calls = stages["decode"]
+        dec_step_ms = (dec_ms / dec_calls / (1 if a.num_beams > 1 else a.tokens + 2)) if dec_calls else None
+        for r_ in roof:
+            r_["share_of_decode_step"] = (r_["avg_ms"] * r_["per_step"] / dec_step_ms) if dec_step_ms else None
+        r = max(singles, key=lambda r_: r_["avg_ms"] * r_["per_step"])
+        PMC_NAMES = {"cross-attention": "attn_cross_mfma8" if a.cross_kv == "fp8" else "attn_cross_split_kernel", "qkv_self_kernel": "qkv_self_kernel",
+                     "gemv_stack_kernel": "gemv_stack_kernel", "fc1": "gemv2_bf16_kernelILi1E", "fc2": "gemv2_bf16_kernelILi2ELi2ELb1ELb0",
+                     "out-projection (combines": "gemv2_bf16_kernelILi2ELi2ELb1ELb1", "logits": "gemv_loop_kernel"}
+
+        def pmc_of(kernel_label):
+            for key, sub in PMC_NAMES.items():
+                if key in kernel_label and not (key == "cross-attention" and "out-projection" in kernel_label):
+                    return pmc_traffic(sub)
+            return None
         line = {
             "metric": "aligned words/s (RTF alongside), CrisperWhisper large-v3 geometry, 30 s chunks, full mel->encoder->decoder->DTW->words path",
             "value": words / dt, "unit": "aligned words/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -502,18 +521,24 @@ def main():
             "stage_ms_per_step": {k: round(val[0] / max(a.steps, 1) / C, 3) for k, val in stages.items()},
             "roofline": {"bound": "hbm", "achieved": r["achieved"], "peak": 8000.0, "unit": "GB/s",
                          "frac": r["achieved"] / 8000.0,
-                         "traffic": pmc_traffic(("attn_cross_mfma8" if a.cross_kv == "fp8" else "attn_cross_split_kernel") if dom == 1 else "gemv2_bf16_kernelILi7"),
-                         "traffic_source": f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE pass of this command (x2 gfx950 correction), not re-measured in this run",
+                         "traffic": pmc_of(r["kernel"]),
+                         "traffic_source": f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE pass of this command at the same batch and --tokens 32 (x2 gfx950 correction; with a TCC counter rocprofv3 segfaults at --tokens 128, and the per-launch traffic does not depend on the token count), not re-measured in this run",
                          "kernel": r["kernel"],
-                         "avg_launch_ms": r["avg_ms"], "algorithmic_bytes_per_launch": r["algo_bytes"]},
+                         "avg_launch_ms": r["avg_ms"], "algorithmic_bytes_per_launch": r["algo_bytes"],
+                         "launches_per_decode_step": r["per_step"], "share_of_decode_step": r["share_of_decode_step"],
+                         "dominant_by": "largest measured share of the decode step among all launches of the layer + logits (roofline_other lists the rest)",
+                         # the step as a whole (filled in below from the stage timers): algorithmic bytes of one token step / its time
+                         "step_frac": None, "step_achieved": None},
             "parity": parity,
             "collective": {"backend": ("rccl (torch.distributed nccl)" if pg == "nccl" else pg), "all_gathers_in_timed_region": n_gathers,
                            "ranks_seen": (td.get_world_size() if pg is not None else 1), "devices_visible": ndev,
                            "chunks_per_rank": [B * C] * world, "note": pg_note},
             "longform": longform,
-            "roofline_other": [{"kernel": roof[k]["kernel"], "achieved_GBps": roof[k]["achieved"],
-                                "avg_launch_ms": roof[k]["avg_ms"], "algorithmic_bytes_per_launch": roof[k]["algo_bytes"]}
-                               for k in roof if k != dom],
+            "roofline_other": [{"kernel": r_["kernel"], "achieved_GBps": r_["achieved"], "frac_of_8TBps": r_["achieved"] / 8000.0,
+                                "avg_launch_ms": r_["avg_ms"], "algorithmic_bytes_per_launch": r_["algo_bytes"],
+                                "launches_per_decode_step": r_["per_step"], "share_of_decode_step": r_["share_of_decode_step"],
+                                "traffic": pmc_of(r_["kernel"])}
+                               for r_ in roof if r_ is not r],
         }
         # per-stage achieved fraction of roofline (BASELINE.md section 3 work figures; times = HIP events per call)
         if a.geometry == "large-v3":
@@ -548,9 +573,12 @@ def main():
                 streamed = by + (g.dec_layers * g.d_model * g.d_model * 2.0 if (a.dtype in ("bf16", "f16") and B <= 16 and a.num_beams == 1 and not os.environ.get("CW_NO_FUSE6")) else 0.0)
                 sr["decode_step"] = {"bound": "hbm", "algorithmic_bytes": by, "streamed_bytes": streamed, "ms_per_step": per_step_ms,
                                      "achieved_GBps": by / per_step_ms / 1e6, "frac_of_8TBps": by / per_step_ms / 1e6 / 8000.0,
-                                     "launches_per_layer": 12 if a.num_beams > 1 and B * a.num_beams > 16 else (7 if streamed > by else 8)}
+                                     "launches_per_layer": (sum(1 for r_ in roof if 0 <= r_["stage"] < 100) if a.num_beams == 1 else (12 if B * a.num_beams > 16 else 8))}
                 if a.num_beams > 1:
                     sr["decode_step"]["rows"] = B * a.num_beams
+                line["roofline"]["step_frac"] = sr["decode_step"]["frac_of_8TBps"]
+                line["roofline"]["step_achieved"] = sr["decode_step"]["achieved_GBps"]
+                line["roofline"]["sum_of_launch_shares"] = sum(r_["share_of_decode_step"] for r_ in roof if r_["stage"] >= 0 and r_["share_of_decode_step"] is not None)
             t = per_call("timestamps")
             if t:
                 by = 4.0 * 15 * a.tokens * 1500 * B

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrisperwhisper.so")
+# CW_LIB_PATH: a development build of the same library (A/B of compile-time variants, e.g. -DCW_PHASE_TIMING); never a fallback
+LIB_PATH = os.environ.get("CW_LIB_PATH") or os.path.join(_HERE, "libcrisperwhisper.so")
 
 CW_DTYPE_F32, CW_DTYPE_BF16, CW_DTYPE_F16 = 0, 1, 2
 N_SAMPLES, N_FRAMES, N_CTX = 480000, 3000, 1500
@@ -103,6 +104,8 @@ _SIGS = {
     "cw_test_sample": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "cw_stage_times": (_I, [_P, _P, _P, _I]),
     "cw_time_kernel": (_I, [_P, _I, _I, _I, _P, _P]),
+    "cw_time_decode_stage": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "cw_decode_stage_name": (C.c_char_p, [_I]),
 }
 
 _lib = None

@@ -265,6 +265,13 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
 
     if (!chain) {
         // ================= the twelve K/V waves =================
+        // A/B (CW_DL_KVWAIT=1|2): the stream starts only when the chain's tile has its rows in LDS (1) / its weights through the
+        // matrix cores (2) -- requests issued together with the tile's share the memory system fairly, and the tile then lands
+        // when half the stream has, not first
+        if (p.kv_wait && has_tile) {
+            const unsigned need = p.kv_wait == 1 ? 4u : 8u;
+            while (__hip_atomic_load(cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
+        }
         // (a) the chain waves' share of group 0's rows goes to LDS by DMA, requested here and FIRST: a chain wave that carried
         // these 16 requests itself would find every poll queued behind them (vector memory returns in order)
         {

@@ -19,6 +19,16 @@ static thread_local char g_err[512] = "";
 // identical in both builds
 #define KD(c, fn, ...) ((c)->f16 ? cw_f16::fn(__VA_ARGS__) : cw_bf16::fn(__VA_ARGS__))
 
+// launches of one decoder layer, as decode_step issues them (cw_time_decode_stage / cw_decode_stage_name)
+#define CW_MAX_DEC_STAGES 24
+enum DecStageKind { DST_OTHER = 0, DST_QKV_SELF, DST_QKV, DST_SELF_ATTN, DST_O_PROJ, DST_STACK, DST_STACK_CROSS, DST_CROSS_Q, DST_CROSS_ATTN,
+                    DST_CROSS_O, DST_FC1, DST_FC2, DST_MLP_PAIR, DST_N };
+static const char* const kDecStageName[DST_N] = {
+    "other (A/B path)", "LayerNorm + q/k/v projection + self-attention (qkv_self_kernel)", "LayerNorm + q/k/v projection + cache append",
+    "self-attention", "self-attention out-projection", "fused out-projection + cross-query stage (gemv_stack_kernel)",
+    "fused stage + cross-attention (dec_layer_a_kernel)", "LayerNorm + cross-attention query projection", "cross-attention",
+    "cross-attention out-projection (combines the key-split partials)", "LayerNorm + fc1 + GELU", "fc2", "fc1 + fc2 (mlp_pair_kernel)"};
+
 struct LayerW {
     void* wqkv = nullptr; float* bqkv = nullptr;
     void *wqkv8 = nullptr, *w18 = nullptr, *w28 = nullptr, *wkv_c8 = nullptr;   // e4m3 copies (option encoder_gemm_fp8) ...
@@ -172,6 +182,9 @@ struct cw_ctx {
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_step[2] = {nullptr, nullptr};
+    // cw_time_decode_stage: one launch (stage_sel) of one layer (layer_sel) of decode_step; -1 = everything (the step itself)
+    int stage_sel = -1, layer_sel = -1, stage_count = 0;
+    int stage_kind[CW_MAX_DEC_STAGES] = {};
     float stage_ms[CW_N_STAGES] = {};
     int stage_calls[CW_N_STAGES] = {};
 };
@@ -1098,6 +1111,7 @@ static DecLayerParams dec_layer_params(cw_ctx* c, int l, int nb, const float* xi
     dp.qw = L.q_wsum; dp.qbias = L.bq_c;
     dp.gq = c->d_gq; dp.gps = c->d_gps; dp.epoch = c->d_epoch; dp.layer = l; dp.err = c->d_err;
     dp.Mb = nb; dp.D = D; dp.H = H;
+    dp.kv_wait = cw_sw::cw_switches().dl_kvwait;
     return dp;
 }
 
@@ -1165,8 +1179,18 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     };
     if (rows) CWCHK(c, KD(c, cw_launch_rows_prep, c->dx, nb, D, c->d_xfrag, c->d_rstats, lo_off, c->st));
     const bool pf = c->prefetch > 0 && c->bf16 && c->beam_K == 0 && !c->kv8;
-    for (int l = 0; l < c->d.dec_layers; ++l) {
+    // cw_time_decode_stage runs ONE launch (stage_sel) of ONE layer (layer_sel) through this very code: the kernels it times are
+    // the ones the step launches, with the step's arguments
+#define STG(kind, call)                                                                             \
+    do {                                                                                            \
+        if (c->stage_sel < 0 || c->stage_sel == stage_no) CWCHK(c, call);                           \
+        if (stage_no < CW_MAX_DEC_STAGES) c->stage_kind[stage_no] = (kind);                         \
+        c->stage_count = ++stage_no;                                                                \
+    } while (0)
+    const int l_lo = c->layer_sel >= 0 ? c->layer_sel : 0, l_hi = c->layer_sel >= 0 ? c->layer_sel + 1 : c->d.dec_layers;
+    for (int l = l_lo; l < l_hi; ++l) {
         LayerW& L = c->dec[l];
+        int stage_no = 0;
         if (pf && l + 1 < c->d.dec_layers) {   // layer l + 1's streams are touched while layer l runs (side stream: a parallel graph branch)
             HIPCHK(c, hipEventRecord(c->ev_pf[0], c->st));
             HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_pf[0], 0));
@@ -1182,24 +1206,24 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             qp.gq = c->d_gq2; qp.gkv = c->d_gkv; qp.epoch = c->d_epoch; qp.layer = l; qp.err = c->d_err; qp.Mb = nb; qp.D = D; qp.H = H;
             const int dbg = cw_sw::cw_switches().qkv_self_dbg;   // 1: tiles fused, attention by attn_decode_kernel behind it (bisecting aid)
             if (dbg) { qp.q_plain = c->dq; qp.no_attn = 1; }
-            CWCHK(c, KD(c, cw_launch_qkv_self, qp, c->st));
+            STG(DST_QKV_SELF, KD(c, cw_launch_qkv_self, qp, c->st));
             if (dbg) {
                 DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
-                CWCHK(c, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
+                STG(DST_SELF_ATTN, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
             }
         } else {
         {   // LN + fused q/k/v projection; k,v appended to the self-attention cache at pos[b]
             EpiParams ep = epi0(); ep.outf = c->dq; ep.out1 = L.sk; ep.out2 = L.sv; ep.bias = L.bqkv;
             ep.H = H; ep.S_pad = TGT; ep.d_model = D; ep.row_pos = c->d_pos;
-            if (skinny) CWCHK(c, sk_ln(EPI_QKV_CACHE, L.wqkv, 3 * D, L.qkv_wsum, ep));
-            else if (rows) CWCHK(c, rows_consume(EPI_QKV_CACHE, L.wqkv, 3 * D, ep, L.qkv_wsum));
-            else CWCHK(c, gemv_ln(c, EPI_QKV_CACHE, xin, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep));
+            if (skinny) STG(DST_QKV, sk_ln(EPI_QKV_CACHE, L.wqkv, 3 * D, L.qkv_wsum, ep));
+            else if (rows) STG(DST_QKV, rows_consume(EPI_QKV_CACHE, L.wqkv, 3 * D, ep, L.qkv_wsum));
+            else STG(DST_QKV, gemv_ln(c, EPI_QKV_CACHE, xin, nb, D, L.wqkv, 3 * D, L.ln1_g, c->ln_folded ? nullptr : L.ln1_b, ep));
         }
         {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
             if (frag) p.out_frag = (unsigned short*)c->d_xfrag2;
             if (c->beam_K > 0) p.anc = c->d_anc;
-            CWCHK(c, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
+            STG(DST_SELF_ATTN, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
         }
         }
         if (fuse) {
@@ -1211,7 +1235,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                             nb * H * ATT_NS <= 4 * c->n_cu && TD <= 128 && KD(c, cw_dec_layer_lds, D) <= (size_t)160 * 1024;
             if (dl) {
                 const DecLayerParams dp = dec_layer_params(c, l, nb, xin, xalt);
-                CWCHK(c, KD(c, cw_launch_dec_layer, dp, c->n_cu, c->st));
+                STG(DST_STACK_CROSS, KD(c, cw_launch_dec_layer, dp, c->n_cu, c->st));
             } else
             {   // X1 over [W'q_c ; W'q_c Wo ; Wo]:  qa = W'q_c x + W'q_c bo,  qb = (W'q_c Wo) a,  x1 = x + Wo a + bo
                 StackParams sp;
@@ -1223,7 +1247,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo;      sp.seg[2].out = xalt;    sp.seg[2].tile0 = 2 * TD; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
                 sp.seg[2].resid = xin; sp.seg[2].pstats = c->d_pstats;   // LayerNorm partial sums of x1 for the cross-attention
                 if (c->fuse_mlp) { sp.zero = c->d_u1; sp.zero_n4 = nb * F / 4; }   // X2 below accumulates its two halves into u1
-                CWCHK(c, KD(c, cw_launch_gemv_stack, sp, nt3, c->st));
+                STG(DST_STACK, KD(c, cw_launch_gemv_stack, sp, nt3, c->st));
             }
             // cross-attention; the kernel finishes q_c = rstd(x1) (qa + qb - mean(x1) W'q_c 1) + b'q_c
             CrossSplitParams p{nullptr, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml,
@@ -1233,26 +1257,26 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             p.qa = c->d_qa; p.qb = c->d_qb; p.qw = L.q_wsum; p.qbias = L.bq_c;
             p.pstats = c->d_pstats; p.n_pstats = (TD + nt3 - 1) / nt3;
             if (!c->fuse_mlp) {
-                if (!dl) CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
+                if (!dl) STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_cross_split, true, p, c->st));
                 {   // out-projection combines the key-split partials; x2 = x1 + Wo_c a_c + bo_c in place
                     EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.bo_c; ep.ldo = D;
                     CombineParams cb{c->d_part_ml, H, nb * D};
-                    CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag, c->wpacked));
+                    STG(DST_CROSS_O, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag, c->wpacked));
                 }
                 if (c->mlp_pair && F % D == 0 && D % 32 == 0 && F / 32 <= 256 && F / D <= 32) {
                     // LN + fc1 + GELU, group barrier, fc2 + residual in one launch (decfuse.hip: mlp_pair_kernel)
                     MlpPairParams mp{xalt, L.w1, L.b1, L.w2, L.b2, c->d_xfrag2, c->d_bar, c->d_err, nb, D, F, c->wpacked ? 1 : 0, c->mlp_pair_fence ? 1 : 0};
-                    CWCHK(c, KD(c, cw_launch_mlp_pair, mp, c->st));
+                    STG(DST_MLP_PAIR, KD(c, cw_launch_mlp_pair, mp, c->st));
                 } else {
                     // fc1 writes gelu(.) in the 16-bit type fc2 would round it to anyway (bit-identical): fc2's activation load halves
                     const bool mid16 = F > 1280 && c->mid16;
                     {
                         EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
-                        CWCHK(c, gemv_ln(c, mid16 ? EPI_GELU : EPI_GELU_F32, xalt, nb, D, L.w1, F, L.ln2_g, nullptr, ep));
+                        STG(DST_FC1, gemv_ln(c, mid16 ? EPI_GELU : EPI_GELU_F32, xalt, nb, D, L.w1, F, L.ln2_g, nullptr, ep));
                     }
                     {
                         EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.b2; ep.ldo = D; ep.x16 = mid16 ? 1 : 0;
-                        CWCHK(c, gemv_ln(c, EPI_RESID_F32, mid16 ? (const float*)c->d_xfrag2 : c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
+                        STG(DST_FC2, gemv_ln(c, EPI_RESID_F32, mid16 ? (const float*)c->d_xfrag2 : c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
                     }
                 }
                 float* t = xin; xin = xalt; xalt = t;
@@ -1262,7 +1286,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             // finished attention output in one plane (one block per (row, head): 17 us against 12) and makes every fc2 block
             // redo the statistics and the GELU of its K slice.
             p.a_out = c->dattn; p.xstat = xalt;
-            CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
+            STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_cross_split, true, p, c->st));
             {   // X2 over [W'1 ; W'1 Wo_c ; Wo_c]:  u1 = W'1 x1 + W'1 bo_c + (W'1 Wo_c) a_c (two halves, atomics into the zeros X1
                 // left: two commutative additions, so the order does not matter),  x2 = x1 + Wo_c a_c + bo_c (+ a copy that
                 // fc2 takes the LayerNorm statistics of while its atomics are already modifying the stream)
@@ -1274,19 +1298,19 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 sp.seg[1].x = c->dattn; sp.seg[1].bias = nullptr;   sp.seg[1].out = c->d_u1; sp.seg[1].tile0 = TF;     sp.seg[1].n_tiles = TF; sp.seg[1].epi = 2;
                 sp.seg[2].x = c->dattn; sp.seg[2].bias = L.bo_c;    sp.seg[2].out = xin;     sp.seg[2].tile0 = 2 * TF; sp.seg[2].n_tiles = TD; sp.seg[2].epi = 1;
                 sp.seg[2].resid = xalt; sp.seg[2].out2 = c->dx2c;
-                CWCHK(c, KD(c, cw_launch_gemv_stack, sp, c->stack_nt5, c->st));
+                STG(DST_STACK, KD(c, cw_launch_gemv_stack, sp, c->stack_nt5, c->st));
             }
             {   // fc2: mid = gelu(rstd(x2) (u1 - mean(x2) W'1 1) + b'1) on load; x3 = x2 + W2 mid + b2 in place
                 Fc2xParams fp{c->dx2c, c->d_u1, L.u1_wsum, L.b1, L.w2, L.b2, xin, nb, D, F, c->wpacked ? 1 : 0};
-                CWCHK(c, KD(c, cw_launch_gemv_fc2x, fp, c->st));
+                STG(DST_FC2, KD(c, cw_launch_gemv_fc2x, fp, c->st));
             }
             continue;
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo; ep.ldo = D;
-            if (rows) CWCHK(c, rows_produce(L.wo, D, L.bo));
-            else if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
-            else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));
+            if (rows) STG(DST_O_PROJ, rows_produce(L.wo, D, L.bo));
+            else if (frag) STG(DST_O_PROJ, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
+            else STG(DST_O_PROJ, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo, D, nullptr, nullptr, ep));
         }
         if (xfull) {
             CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml,
@@ -1299,22 +1323,22 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                 sp.x = c->dx; sp.W = L.wq_c; sp.Mb = nb; sp.K = D; sp.N = D; sp.planes = c->d_planes;
                 const int nks = KD(c, cw_skinny_pick_nks, D, D, (int)(c->planes_cap / ((size_t)nb * D)));
                 if (nks < 1) return fail(c, CW_ERR_INVALID, "no K split for the cross-attention query GEMM");
-                CWCHK(c, KD(c, cw_launch_skinny, 0, sp, nks, c->st));
+                STG(DST_OTHER, KD(c, cw_launch_skinny, 0, sp, nks, c->st));
                 p.q = nullptr; p.xstat = c->dx; p.qa = c->d_planes; p.q_planes = (D / 32) / nks; p.q_plane_stride = nb * D;
                 p.qw = L.q_wsum; p.qbias = L.bq_c;
             } else {
                 EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
-                CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep));
+                STG(DST_CROSS_Q, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep));
             }
-            CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
+            STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_cross_split, true, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
-            CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag, c->wpacked));
+            STG(DST_CROSS_O, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag, c->wpacked));
         } else {
         {   // cross-attention: LN + q projection, attention over the cached encoder K/V
             EpiParams ep = epi0(); ep.outf = c->dq; ep.bias = L.bq_c; ep.ldo = D;
-            if (skinny) CWCHK(c, sk_ln(EPI_STORE_F32, L.wq_c, D, L.q_wsum, ep));
-            else if (rows) CWCHK(c, rows_consume(EPI_STORE_F32, L.wq_c, D, ep, L.q_wsum));
-            else CWCHK(c, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep));
+            if (skinny) STG(DST_CROSS_Q, sk_ln(EPI_STORE_F32, L.wq_c, D, L.q_wsum, ep));
+            else if (rows) STG(DST_CROSS_Q, rows_consume(EPI_STORE_F32, L.wq_c, D, ep, L.q_wsum));
+            else STG(DST_CROSS_Q, gemv_ln(c, EPI_STORE_F32, c->dx, nb, D, L.wq_c, D, L.lnc_g, c->ln_folded ? nullptr : L.lnc_b, ep));
         }
         if (c->bf16) {
             // keys split over ATT_NS blocks per (row, head); the out-projection GEMV combines the partials
@@ -1324,37 +1348,38 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             p.kv_div = c->beam_K > 0 ? c->beam_K : 1;
             if (c->kv8) {
                 p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs;
-                CWCHK(c, KD(c, cw_launch_attn_cross_split_fp8, p, c->st));
-            } else CWCHK(c, KD(c, cw_launch_attn_cross_split, true, p, c->st));
+                STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_cross_split_fp8, p, c->st));
+            } else STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_cross_split, true, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
             CombineParams cb{c->d_part_ml, H, nb * D};
             if (rows) {
-                CWCHK(c, KD(c, cw_launch_rows_combine, c->d_part_o, nb, D, cb, c->d_xfrag2, c->st));
-                CWCHK(c, rows_produce(L.wo_c, D, L.bo_c));
-            } else CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag, c->wpacked));
+                STG(DST_OTHER, KD(c, cw_launch_rows_combine, c->d_part_o, nb, D, cb, c->d_xfrag2, c->st));
+                STG(DST_CROSS_O, rows_produce(L.wo_c, D, L.bo_c));
+            } else STG(DST_CROSS_O, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag, c->wpacked));
         } else {
             DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn, nb, H);
             p.align_out = c->d.n_align > 0 ? c->d_align : nullptr; p.align_slot = c->d_align_slot + (size_t)l * H;
             p.n_align = c->d.n_align; p.align_rows = TGT;
             p.kv_div = c->beam_K > 0 ? c->beam_K : 1;
-            CWCHK(c, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
+            STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.bo_c; ep.ldo = D;
-            CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo_c, D, nullptr, nullptr, ep));
+            STG(DST_CROSS_O, gemv_ln(c, EPI_RESID_F32, c->dattn, nb, D, L.wo_c, D, nullptr, nullptr, ep));
         }
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
-            if (skinny) CWCHK(c, sk_ln(EPI_GELU_FRAG, L.w1, F, L.u1_wsum, ep));
-            else if (rows) CWCHK(c, rows_consume(EPI_GELU_FRAG, L.w1, F, ep, L.u1_wsum));
-            else CWCHK(c, gemv_ln(c, frag ? EPI_GELU_FRAG : EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, c->ln_folded ? nullptr : L.ln2_b, ep));
+            if (skinny) STG(DST_FC1, sk_ln(EPI_GELU_FRAG, L.w1, F, L.u1_wsum, ep));
+            else if (rows) STG(DST_FC1, rows_consume(EPI_GELU_FRAG, L.w1, F, ep, L.u1_wsum));
+            else STG(DST_FC1, gemv_ln(c, frag ? EPI_GELU_FRAG : EPI_GELU_F32, c->dx, nb, D, L.w1, F, L.ln2_g, c->ln_folded ? nullptr : L.ln2_b, ep));
         }
         {
             EpiParams ep = epi0(); ep.outf = c->dx; ep.resid = c->dx; ep.bias = L.b2; ep.ldo = D;
-            if (rows) CWCHK(c, rows_produce(L.w2, F, L.b2));
-            else if (frag) CWCHK(c, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
-            else CWCHK(c, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
+            if (rows) STG(DST_FC2, rows_produce(L.w2, F, L.b2));
+            else if (frag) STG(DST_FC2, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
+            else STG(DST_FC2, gemv_ln(c, EPI_RESID_F32, c->dmid, nb, F, L.w2, D, nullptr, nullptr, ep));
         }
     }
+#undef STG
     if (pf && c->d.dec_layers > 1) {           // join the side stream (required before the capture ends; the last prefetch is long done)
         HIPCHK(c, hipEventRecord(c->ev_pf[1], c->st2));
         HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_pf[1], 0));
@@ -2628,6 +2653,71 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
         case 6: *algo_bytes = 2.0 * nb * H * 65 * 64 * e + 2.0 * nb * D * 4; break;
         case 7: *algo_bytes = (double)V * D * e + (double)nb * (D + V) * 4; break;
         default: *algo_bytes = 0; break;
+    }
+    return CW_OK;
+}
+
+const char* cw_decode_stage_name(int32_t kind) { return (kind >= 0 && kind < DST_N) ? kDecStageName[kind] : "?"; }
+
+// One launch of the decoder layer AS decode_step ISSUES IT at nb rows (same code path, same arguments), `iters` times back to back,
+// cycling through the layers so that every launch streams its operands from HBM.  stage = index of the launch inside the layer
+// (0 .. *n_stages - 1; the count depends on the rows, the dtype and the switches); stage == -1: the whole layer (all its launches).
+int32_t cw_time_decode_stage(cw_ctx* c, int32_t nb, int32_t stage, int32_t iters, float* avg_ms, double* algo_bytes, int32_t* kind,
+                             int32_t* n_stages) {
+    if (nb < 1 || nb > c->Bm || iters < 1 || stage < -1 || stage >= CW_MAX_DEC_STAGES) return fail(c, CW_ERR_INVALID, "time_decode_stage: bad args");
+    if (c->beam_K > 0) return fail(c, CW_ERR_STATE, "time_decode_stage: greedy rows only");
+    const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, NL = c->d.dec_layers;
+    struct Restore { cw_ctx* c; ~Restore() { c->stage_sel = -1; c->layer_sel = -1; } } restore{c};
+    CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 64, nb, c->st, c->d_epoch));
+    // which launches does a layer have at this row count?  (nothing is launched: no stage has this index)
+    c->stage_sel = CW_MAX_DEC_STAGES; c->layer_sel = 0;
+    CWCHK(c, decode_step(c, nb, false));
+    const int ns = c->stage_count;
+    if (n_stages) *n_stages = ns;
+    if (stage >= ns) return fail(c, CW_ERR_INVALID, "time_decode_stage: the layer has %d launches at %d rows", ns, nb);
+    c->stage_sel = stage;
+    auto one = [&](int i) -> int {
+        c->layer_sel = i % NL;
+        // granule tags are (epoch, layer): a second pass over the layers must not find the first pass's granules valid
+        if (c->layer_sel == 0) CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 64, nb, c->st, c->d_epoch));
+        return decode_step(c, nb, false);
+    };
+    for (int i = 0; i < 3; ++i) CWCHK(c, one(i));
+    HIPCHK(c, hipEventRecord(c->ev0, c->st));
+    for (int i = 0; i < iters; ++i) CWCHK(c, one(3 + i));
+    HIPCHK(c, hipEventRecord(c->ev1, c->st));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = ms / iters;
+    // algorithmic bytes: the weights of the projection(s), the cache rows, the activation rows in and out (f32 unless noted)
+    const double e = (double)c->esz, act = (double)nb * D * 4.0;
+    auto bytes_of = [&](int k) -> double {
+        const double self_kv = 2.0 * nb * H * 65 * 64 * e;                                        // 65 cached positions (d_pos = 64)
+        const double cross_kv = 2.0 * nb * H * CW_N_CTX * 64 * (c->kv8 ? 1.0 : e);
+        switch (k) {
+            case DST_QKV: return 3.0 * D * D * e + 4.0 * act;
+            case DST_SELF_ATTN: return self_kv + 2.0 * act;
+            case DST_QKV_SELF: return 3.0 * D * D * e + self_kv + 2.0 * act;
+            case DST_O_PROJ: case DST_CROSS_Q: return (double)D * D * e + 2.0 * act;
+            case DST_STACK: return 3.0 * D * D * e + 5.0 * act;                                   // x, a in; qa, qb, x1 out
+            case DST_CROSS_ATTN: return cross_kv + 2.0 * act;
+            case DST_STACK_CROSS: return 3.0 * D * D * e + cross_kv + 4.0 * act;
+            case DST_CROSS_O: return (double)D * D * e + 2.0 * act;
+            case DST_FC1: return (double)F * D * e + act + (double)nb * F * e;
+            case DST_FC2: return (double)F * D * e + (double)nb * F * e + 2.0 * act;
+            case DST_MLP_PAIR: return 2.0 * F * D * e + 3.0 * act;
+            default: return 0.0;
+        }
+    };
+    if (stage >= 0) {
+        if (kind) *kind = c->stage_kind[stage];
+        *algo_bytes = bytes_of(c->stage_kind[stage]);
+    } else {
+        if (kind) *kind = -1;
+        double t = 0.0;
+        for (int i = 0; i < ns && i < CW_MAX_DEC_STAGES; ++i) t += bytes_of(c->stage_kind[i]);
+        *algo_bytes = t;
     }
     return CW_OK;
 }

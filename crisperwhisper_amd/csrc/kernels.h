@@ -251,6 +251,7 @@ struct DecLayerParams {
     int layer;
     int* err;                  // set to 1 when a poll gave up (results are then invalid; the engine reports it)
     int Mb, D, H;
+    int kv_wait;               // A/B: 0 = K/V requested at kernel entry, 1 / 2 = after the chain's rows are in LDS / after its MFMAs
 };
 
 // declayer.hip: LayerNorm + q/k/v projection + self-attention of rows <= 8 in ONE launch (gemv2_bf16_kernel<EPI_QKV_CACHE> tiles,

@@ -39,6 +39,7 @@ Switches read_switches() {
     s.cross_lds_pad = num("CW_CROSS_LDS_PAD", 0);
     s.cross8_nsb = num("CW_CROSS8_NSB", 0);
     s.dl_depth = num("CW_DL_DEPTH", 16);
+    s.dl_kvwait = num("CW_DL_KVWAIT", 0);
     s.qkv_self_dbg = num("CW_QKV_SELF_DBG", 0);
     s.no_glds = flag("CW_NO_GLDS");
     s.no_gemm256 = flag("CW_NO_GEMM256");

@@ -431,3 +431,15 @@ class Engine:
         by = C.c_double(0.0)
         self._chk(self.lib.cw_time_kernel(self.ctx, which, nb, iters, C.byref(ms), C.byref(by)))
         return ms.value, by.value
+
+    def time_decode_stages(self, nb: int, iters: int):
+        """Every launch of the decoder layer as the decode step issues it for `nb` greedy rows, timed one at a time (HIP events on
+        the engine's stream, layers cycled): [{"stage", "kernel", "avg_ms", "algo_bytes"}], plus the whole layer as stage -1."""
+        out = []
+        ms, by, kind, ns = C.c_float(0.0), C.c_double(0.0), C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.cw_time_decode_stage(self.ctx, nb, -1, iters, C.byref(ms), C.byref(by), C.byref(kind), C.byref(ns)))
+        out.append({"stage": -1, "kernel": "whole decoder layer (all launches)", "avg_ms": ms.value, "algo_bytes": by.value})
+        for s in range(ns.value):
+            self._chk(self.lib.cw_time_decode_stage(self.ctx, nb, s, iters, C.byref(ms), C.byref(by), C.byref(kind), C.byref(ns)))
+            out.append({"stage": s, "kernel": self.lib.cw_decode_stage_name(kind.value).decode(), "avg_ms": ms.value, "algo_bytes": by.value})
+        return out

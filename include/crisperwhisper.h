@@ -295,6 +295,14 @@ int32_t cw_stage_times(cw_ctx* ctx, float* ms /* [CW_N_STAGES] */, int32_t* call
  * which = 0 decode GEMV (fc1 of decoder layer 0, LN fused), 1 cross-attention decode (layer 0).
  * Returns average ms per launch and the algorithmic bytes one launch must move.                          */
 int32_t cw_time_kernel(cw_ctx* ctx, int32_t which, int32_t nb, int32_t iters, float* avg_ms, double* algo_bytes);
+/* Times ONE launch of the decoder layer exactly as the decode step issues it for `nb` greedy rows (the step's own launch code with
+ * the step's arguments; the layers are cycled so that every launch streams its operands from HBM).  stage = index of the launch
+ * inside the layer, 0 .. *n_stages - 1 (the count depends on rows, dtype and cache mode); stage = -1 times the whole layer.
+ * Returns average ms per launch, the algorithmic bytes it must move, and its kind (cw_decode_stage_name).  Measurement aid of
+ * bench.py's roofline block: the reference has no counterpart (it times the pipeline call, /root/reference/transcribe.py:33). */
+int32_t cw_time_decode_stage(cw_ctx* ctx, int32_t nb, int32_t stage, int32_t iters, float* avg_ms, double* algo_bytes,
+                             int32_t* kind, int32_t* n_stages);
+const char* cw_decode_stage_name(int32_t kind);
 
 #ifdef __cplusplus
 }
