@@ -564,7 +564,7 @@ def main():
             ms, calls = stages["decode"]
             if calls:
                 steps_per_call = a.tokens + 2            # prompt positions 0,1 + one forward per generated token
-                by = 1.812e9 + B * 245.76e6               # weights (bf16) + cross-K/V per step; self-K/V omitted
+                by = 1.812e9 + B * 245.76e6 * (0.5 if a.cross_kv == "fp8" else 1.0)   # weights (bf16) + cross-K/V per step (e4m3 cache: one byte per element); self-K/V omitted
                 per_step_ms = ms / calls / steps_per_call
                 if a.num_beams > 1:                       # beam search: the stage timer brackets every cw_beam_step (one forward of B x beams rows)
                     per_step_ms = ms / calls

@@ -1488,6 +1488,7 @@ __global__ __launch_bounds__(512) void kv_quant_fp8_kernel(const bf16_t* __restr
 // the e4m3 cross-attention runs on the fp8 matrix cores and reads V in fragment-major order unless CW_CROSS8_VALU=1 (round-2/4
 // VALU kernel over a row-major V, A/B); the quantiser writes the layout the attention kernel of this process reads
 static bool cross8_mfma(int n_keys) { return !cw_sw::cw_switches().cross8_valu && (n_keys + ATT_NS - 1) / ATT_NS <= 256; }
+bool cw_cross8_is_mfma(int n_keys) { return cross8_mfma(n_keys); }   // the engine composes the fused query stage only with the matrix-core kernel
 size_t cw_kv8_v_bytes(int H, int S) {   // bytes of the e4m3 V cache per batch item (either layout fits)
     const size_t row_major = (size_t)H * S * 64, frag = (size_t)H * ATT_NS * X8_SPLIT_BYTES;
     return row_major > frag ? row_major : frag;
@@ -1672,9 +1673,13 @@ __device__ inline long split3_e4m3(const float* x, int term) {
 // NSB = key splits per block (grid (H, B, ATT_NS / NSB)): with thousands of blocks the launch is bound by the bytes a CU has in
 // flight; two adjacent splits per block double them (a wave owns 32 keys of each) under the same three barriers, and every
 // split is computed exactly as a block of its own would (bit-identical partials).
-template <int NSB>
+// FUSED (fused out-projection / cross-query stage in front, decfuse.hip): wave 0 finishes the query exactly as
+// attn_cross_split_kernel<T, 1, true> does -- lane c = column c of the head, q = rstd(x1) (qa + qb - mean(x1) qw) + qbias from the
+// per-tile LayerNorm partial sums the producing GEMV left behind -- and hands the 16 columns of each lane over through LDS.
+template <int NSB, bool FUSED>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSplitParams p) {
     __shared__ float s_max[NSB * 8];
+    __shared__ float s_qf[FUSED ? 64 : 1];
     __shared__ __attribute__((aligned(16))) float red[NSB * 8 * 64];
     __shared__ float red_l[NSB * 8];
     __shared__ __attribute__((aligned(16))) float s_p[8 * 32];
@@ -1711,6 +1716,23 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
     if (wave == 0) {
         float qf[16];
         const float* qp = p.q + (size_t)b * D + h * 64 + g * 16;
+        if (FUSED) {
+            const float2 pt0 = *(const float2*)(p.pstats + ((size_t)min(lane, p.n_pstats - 1) * 16 + b) * 2);
+            const float2 pt1 = *(const float2*)(p.pstats + ((size_t)min(lane + 64, p.n_pstats - 1) * 16 + b) * 2);
+            const size_t col = (size_t)h * 64 + lane;
+            const float qa1 = p.qa[(size_t)b * D + col], qb1 = p.qb[(size_t)b * D + col], qw1 = p.qw[col], qc1 = p.qbias[col];
+            const float inv_d = 1.0f / (float)D;
+            const float ps1 = (lane < p.n_pstats ? pt0.x : 0.f) + (lane + 64 < p.n_pstats ? pt1.x : 0.f);
+            const float ps2 = (lane < p.n_pstats ? pt0.y : 0.f) + (lane + 64 < p.n_pstats ? pt1.y : 0.f);
+            const float mean = wave_sum(ps1) * inv_d;
+            const float var = fmaxf(wave_sum(ps2) * inv_d - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            s_qf[lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            qp = s_qf + g * 16;
+        }
         const float4 q0 = *(const float4*)qp, q1 = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
         qf[0] = q0.x; qf[1] = q0.y; qf[2] = q0.z; qf[3] = q0.w; qf[4] = q1.x; qf[5] = q1.y; qf[6] = q1.z; qf[7] = q1.w;
         qf[8] = q2.x; qf[9] = q2.y; qf[10] = q2.z; qf[11] = q2.w; qf[12] = q3.x; qf[13] = q3.y; qf[14] = q3.z; qf[15] = q3.w;
@@ -1817,11 +1839,19 @@ int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st) {
     if (cross8_mfma(p.n_keys)) {
         // CW_CROSS8_NSB=2 (A/B): two splits per block -- twice the bytes in flight per CU, measured equal (the memory system is the bound)
         const int f = cw_sw::cw_switches().cross8_nsb;
+        if (p.qa) {   // fused stage in front: the kernel finishes the query
+            if (!p.qb || !p.qw || !p.qbias || !p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.kv_div > 1) return CW_ERR_INVALID;
+            if (ATT_NS % 2 == 0 && f == 2)
+                hipLaunchKernelGGL((attn_cross_mfma8_kernel<2, true>), dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
+            else hipLaunchKernelGGL((attn_cross_mfma8_kernel<1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+            return CW_OK;
+        }
         if (ATT_NS % 2 == 0 && f == 2)
-            hipLaunchKernelGGL(attn_cross_mfma8_kernel<2>, dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
-        else hipLaunchKernelGGL(attn_cross_mfma8_kernel<1>, dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+            hipLaunchKernelGGL((attn_cross_mfma8_kernel<2, false>), dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
+        else hipLaunchKernelGGL((attn_cross_mfma8_kernel<1, false>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
         return CW_OK;
     }
+    if (p.qa) return CW_ERR_INVALID;                            // the VALU kernel takes a finished query
     // two splits per block once the grid is several times what is resident (4 blocks of 512 threads per CU); A/B: CW_CROSS8_NSB=1|2
     const int force = cw_sw::cw_switches().cross8_nsb;
     const bool pair = ATT_NS % 2 == 0 && (force ? force == 2 : (size_t)p.H * p.B * ATT_NS >= 4096);

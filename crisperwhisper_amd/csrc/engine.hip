@@ -1123,8 +1123,9 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     const bool frag = c->bf16 && nb > 16;
     // fused out-projection / cross-query stage (decfuse.hip): greedy rows of one MFMA half tile, 16-bit caches.  The residual
     // stream then alternates between two buffers: a layer reads x from `xin` and leaves x1, x2, x3 in `xalt`.
-    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 16 && c->beam_K == 0 && !c->kv8 &&
-                      !((c->fuse_mlp || c->mlp_pair) && nb > 8);
+    // (e4m3 cache: the fp8 matrix-core kernel finishes the fused query too; its VALU fallback does not)
+    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 16 && c->beam_K == 0 &&
+                      (!c->kv8 || (KD(c, cw_cross8_is_mfma, CW_N_CTX) && !c->fuse_mlp)) && !((c->fuse_mlp || c->mlp_pair) && nb > 8);
     float *xin = c->dx, *xalt = c->dx1;
     // 17..64 rows without preparation launches (decfuse.hip: gemv_rows_kernel): the residual GEMVs own whole columns and leave
     // the stream in f32, its 16-bit fragment-major copy in d_xfrag and LayerNorm partial sums in d_rstats; the LayerNorm
@@ -1231,7 +1232,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             const int nt3 = c->stack_nt3 > 0 ? c->stack_nt3 : 1;   // column tiles per X1 block (3 * TD blocks at 1: 240 at large-v3)
             // rows <= 8: X1 and the cross-attention as ONE persistent launch (declayer.hip): the K/V rows are requested at kernel
             // entry and stream under the GEMV tile; qa / qb / the partial sums cross CUs as granules.  Bit-identical to the two launches.
-            const bool dl = c->declayer && !c->fuse_mlp && nt3 == 1 && c->wpacked && nb <= 8 && 3 * TD <= c->n_cu &&
+            const bool dl = c->declayer && !c->kv8 && !c->fuse_mlp && nt3 == 1 && c->wpacked && nb <= 8 && 3 * TD <= c->n_cu &&
                             nb * H * ATT_NS <= 4 * c->n_cu && TD <= 128 && KD(c, cw_dec_layer_lds, D) <= (size_t)160 * 1024;
             if (dl) {
                 const DecLayerParams dp = dec_layer_params(c, l, nb, xin, xalt);
@@ -1257,6 +1258,10 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             p.qa = c->d_qa; p.qb = c->d_qb; p.qw = L.q_wsum; p.qbias = L.bq_c;
             p.pstats = c->d_pstats; p.n_pstats = (TD + nt3 - 1) / nt3;
             if (!c->fuse_mlp) {
+                if (c->kv8) {
+                    p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs;
+                    STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_cross_split_fp8, p, c->st));
+                } else
                 if (!dl) STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_cross_split, true, p, c->st));
                 {   // out-projection combines the key-split partials; x2 = x1 + Wo_c a_c + bo_c in place
                     EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.bo_c; ep.ldo = D;
@@ -2585,9 +2590,10 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
                 if (c->bf16) {
                     CrossSplitParams p{c->dq, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml, nullptr, c->d_align_ml, nullptr,
                                        c->d_pos, 0, 0, nb, H};
-                    if (c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 16 && !c->kv8) {
+                    if (c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 16 && (!c->kv8 || KD(c, cw_cross8_is_mfma, CW_N_CTX))) {
                         p.kv_div = 1; p.qa = c->d_qa; p.qb = c->d_qb; p.qw = L.q_wsum; p.qbias = L.bq_c;
                         p.pstats = c->d_pstats; p.n_pstats = D / 16;
+                        if (c->kv8) { p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs; return KD(c, cw_launch_attn_cross_split_fp8, p, c->st); }
                         return KD(c, cw_launch_attn_cross_split, true, p, c->st);
                     }
                     if (c->kv8) { p.K = L.ck8; p.V = L.cv8; p.kv_scale = L.kvs; return KD(c, cw_launch_attn_cross_split_fp8, p, c->st); }

@@ -337,6 +337,7 @@ struct MelTables {
     int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st); \
     int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st); \
     int cw_launch_kv_quant_fp8(const void* K, const void* V, void* K8, void* V8, float* kv_scale, int B, int H, int S, hipStream_t st); \
+    bool cw_cross8_is_mfma(int n_keys); \
     int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st); \
     size_t cw_kv8_v_bytes(int H, int S); \
     int cw_launch_align_normalize(float* align, const float* align_ml, int B, int n_align, int align_rows, int L, int n_keys, hipStream_t st); \

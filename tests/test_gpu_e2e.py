@@ -1274,13 +1274,15 @@ def test_persistent_decoder_layer_is_bit_identical(feature, rows, dt):
     assert steps > 2000
 
 
+@pytest.mark.parametrize("kv", [None, "fp8"])
 @pytest.mark.parametrize("rows", [3, 8, 12])
-def test_fused_decoder_stage_tracks_eight_launch_layer(rows):
+def test_fused_decoder_stage_tracks_eight_launch_layer(rows, kv):
     """csrc/decfuse.hip: the out-projection + cross-query stage applied through the load-time product matrix (7 launches per
     layer) against the same engine with the stage switched off (CW_NO_FUSE6=1, 8 launches), large-v3 shapes on a 2+2-layer stack,
     teacher-forced, 1..16 rows (two or four rows per wave): logits within bf16 rounding of each other, same tokens, alignment
     rows within 2e-2 -- the two differ only in where the 16-bit roundings fall (x before the mean is subtracted, the product
-    W'q Wo rounded once)."""
+    W'q Wo rounded once).  kv = "fp8": the same over the e4m3 cross-attention cache, whose matrix-core kernel
+    (attn_cross_mfma8_kernel<.., FUSED>) finishes the fused query like the bf16 kernel does."""
     import os
     g, v = syn.large_v3_geometry()
     g.enc_layers = g.dec_layers = 2
@@ -1298,7 +1300,7 @@ def test_fused_decoder_stage_tracks_eight_launch_layer(rows):
         if mode == "eight":
             os.environ["CW_NO_FUSE6"] = "1"
         try:
-            eng = Engine(spec, dtype="bf16", max_batch=rows)
+            eng = Engine(spec, dtype="bf16", max_batch=rows, cross_kv_dtype=kv)
         finally:
             os.environ.pop("CW_NO_FUSE6", None)
         try:
