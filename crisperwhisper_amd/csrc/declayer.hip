@@ -832,6 +832,299 @@ int cw_launch_qkv_self(const QkvSelfParams& p, hipStream_t st) {
     return CW_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fc1 + fc2 in ONE launch (rows <= 8): grid = F / 32 fc1 blocks, then (D / 32) x KS fc2 blocks, 256 threads.
+//   fc1 block j:  LayerNorm + two 16-column tiles + GELU of gemv2_bf16_kernel<EPI_GELU, 2, false, false, NS1, PL1, 2> (gemm.hip),
+//                 operation for operation; the 16-bit rows leave as write-through (sc1) 4-byte stores; when the block's stores have
+//                 drained (vmcnt 0 + block barrier) thread 0 publishes flag j = {tag, 1};
+//   fc2 block:    gemv2_bf16_kernel<EPI_RESID_F32, 2, true, false, NS2, .., 2, true> for (column pair, K slice): its 64-80 KB of
+//                 weights are requested at kernel entry (they depend on nothing), wave 0 then polls the F / 32 flags, and the rows of
+//                 the K slice come in by 8-byte sc1 loads (another CU wrote them a microsecond ago: plain loads could hit a stale L2 line).
+// ALL fc1 flags are awaited, not just the 32 producers of the K slice: fc2 accumulates into the residual rows fc1 reads, in place,
+// and every fc1 block must have taken its copy first.  A kernel boundary without the boundary: no launch, no cold weight stream
+// behind it (MI355X_MICROARCH.md, rows handoff-flag / prefetch-credit).  Blocks are dispatched in index order, producers never wait,
+// consumers wait only for lower-numbered blocks: no residency requirement.
+// MEASURED (profiles/r05_mlp_chain_phases.txt): 13.1 us against 5.7 + 4.9 for the two launches.  The write-through stores of the
+// slowest fc1 block take 2.8 us to drain, the flags are seen 1.5 us after that, the rows arrive 0.55 us later: 4.5-5 us from
+// "rows stored" to "rows in the consumer's LDS", where a kernel boundary + cold weight stream costs ~3.  A/B only (CW_MLP_CHAIN=1).
+// Bit-identical to the two launches (same K slices, same
+// summation orders; the residual updates are on the 2^-12 grid, so the order of the atomics does not matter).
+// ---------------------------------------------------------------------------------------------------
+template <int NS1, int PL1, int NS2>
+__global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int D = p.D, F = p.F, Mb = p.Mb;
+    const int n1 = F >> 5;
+    const unsigned tag = (p.epoch[0] << 6) | (unsigned)p.layer;
+    const int bid = blockIdx.x;
+    constexpr int NT = 2;
+    if (bid < n1) {
+        // ================= fc1: LN + GEMV tile pair + GELU =================
+        DLPH(0);
+        const int K = D, N = F;
+        const int xs_stride = K + 8;
+        bf16_t* xs = (bf16_t*)msm;                                  // [16][K+8]
+        float* red = (float*)(msm + (size_t)16 * xs_stride * 2);     // [4 waves][NT][4][64]
+        const int n0 = bid * 16 * NT;
+        const int steps = K >> 7, nvec = K >> 2;
+        int nn[NT], ncl[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { nn[t] = n0 + t * 16 + l15; ncl[t] = nn[t] < N ? nn[t] : N - 1; }
+        float bias_v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bias_v[t] = p.b1 ? p.b1[ncl[t]] : 0.f;
+        float4 xv[2][PL1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = wave + 4 * i;
+            row = row < Mb ? row : Mb - 1;
+#pragma unroll
+            for (int c = 0; c < PL1; ++c) {
+                int v4 = lane + 64 * c;
+                v4 = v4 < nvec ? v4 : nvec - 1;
+                xv[i][c] = *(const float4*)(p.x + (size_t)row * K + v4 * 4);
+            }
+        }
+        dl_u32x4_t wq[NT][NS1][4];
+        const bf16_t* __restrict__ W = (const bf16_t*)p.W1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int s = 0; s < NS1; ++s) {
+                int step = wave + 4 * s;
+                step = step < steps ? step : steps - 1;
+                const dl_u32x4_t* wp = (const dl_u32x4_t*)(W + ((((size_t)(ncl[t] >> 4) * (K >> 5)) + step * 4) * 64 + g * 16 + (ncl[t] & 15)) * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * 64];
+            }
+        }
+        DLPH(1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float sx = 0.f;
+#pragma unroll
+            for (int c = 0; c < PL1; ++c) {
+                const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+                sx += ok * ((xv[i][c].x + xv[i][c].y) + (xv[i][c].z + xv[i][c].w));
+            }
+            const float mean = wave_sum(sx) / (float)K;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < PL1; ++c) {
+                const float ok = (lane + 64 * c < nvec) ? 1.f : 0.f;
+                const float a = xv[i][c].x - mean, b = xv[i][c].y - mean, cc = xv[i][c].z - mean, d = xv[i][c].w - mean;
+                q += ok * cw_sumsq4(a, b, cc, d);
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+#pragma unroll
+            for (int c = 0; c < PL1; ++c) {
+                xv[i][c].x = (xv[i][c].x - mean) * rstd; xv[i][c].y = (xv[i][c].y - mean) * rstd;
+                xv[i][c].z = (xv[i][c].z - mean) * rstd; xv[i][c].w = (xv[i][c].w - mean) * rstd;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave + 4 * i;
+#pragma unroll
+            for (int c = 0; c < PL1; ++c) {
+                int v4 = lane + 64 * c;
+                v4 = v4 < nvec ? v4 : nvec - 1;
+                const float4 v = xv[i][c];
+                ushort4 o;
+                o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+                *(ushort4*)(xs + (size_t)row * xs_stride + v4 * 4) = o;
+            }
+        }
+        DLPH(2);
+        __syncthreads();
+        DLPH(3);
+        f32x4_t acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS1; ++s) {
+            const int step = wave + 4 * s;
+            if (step < steps) {
+                const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = cw_mfma_16x16x32(a, __builtin_bit_cast(bf16x8_t, wq[t][s][j]), acc[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+        DLPH(4);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int r = wave;
+            const float v = red[((0 * NT + t) * 4 + r) * 64 + lane] + red[((1 * NT + t) * 4 + r) * 64 + lane] +
+                            red[((2 * NT + t) * 4 + r) * 64 + lane] + red[((3 * NT + t) * 4 + r) * 64 + lane];
+            const int m = g * 4 + r, n = nn[t];
+            const unsigned h16 = (unsigned)f32_to_bf16(gelu_erf(v + bias_v[t]));
+            const unsigned other = (unsigned)__shfl_xor((int)h16, 1, 64);          // the neighbouring column's 16 bits
+            if (m < Mb && n < N && !(l15 & 1))
+                __hip_atomic_store((unsigned*)p.mid + (((size_t)m * F + n) >> 1), h16 | (other << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        DLPH(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores have left the CU ...
+        __syncthreads();                                               // ... and so have the other three waves'
+        DLPH(6);
+        if (tid == 0) dl_gran_st(p.flags + bid, tag, 1u);
+        return;
+    }
+    // ================= fc2: K slice x column pair, weights first =================
+    {
+        const int K = F, N = D;
+        const int nbx = N >> 5;
+        const int fb = bid - n1, bx = fb % nbx, by = fb / nbx;
+        DLPH(0);
+        const int Kb = p.Kb2, kbase = by * Kb;
+        const int xs_stride = Kb + 8;
+        bf16_t* xs = (bf16_t*)msm;
+        float* red = (float*)(msm + (size_t)16 * xs_stride * 2);
+        const int n0 = bx * 16 * NT;
+        const int steps = Kb >> 7;
+        int nn[NT], ncl[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { nn[t] = n0 + t * 16 + l15; ncl[t] = nn[t] < N ? nn[t] : N - 1; }
+        float bias_v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bias_v[t] = p.b2 ? p.b2[ncl[t]] : 0.f;
+        // A/B (CW_MLP_CHAIN_DELAY, units of 64 clocks): hold the weight requests back so that fc1's loads go first
+        for (int dly = p.delay; dly > 0; dly -= 64) __builtin_amdgcn_s_sleep(64);
+        dl_u32x4_t wq[NT][NS2][4];
+        const bf16_t* __restrict__ W = (const bf16_t*)p.W2;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int s = 0; s < NS2; ++s) {
+                int step = wave + 4 * s;
+                step = step < steps ? step : steps - 1;
+                const dl_u32x4_t* wp = (const dl_u32x4_t*)(W + ((((size_t)(ncl[t] >> 4) * (K >> 5)) + (kbase >> 5) + step * 4) * 64 + g * 16 + (ncl[t] & 15)) * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * 64];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        DLPH(1);
+        // every fc1 block has published (and therefore read its copy of the residual rows): up to 512 flags, all eight loads of a
+        // round in flight together
+        if (wave == 0) {
+            bool ready = false;
+#pragma unroll 1
+            for (int spins = 0; !ready; ++spins) {
+                if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }
+                dl_u64_t f[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) f[q] = dl_gran_ld(p.flags + min(lane + 64 * q, n1 - 1));
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ok = ok && (unsigned)(f[q] >> 32) == tag;
+                ready = __all(ok);
+                if (!ready) __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        DLPH(7);
+        __syncthreads();
+        DLPH(8);
+        // the 16-bit rows of the K slice: rows wave, wave + 4 (clamped like the launch path), 8 bytes per lane per load, every load
+        // out before the first LDS write (Kb <= 1024: at most four per row)
+        {
+            const int per_row = Kb >> 8;
+            dl_u64_t mv[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wave + 4 * i;
+                const int rowc = row < Mb ? row : Mb - 1;
+                const dl_u64_t* src = (const dl_u64_t*)((const bf16_t*)p.mid + (size_t)rowc * K + kbase);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) mv[i][c] = dl_gran_ld(src + lane + 64 * min(c, per_row - 1));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wave + 4 * i;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < per_row) *(dl_u64_t*)(xs + (size_t)row * xs_stride + (lane + 64 * c) * 4) = mv[i][c];
+            }
+        }
+        DLPH(9);
+        __syncthreads();
+        f32x4_t acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS2; ++s) {
+            const int step = wave + 4 * s;
+            if (step < steps) {
+                const bf16_t* xr = xs + (size_t)l15 * xs_stride + step * 128 + g * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8_t a = *(const bf16x8_t*)(xr + j * 32);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = cw_mfma_16x16x32(a, __builtin_bit_cast(bf16x8_t, wq[t][s][j]), acc[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave * NT + t) * 4 + r) * 64 + lane] = acc[t][r];
+        DLPH(10);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int r = wave;
+            const float v = red[((0 * NT + t) * 4 + r) * 64 + lane] + red[((1 * NT + t) * 4 + r) * 64 + lane] +
+                            red[((2 * NT + t) * 4 + r) * 64 + lane] + red[((3 * NT + t) * 4 + r) * 64 + lane];
+            const int m = g * 4 + r, n = nn[t];
+            if (m < Mb && n < N) atomicAdd(p.xio + (size_t)m * N + n, resid_grid(v + (by == 0 ? bias_v[t] : 0.f)));
+        }
+        DLPH(11);
+    }
+}
+
+// K slices of fc2 exactly as launch_gemv2 (gemm.hip) picks them for the in-place residual GEMV with two column tiles per block
+static int mlp_chain_ksplit(int D, int F) {
+    int ks = 1;
+    const int tiles = D / 16, steps = F / 128;
+    while (tiles * ks < 256 && steps % (ks * 2) == 0 && steps / (ks * 2) >= 4) ks *= 2;
+    while (F / ks > 1280) ks *= 2;
+    for (int k2 = ks + 1; (D / 32) * k2 <= 256; ++k2) if (F % (k2 * 128) == 0) ks = k2;
+    return ks;
+}
+bool cw_mlp_chain_ok(int Mb, int D, int F) {
+    if (Mb < 1 || Mb > 8 || D % 128 || D <= 768 || D > 1280 || F % 256 || F <= 1280) return false;
+    const int ks = mlp_chain_ksplit(D, F);
+    if (F % ks || (F / ks) % 256 || F / ks > 1024 || F / ks < 512) return false;     // NS2 = 2 covers 5..8 K steps per slice
+    // the launch path must make the same choices: two tiles per fc2 block (grid (D / 16) x ks > 256 blocks) and per fc1 block
+    return (D / 16) * ks > 256 && (D / 32) * ks >= 128 && F / 16 > 256 && F / 32 >= 128 && F / 32 <= 512;
+}
+
+int cw_launch_mlp_chain(const MlpChainParams& p0, hipStream_t st) {
+    MlpChainParams p = p0;
+    if (!cw_mlp_chain_ok(p.Mb, p.D, p.F) || !p.flags || !p.epoch || !p.err || !p.mid || !p.x || !p.xio) return CW_ERR_INVALID;
+    const int ks = mlp_chain_ksplit(p.D, p.F);
+    p.Kb2 = p.F / ks;
+    p.delay = cw_sw::cw_switches().mlp_chain_delay;
+    const size_t lds1 = (size_t)16 * (p.D + 8) * 2 + 4 * 2 * 4 * 64 * 4, lds2 = (size_t)16 * (p.Kb2 + 8) * 2 + 4 * 2 * 4 * 64 * 4;
+    const size_t lds = lds1 > lds2 ? lds1 : lds2;
+    const dim3 grid(p.F / 32 + (p.D / 32) * ks);
+    static std::once_flag attr;
+    std::call_once(attr, [] { (void)hipFuncSetAttribute((const void*)mlp_chain_kernel<3, 5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); });
+    hipLaunchKernelGGL((mlp_chain_kernel<3, 5, 2>), grid, dim3(256), lds, st, p);
+    return CW_OK;
+}
+
 size_t cw_dec_layer_lds(int D) {
     return (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 16 + 32 + 32 + 4 * 64 + 4 * 8 * 64 + 4) * 4 + (size_t)4 * 16 * 1024;
 }

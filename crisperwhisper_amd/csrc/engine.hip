@@ -22,12 +22,13 @@ static thread_local char g_err[512] = "";
 // launches of one decoder layer, as decode_step issues them (cw_time_decode_stage / cw_decode_stage_name)
 #define CW_MAX_DEC_STAGES 24
 enum DecStageKind { DST_OTHER = 0, DST_QKV_SELF, DST_QKV, DST_SELF_ATTN, DST_O_PROJ, DST_STACK, DST_STACK_CROSS, DST_CROSS_Q, DST_CROSS_ATTN,
-                    DST_CROSS_O, DST_FC1, DST_FC2, DST_MLP_PAIR, DST_N };
+                    DST_CROSS_O, DST_FC1, DST_FC2, DST_MLP_PAIR, DST_MLP_CHAIN, DST_N };
 static const char* const kDecStageName[DST_N] = {
     "other (A/B path)", "LayerNorm + q/k/v projection + self-attention (qkv_self_kernel)", "LayerNorm + q/k/v projection + cache append",
     "self-attention", "self-attention out-projection", "fused out-projection + cross-query stage (gemv_stack_kernel)",
     "fused stage + cross-attention (dec_layer_a_kernel)", "LayerNorm + cross-attention query projection", "cross-attention",
-    "cross-attention out-projection (combines the key-split partials)", "LayerNorm + fc1 + GELU", "fc2", "fc1 + fc2 (mlp_pair_kernel)"};
+    "cross-attention out-projection (combines the key-split partials)", "LayerNorm + fc1 + GELU", "fc2", "fc1 + fc2 (mlp_pair_kernel)",
+    "LayerNorm + fc1 + GELU + fc2 in one launch (mlp_chain_kernel)"};
 
 struct LayerW {
     void* wqkv = nullptr; float* bqkv = nullptr;
@@ -101,7 +102,9 @@ struct cw_ctx {
     bool declayer = false;          // CW_DECLAYER=1: stage A of declayer.hip (fused stage + cross-attention in one persistent launch; bit-identical,
                                     // measured SLOWER: 22-24 us against 18.4 for the two launches -- A/B and differential test only)
     bool qkv_self = true;           // q/k/v projection + self-attention in one launch (declayer.hip: qkv_self_kernel); CW_NO_QKV_SELF=1: two launches
-    unsigned long long *d_gq = nullptr, *d_gps = nullptr, *d_gq2 = nullptr, *d_gkv = nullptr;
+    unsigned long long *d_gq = nullptr, *d_gps = nullptr, *d_gq2 = nullptr, *d_gkv = nullptr, *d_gflag = nullptr;
+    bool mlp_chain = false;         // CW_MLP_CHAIN=1: fc1 + fc2 in one launch (declayer.hip: mlp_chain_kernel; flags instead of a kernel boundary);
+                                    // bit-identical, measured SLOWER: 13.1 us against 5.7 + 4.9 for the two launches (profiles/r05_mlp_chain_phases.txt)
     unsigned int* d_epoch = nullptr;
     int n_cu = 0;
     int stack_nt3 = 0, stack_nt5 = 0;   // column tiles per block of the two stacked GEMVs (0 = launcher's choice; CW_STACK_NT3/5)
@@ -399,6 +402,7 @@ static int create_impl(cw_ctx* c) {
     c->mlp_pair_fence = sw.mlp_pair_fence;
     c->declayer = sw.declayer;
     c->qkv_self = !sw.no_qkv_self;
+    c->mlp_chain = sw.mlp_chain;
     c->stack_nt3 = sw.stack_nt3;
     c->stack_nt5 = sw.stack_nt5;
     c->prefetch = sw.prefetch;   // experiments builds only (refused above otherwise)
@@ -547,6 +551,7 @@ static int create_impl(cw_ctx* c) {
     {   // declayer.hip: granules are valid by tag only (never cleared); epoch 0 is never used
         CWCHK(c, dmalloc(c, &c->d_gq, (size_t)2 * 16 * D * 8)); CWCHK(c, dmalloc(c, &c->d_gps, (size_t)(D / 16) * 16 * 2 * 8));
         CWCHK(c, dmalloc(c, &c->d_gq2, (size_t)16 * D * 8)); CWCHK(c, dmalloc(c, &c->d_gkv, (size_t)2 * 16 * (D / 2) * 8));
+        CWCHK(c, dmalloc(c, &c->d_gflag, (size_t)512 * 8));
         CWCHK(c, dmalloc(c, &c->d_epoch, 4));
         const unsigned int one = 1;
         HIPCHK(c, hipMemcpy(c->d_epoch, &one, 4, hipMemcpyHostToDevice));
@@ -1272,6 +1277,14 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                     // LN + fc1 + GELU, group barrier, fc2 + residual in one launch (decfuse.hip: mlp_pair_kernel)
                     MlpPairParams mp{xalt, L.w1, L.b1, L.w2, L.b2, c->d_xfrag2, c->d_bar, c->d_err, nb, D, F, c->wpacked ? 1 : 0, c->mlp_pair_fence ? 1 : 0};
                     STG(DST_MLP_PAIR, KD(c, cw_launch_mlp_pair, mp, c->st));
+                } else if (c->mlp_chain && c->wpacked && c->mid16 && nb <= 8 && KD(c, cw_mlp_chain_ok, nb, D, F)) {
+                    // LN + fc1 + GELU and fc2 + residual in ONE launch: fc2's blocks request their weights at kernel entry and wait for
+                    // the fc1 blocks' flags instead of a kernel boundary (declayer.hip: mlp_chain_kernel); bit-identical
+                    MlpChainParams mp;
+                    memset(&mp, 0, sizeof(mp));
+                    mp.x = xalt; mp.W1 = L.w1; mp.b1 = L.b1; mp.W2 = L.w2; mp.b2 = L.b2; mp.xio = xalt; mp.mid = c->d_xfrag2;
+                    mp.flags = c->d_gflag; mp.epoch = c->d_epoch; mp.layer = l; mp.err = c->d_err; mp.Mb = nb; mp.D = D; mp.F = F;
+                    STG(DST_MLP_CHAIN, KD(c, cw_launch_mlp_chain, mp, c->st));
                 } else {
                     // fc1 writes gelu(.) in the 16-bit type fc2 would round it to anyway (bit-identical): fc2's activation load halves
                     const bool mid16 = F > 1280 && c->mid16;
@@ -2712,7 +2725,7 @@ int32_t cw_time_decode_stage(cw_ctx* c, int32_t nb, int32_t stage, int32_t iters
             case DST_CROSS_O: return (double)D * D * e + 2.0 * act;
             case DST_FC1: return (double)F * D * e + act + (double)nb * F * e;
             case DST_FC2: return (double)F * D * e + (double)nb * F * e + 2.0 * act;
-            case DST_MLP_PAIR: return 2.0 * F * D * e + 3.0 * act;
+            case DST_MLP_PAIR: case DST_MLP_CHAIN: return 2.0 * F * D * e + 3.0 * act;
             default: return 0.0;
         }
     };

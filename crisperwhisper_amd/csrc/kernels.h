@@ -275,6 +275,25 @@ struct QkvSelfParams {
     int Mb, D, H;
 };
 
+// declayer.hip: LayerNorm + fc1 + GELU and fc2 + residual of rows <= 8 in ONE launch (fc1 blocks publish a flag each, fc2 blocks
+// request their weights at entry and wait for the flags)
+struct MlpChainParams {
+    const float* x;            // [Mb][D] residual rows entering the MLP (LayerNorm gamma / beta folded into W1 / b1)
+    const void* W1;            // [F][D] 16-bit fragment-major
+    const float* b1;           // [F]
+    const void* W2;            // [D][F] 16-bit fragment-major
+    const float* b2;           // [D]
+    float* xio;                // [Mb][D] the residual rows again: fc2 accumulates x += grid(W2 mid + b2) in place
+    void* mid;                 // [Mb][F] 16-bit gelu(fc1) rows (written write-through, read by sc1 loads)
+    unsigned long long* flags; // [F / 32] {tag, 1}: fc1 block j has drained its stores
+    const unsigned int* epoch;
+    int layer;
+    int* err;
+    int Mb, D, F;
+    int Kb2;                   // set by the launcher: K slice of an fc2 block
+    int delay;                 // A/B: the fc2 blocks sleep this many x 64 clocks before they request their weights
+};
+
 // mel.hip
 struct MelTables {
     const double* cos_t;  // [400]
@@ -312,6 +331,8 @@ struct MelTables {
     int cw_launch_fold_rowvec(const float* A, const float* s, float scale, const float* v, const void* W16, int N, int J, float* c_out, float* w_out, hipStream_t st); \
     int cw_launch_gemv_stack(const StackParams& p, int nt, hipStream_t st); \
     int cw_launch_dec_layer(const DecLayerParams& p, int n_cu, hipStream_t st); \
+    bool cw_mlp_chain_ok(int Mb, int D, int F); \
+    int cw_launch_mlp_chain(const MlpChainParams& p, hipStream_t st); \
     int cw_launch_qkv_self(const QkvSelfParams& p, hipStream_t st); \
     size_t cw_dec_layer_lds(int D); \
     int cw_launch_gemv_fc2x(const Fc2xParams& p, hipStream_t st); \

@@ -23,6 +23,7 @@ Switches read_switches() {
     s.mlp_pair_fence = flag("CW_MLP_PAIR_FENCE");
     s.declayer = flag("CW_DECLAYER");
     s.no_qkv_self = flag("CW_NO_QKV_SELF");
+    s.mlp_chain = flag("CW_MLP_CHAIN");
     s.skinny = num("CW_SKINNY", 0);
     s.prefetch = num("CW_PREFETCH", 0);
     s.prefetch_wide = num("CW_PREFETCH_WIDE", 0);
@@ -40,6 +41,7 @@ Switches read_switches() {
     s.cross8_nsb = num("CW_CROSS8_NSB", 0);
     s.dl_depth = num("CW_DL_DEPTH", 16);
     s.dl_kvwait = num("CW_DL_KVWAIT", 0);
+    s.mlp_chain_delay = num("CW_MLP_CHAIN_DELAY", 0);
     s.qkv_self_dbg = num("CW_QKV_SELF_DBG", 0);
     s.no_glds = flag("CW_NO_GLDS");
     s.no_gemm256 = flag("CW_NO_GEMM256");
@@ -64,6 +66,7 @@ Switches read_switches() {
     if (s.stack_nt3 < 0 || s.stack_nt3 > 3) s.stack_nt3 = 0;
     if (s.stack_nt5 < 0 || s.stack_nt5 > 3) s.stack_nt5 = 0;
     if (s.prefetch < 0) s.prefetch = 0;
+    if (s.mlp_chain_delay < 0 || s.mlp_chain_delay > 4096) s.mlp_chain_delay = 0;
     if (s.test_gemm_reps < 0) s.test_gemm_reps = 0;
     if (s.test_attn_reps < 0) s.test_attn_reps = 0;
     return s;

@@ -1219,12 +1219,15 @@ def test_logits_projection_persistent_column_loop_is_bit_identical(dt, rows):
 
 
 @pytest.mark.parametrize("feature,rows,dt", [("qkv_self", 8, "bf16"), ("qkv_self", 8, "f16"), ("qkv_self", 5, "bf16"), ("qkv_self", 1, "bf16"),
-                                             ("declayer", 8, "bf16"), ("declayer", 8, "f16"), ("declayer", 3, "bf16")])
+                                             ("declayer", 8, "bf16"), ("declayer", 8, "f16"), ("declayer", 3, "bf16"),
+                                             ("mlp_chain", 8, "bf16"), ("mlp_chain", 8, "f16"), ("mlp_chain", 5, "bf16"), ("mlp_chain", 1, "bf16")])
 def test_persistent_decoder_layer_is_bit_identical(feature, rows, dt):
     """csrc/declayer.hip: decoder stages that hand their results across CUs INSIDE a launch as 8-byte {tag, value} granules.
     qkv_self: LayerNorm + q/k/v projection + self-attention in one launch (default) against CW_NO_QKV_SELF=1 (two launches);
     declayer: fused out-projection / cross-query stage + cross-attention in one persistent launch (CW_DECLAYER=1, one 1024-thread
-    workgroup per CU; measured slower, A/B only) against the two launches.  Same arithmetic in the same order, so EVERYTHING must
+    workgroup per CU; measured slower, A/B only) against the two launches; mlp_chain: LayerNorm + fc1 + GELU and fc2 + residual in
+    one launch (CW_MLP_CHAIN=1; fc2's blocks take their weights at kernel entry and wait for the fc1 blocks' flags; measured slower,
+    A/B only) against the two launches.  Same arithmetic in the same order, so EVERYTHING must
     be bit-identical: the logits of the captured steps, every token of > 2000 consecutive free-running decoder forwards (five
     generate calls of 440 positions -- history longer than the 128 keys of the attention's register path -- through graph replay:
     the granule tags come from a device counter), the alignment rows and the token timestamps.  A missed or stale hand-off changes
@@ -1239,7 +1242,8 @@ def test_persistent_decoder_layer_is_bit_identical(feature, rows, dt):
     T = TGT - 4
     clips = [syn.synth_audio(700 + i, 480000 - 20000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
     prompt = np.tile(np.array([[v.sot, v.lang_id("en"), v.transcribe]], np.int32), (rows, 1))
-    envs = {"qkv_self": ({}, {"CW_NO_QKV_SELF": "1"}), "declayer": ({"CW_DECLAYER": "1", "CW_NO_QKV_SELF": "1"}, {"CW_NO_QKV_SELF": "1"})}[feature]
+    envs = {"qkv_self": ({}, {"CW_NO_QKV_SELF": "1"}), "declayer": ({"CW_DECLAYER": "1", "CW_NO_QKV_SELF": "1"}, {"CW_NO_QKV_SELF": "1"}),
+            "mlp_chain": ({"CW_MLP_CHAIN": "1"}, {})}[feature]
     res = {}
     for mode, env in zip(("fused", "launches"), envs):
         os.environ.update(env)
