@@ -405,8 +405,20 @@ def main():
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         return float(tt.item())
 
+    dt_local = dt
+
+    def over_ranks(x, op):
+        if pg is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=f"cuda:{dev}" if pg == "nccl" else "cpu")
+        td.all_reduce(tt, op=op)
+        return float(tt.item())
+
     dt = max_over_ranks(dt)
+    dt_min = over_ranks(dt_local, td.ReduceOp.MIN) if pg is not None else dt_local
     n_gathers = shard.n_collectives
+    gather_us = shard.gather_s / max(n_gathers, 1) * 1e6          # this rank's average; the slowest rank's is reduced below
+    gather_us_max = over_ranks(gather_us, td.ReduceOp.MAX) if pg is not None else gather_us
     stages = eng.stage_times()
     for e_ in engines[1:]:
         for k_, (ms_, n_) in e_.stage_times().items():
@@ -448,9 +460,14 @@ def main():
         pipe(xl[: min(len(xl), 100 * 16000)], generate_kwargs=gk)                       # warm-up of this call path
         fence()
         t0 = time.perf_counter()
-        res = cw.adjust_pauses_for_hf_pipeline_output(pipe(xl, generate_kwargs=gk), engine=eng)
+        res = pipe(xl, generate_kwargs=gk)
+        t_p = time.perf_counter()
+        res = cw.adjust_pauses_for_hf_pipeline_output(res, engine=eng)
+        t_q = time.perf_counter()
         fence()
         lw = max_over_ranks(time.perf_counter() - t0)
+        lf_phase = dict(pipe.stats.get("last_call_phase_s", {}))
+        lf_phase["pause_split"] = t_q - t_p
         longform = {"workload": f"BASELINE configs[2]: {a.longform_seconds} s recording -> {n_chunks} chunks (30 s, 5 s strides), "
                                 f"contiguous chunk shards over {world} rank(s) = {[h - l for l, h in dist.shard_bounds(n_chunks, world)]}, "
                                 f"batch {B}, {a.tokens} tokens/pass, one all-gather of {dist.REC_WORDS * 4}-byte chunk records, seam merge + pause split",
@@ -458,7 +475,9 @@ def main():
                     "chunk_shards": [h - l for l, h in dist.shard_bounds(n_chunks, world)],
                     # digest of the merged output (text + every word with its timestamps): the same at every rank count
                     "output_sha1": hashlib.sha1(json.dumps([res["text"], [[c["text"], list(c["timestamp"])] for c in res["chunks"]]]).encode()).hexdigest(),
-                    "scaling": "strong", "n_gpus": world}
+                    "scaling": "strong", "n_gpus": world,
+                    # rank 0's wall time by phase: only `local_batches` shrinks with the rank count
+                    "phase_s_rank0": {k: (round(v_, 4) if isinstance(v_, float) else v_) for k, v_ in lf_phase.items()}}
     # roofline of the decode step: EVERY launch of the decoder layer as the step issues it at this batch (cw_time_decode_stage runs
     # the step's own launch code one stage at a time) + the logits projection, HIP events on the engine's own stream
     roof = []
@@ -532,7 +551,13 @@ def main():
             "parity": parity,
             "collective": {"backend": ("rccl (torch.distributed nccl)" if pg == "nccl" else pg), "all_gathers_in_timed_region": n_gathers,
                            "ranks_seen": (td.get_world_size() if pg is not None else 1), "devices_visible": ndev,
-                           "chunks_per_rank": [B * C] * world, "note": pg_note},
+                           "chunks_per_rank": [B * C] * world, "note": pg_note,
+                           # what a reader needs to hold an N-GPU line against the N = 1 line: every rank runs the
+                           # N = 1 workload, so per-rank ms_per_step must equal the N = 1 ms_per_step and value must be N x the N = 1 value
+                           "per_rank_ms_per_step": {"min": dt_min / a.steps * 1e3, "max": dt / a.steps * 1e3},
+                           "gather_us_per_call": {"rank0": gather_us, "max_over_ranks": gather_us_max},
+                           "gather_bytes_per_rank": int(B * C * dist.WORD_REC * 4) if hasattr(dist, "WORD_REC") else None,
+                           "expect": "weak scaling: value(N) = N x value(1) x (1 - gather / step), per-rank ms_per_step = N = 1 ms_per_step; DESIGN.md section 5 holds the prediction"},
             "longform": longform,
             "roofline_other": [{"kernel": r_["kernel"], "achieved_GBps": r_["achieved"], "frac_of_8TBps": r_["achieved"] / 8000.0,
                                 "avg_launch_ms": r_["avg_ms"], "algorithmic_bytes_per_launch": r_["algo_bytes"],

@@ -83,14 +83,17 @@ class Shard:
         self.rank, self.world, self.device = rank, world, device
         self.collective_at_world1 = collective_at_world1
         self.n_collectives = 0
+        self.gather_s = 0.0            # host wall time spent inside all_gather_records (staging copy + collective + copy back)
 
     def all_gather_records(self, recs: np.ndarray, max_per_rank: int) -> np.ndarray:
         """recs [n_local, W] int32 (W = REC_WORDS or WORD_REC) -> [n_total, W] ordered by chunk index."""
         if self.world == 1 and not self.collective_at_world1:
             return recs
         self.n_collectives += 1
+        import time
         import torch
         import torch.distributed as dist
+        t_g0 = time.perf_counter()
         REC_WORDS = recs.shape[1]
         buf = np.full((max_per_rank, REC_WORDS), -1, dtype=np.int32)
         buf[:len(recs)] = recs
@@ -100,5 +103,6 @@ class Shard:
         out = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(out, t)
         allr = torch.stack(out).cpu().numpy().reshape(-1, REC_WORDS)
+        self.gather_s += time.perf_counter() - t_g0
         allr = allr[allr[:, 0] >= 0]
         return allr[np.argsort(allr[:, 0], kind="stable")]

@@ -368,7 +368,10 @@ class CrisperWhisperPipeline:
         num_beams = int(gk.get("num_beams", self.default_num_beams))
         if gk.get("length_penalty") not in (None, 1.0) or gk.get("early_stopping") not in (None, False):
             raise ValueError("only the default length_penalty=1.0 / early_stopping=False beam search is implemented")
+        import time as _time
+        t_ph = [_time.perf_counter()]                       # phase clock of this call: load | local batches | gather | collation
         pcm = self._load(inputs)
+        t_ph.append(_time.perf_counter())
         cl = self.chunk_length_s if chunk_length_s is None else chunk_length_s
         sl = self.stride_length_s if stride_length_s is None else stride_length_s
         sr = self.sampling_rate
@@ -433,7 +436,9 @@ class CrisperWhisperPipeline:
         self.stats["generate_calls"] = self.stats.get("generate_calls", 0) + sum(c for _, c in results)
         recs = np.stack(recs) if recs else np.zeros((0, dist.REC_WORDS), np.int32)
         max_per_rank = max(h - l for l, h in dist.shard_bounds(len(windows), self.shard.world))
+        t_ph.append(_time.perf_counter())
         allr = self.shard.all_gather_records(recs, max_per_rank)
+        t_ph.append(_time.perf_counter())
         outputs = []
         for r in allr:
             _, toks, ts, stride = dist.unpack_record(r)
@@ -443,6 +448,11 @@ class CrisperWhisperPipeline:
             outputs.append(o)
         text, words = collate.decode_asr(self.vocab, outputs, time_precision=0.02, warn=logger.warning,
                                          return_timestamps="word" if rt == "word" else True)
+        t_ph.append(_time.perf_counter())
+        # where the wall time of the last call went on this rank (bench.py's long-form leg prints it: the scaling model of
+        # DESIGN.md section 5 needs the rank-local part, which shrinks with the rank count, apart from the rest, which does not)
+        self.stats["last_call_phase_s"] = {"load": t_ph[1] - t_ph[0], "local_batches": t_ph[2] - t_ph[1], "gather": t_ph[3] - t_ph[2],
+                                           "collate_all_chunks": t_ph[4] - t_ph[3], "local_chunks": len(mine), "all_chunks": len(windows)}
         return {"text": text, "chunks": words}
 
 
