@@ -552,6 +552,8 @@ def main():
             "collective": {"backend": ("rccl (torch.distributed nccl)" if pg == "nccl" else pg), "all_gathers_in_timed_region": n_gathers,
                            "ranks_seen": (td.get_world_size() if pg is not None else 1), "devices_visible": ndev,
                            "chunks_per_rank": [B * C] * world, "note": pg_note,
+                           # > 0 only when this rank's GPU is shared with other work: calls repeated on the launch-per-stage decoder kernels
+                           "handoff_fallbacks_rank0": sum(int(e_.lib.cw_handoff_fallbacks(e_.ctx)) for e_ in engines),
                            # what a reader needs to hold an N-GPU line against the N = 1 line: every rank runs the
                            # N = 1 workload, so per-rank ms_per_step must equal the N = 1 ms_per_step and value must be N x the N = 1 value
                            "per_rank_ms_per_step": {"min": dt_min / a.steps * 1e3, "max": dt / a.steps * 1e3},

@@ -106,6 +106,7 @@ _SIGS = {
     "cw_time_kernel": (_I, [_P, _I, _I, _I, _P, _P]),
     "cw_time_decode_stage": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "cw_decode_stage_name": (C.c_char_p, [_I]),
+    "cw_handoff_fallbacks": (_I, [_P]),
 }
 
 _lib = None

@@ -498,8 +498,14 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
 //   rows of the history are requested at kernel entry (they depend on nothing), the query and THIS step's key / value row come
 //   from the granules of the 12 tiles of the head, polled by wave 4 (whose memory queue holds nothing else by then).
 // Unlike stage A above the hand-off happens on a quiet memory system: every block has taken in its 80 KB before anybody polls.
-// Producers never wait, consumers wait only after they have produced: no residency requirement beyond "every block gets a slot
-// eventually".
+// Producers never wait, consumers wait only after they have produced.  RESIDENCY: block i < rows x heads waits for tiles up to
+// 3 D / 16 - 1, so all 240 blocks (122 k threads of the chip's 524 k) must get a slot while the first ones poll.  Alone on the GPU
+// they always do.  When several processes share it (tests/test_dist_gloo.py runs eight ranks on one device) the polling blocks of
+// all of them can hold every slot, the polls run into DL_SPIN_LIMIT and set `err`; the engine then repeats the call with the
+// two-launch path (bit-identical) and keeps this context on it (engine.hip: handoff_gave_up).  Two block orders that need no
+// co-residency were measured and rejected: item blocks behind all tile blocks 8.35 us per launch (7.9 as it is; the XCDs dispatch
+// their shares of a grid independently, so even that order is not a guarantee across processes), items behind the tiles of
+// their head 10.7 us.
 // ---------------------------------------------------------------------------------------------------
 #define QS_THREADS 512
 #define QS_GROUPS (QS_THREADS / 8)

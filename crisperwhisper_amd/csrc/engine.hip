@@ -98,6 +98,7 @@ struct cw_ctx {
     bool mlp_pair_fence = false;    // CW_MLP_PAIR_FENCE=1: round-3 hand-over (agent-scope acquire fence behind the group barrier)
     bool mlp_pair = false;          // CW_MLP_PAIR=1: fc1 + fc2 in one launch with an in-kernel group barrier (A/B: 23 us against 12.8 for two launches)
     unsigned int* d_bar = nullptr; int* d_err = nullptr;   // group barriers of mlp_pair_kernel; "a block gave up waiting" flag
+    int handoff_fallbacks = 0;      // times a call was repeated on the launch-per-stage path because an in-launch hand-off gave up
     // persistent decoder-layer kernel (declayer.hip), rows <= 8: granule buffers, the epoch counter their tags carry, CU count
     bool declayer = false;          // CW_DECLAYER=1: stage A of declayer.hip (fused stage + cross-attention in one persistent launch; bit-identical,
                                     // measured SLOWER: 22-24 us against 18.4 for the two launches -- A/B and differential test only)
@@ -1452,9 +1453,51 @@ static int run_step(cw_ctx* c, int nb) {
     return CW_OK;
 }
 
+// ---- in-launch hand-offs that gave up -------------------------------------------------------------------------------------
+// The kernels of declayer.hip (and the A/B kernel mlp_pair_kernel) let blocks of ONE launch wait for each other.  That needs the
+// waiting blocks and the ones they wait for on the chip together -- always true when the context has the GPU to itself, not
+// when other processes fill it (eight ranks on one device: tests/test_dist_gloo.py).  A block that polls DL_SPIN_LIMIT times
+// without success sets d_err and carries on with garbage.  The entry points below check the flag when their work has drained
+// and, if it is set, switch every such kernel off for this context (for good) and run the call again: the launch-per-stage
+// kernels are bit-identical, so the caller sees the result it would have had, late.
+#define CW_HANDOFF_RETRY 0x7e57
+static void drop_step_graphs(cw_ctx* c);
+static bool handoffs_on(const cw_ctx* c) { return c->qkv_self || c->mlp_chain || c->declayer || c->mlp_pair; }
+static int handoff_gave_up(cw_ctx* c, bool* gave_up) {
+    int e = 0;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
+    *gave_up = e != 0;
+    if (e) { HIPCHK(c, hipMemset(c->d_err, 0, 4)); HIPCHK(c, hipMemset(c->d_bar, 0, 64 * 4)); }
+    return CW_OK;
+}
+static int handoffs_off(cw_ctx* c, const char* where) {
+    if (!handoffs_on(c)) return fail(c, CW_ERR_HIP, "%s: an in-launch hand-off gave up although none is enabled", where);
+    c->qkv_self = c->mlp_chain = c->declayer = c->mlp_pair = false;
+    drop_step_graphs(c);
+    if (c->handoff_fallbacks++ == 0)
+        fprintf(stderr, "crisperwhisper: %s: blocks of one launch waited for each other in vain (GPU shared with other work?); "
+                        "this context continues on the launch-per-stage decoder kernels (same results)\n", where);
+    return CW_OK;
+}
+int32_t cw_handoff_fallbacks(cw_ctx* c) { return c->handoff_fallbacks; }
+
+static int decode_once(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt, int32_t max_length,
+                       int32_t min_new_tokens, const int32_t* forced, int32_t* sequences, int32_t* lengths,
+                       int32_t* argmax_out);
 int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt, int32_t max_length,
                   int32_t min_new_tokens, const int32_t* forced, int32_t* sequences, int32_t* lengths,
                   int32_t* argmax_out) {
+    int r = decode_once(c, nb, prompt, n_prompt, max_length, min_new_tokens, forced, sequences, lengths, argmax_out);
+    if (r != CW_HANDOFF_RETRY) return r;
+    CWCHK(c, handoffs_off(c, "decode"));
+    r = decode_once(c, nb, prompt, n_prompt, max_length, min_new_tokens, forced, sequences, lengths, argmax_out);
+    return r == CW_HANDOFF_RETRY ? fail(c, CW_ERR_HIP, "decode: an in-kernel wait timed out on the launch-per-stage path") : r;
+}
+
+static int decode_once(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt, int32_t max_length,
+                       int32_t min_new_tokens, const int32_t* forced, int32_t* sequences, int32_t* lengths,
+                       int32_t* argmax_out) {
     const int D = c->d.d_model, V = c->d.vocab_size, TGT = c->d.max_target_positions;
     if (!c->gen_set) return fail(c, CW_ERR_STATE, "cw_set_generation not called");
     if (nb < 1 || nb > c->nb_encoded) return fail(c, CW_ERR_STATE, "nb=%d but %d windows encoded", nb, c->nb_encoded);
@@ -1516,10 +1559,10 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->st));
-    {   // a block of a launch with an in-kernel barrier gave up waiting (never expected: all of its blocks are co-resident)
-        int e = 0;
-        HIPCHK(c, hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
-        if (e) { hipMemset(c->d_err, 0, 4); hipMemset(c->d_bar, 0, 64 * 4); return fail(c, CW_ERR_HIP, "decode: an in-kernel group barrier timed out"); }
+    {   // a block of a launch with an in-kernel wait gave up (GPU shared with other work): cw_decode repeats the call
+        bool gave_up = false;
+        CWCHK(c, handoff_gave_up(c, &gave_up));
+        if (gave_up) { tm.stop(); return CW_HANDOFF_RETRY; }
     }
     if (first_copied >= 0)                 // true end = first step after which no row was running
         for (int s2 = first_copied; s2 < step; ++s2)
@@ -1543,7 +1586,7 @@ int32_t cw_decode(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt
 }
 
 // ---- deterministic half of generate_with_fallback (generation_whisper.py:970-1116, 1243-1287)
-static void drop_step_graphs(cw_ctx* c) {
+static void drop_step_graphs(cw_ctx* c) {   // (declared above cw_decode)
     for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // kernel arguments are baked into the graphs
 }
 
@@ -1584,10 +1627,17 @@ int32_t cw_no_speech_probs(cw_ctx* c, int32_t nb, int32_t sot_token, float* out)
     for (int b = 0; b < nb; ++b) ids[(size_t)b * TGT] = sot_token;
     HIPCHK(c, hipMemcpyAsync(c->d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
-    CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 0, nb, c->st, c->d_epoch));
-    CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, 0, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
-    CWCHK(c, decode_step(c, nb, true));
-    KCHK(c);
+    for (int attempt = 0;; ++attempt) {
+        CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 0, nb, c->st, c->d_epoch));
+        CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, 0, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
+        CWCHK(c, decode_step(c, nb, true));
+        KCHK(c);
+        bool gave_up = false;
+        CWCHK(c, handoff_gave_up(c, &gave_up));
+        if (!gave_up) break;
+        if (attempt) return fail(c, CW_ERR_HIP, "no_speech_probs: an in-kernel wait timed out on the launch-per-stage path");
+        CWCHK(c, handoffs_off(c, "no_speech_probs"));
+    }
     std::vector<float> lg((size_t)nb * V);
     CWCHK(c, cw_get_logits(c, lg.data(), nb));
     for (int b = 0; b < nb; ++b) {

@@ -303,6 +303,10 @@ int32_t cw_time_kernel(cw_ctx* ctx, int32_t which, int32_t nb, int32_t iters, fl
 int32_t cw_time_decode_stage(cw_ctx* ctx, int32_t nb, int32_t stage, int32_t iters, float* avg_ms, double* algo_bytes,
                              int32_t* kind, int32_t* n_stages);
 const char* cw_decode_stage_name(int32_t kind);
+/* Number of calls this context repeated on the launch-per-stage decoder kernels because blocks of one launch waited for each other
+ * in vain (only when the GPU is shared with other work; 0 in normal operation).  After the first one the context stays on those
+ * kernels; results are identical either way. */
+int32_t cw_handoff_fallbacks(cw_ctx* ctx);
 
 #ifdef __cplusplus
 }
