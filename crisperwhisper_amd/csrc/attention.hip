@@ -1679,7 +1679,7 @@ __device__ inline long split3_e4m3(const float* x, int term) {
 template <int NSB, bool FUSED>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSplitParams p) {
     __shared__ float s_max[NSB * 8];
-    __shared__ float s_qf[FUSED ? 64 : 1];
+    __shared__ __attribute__((aligned(16))) float s_qf[FUSED ? 8 * 64 : 1];   // FUSED: a wave-private row each
     __shared__ __attribute__((aligned(16))) float red[NSB * 8 * 64];
     __shared__ float red_l[NSB * 8];
     __shared__ __attribute__((aligned(16))) float s_p[8 * 32];
@@ -1693,6 +1693,16 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
     const int D = p.H * 64;
     const int bk = p.kv_div > 1 ? b / p.kv_div : b;
     const size_t bh = (size_t)bk * p.H + h;
+    // FUSED: every wave finishes the query itself (no block barrier in front of the first MFMA); its six small loads (256 B per
+    // wave instruction) go out before the K / V rows so that they come back first
+    float2 pt0 = make_float2(0.f, 0.f), pt1 = pt0;
+    float qa1 = 0.f, qb1 = 0.f, qw1 = 0.f, qc1 = 0.f;
+    if (FUSED) {
+        pt0 = *(const float2*)(p.pstats + ((size_t)min(lane, p.n_pstats - 1) * 16 + b) * 2);
+        pt1 = *(const float2*)(p.pstats + ((size_t)min(lane + 64, p.n_pstats - 1) * 16 + b) * 2);
+        const size_t col = (size_t)h * 64 + lane;
+        qa1 = p.qa[(size_t)b * D + col]; qb1 = p.qb[(size_t)b * D + col]; qw1 = p.qw[col]; qc1 = p.qbias[col];
+    }
     // every load of the block first
     int k_lo[NSB], nk[NSB];
     uint4 kf[NSB][2], vf[NSB][2];
@@ -1713,26 +1723,40 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
     // the query fragments are the same for all eight waves: wave 0 loads the row (16 B-per-lane loads cost the CU's address
     // unit 16 clocks each whatever they fetch), scales it to the e4m3 range and splits it; the others pick the 16 bytes up from
     // LDS behind a barrier that their own K / V loads are in flight across
+    long aq0, aq1;
+    float c1;
+    if (FUSED) {
+        __builtin_amdgcn_sched_barrier(0);                        // the K / V requests are out before the first wait
+        const float inv_d = 1.0f / (float)D;
+        const float ps1 = (lane < p.n_pstats ? pt0.x : 0.f) + (lane + 64 < p.n_pstats ? pt1.x : 0.f);
+        const float ps2 = (lane < p.n_pstats ? pt0.y : 0.f) + (lane + 64 < p.n_pstats ? pt1.y : 0.f);
+        const float mean = wave_sum(ps1) * inv_d;
+        const float var = fmaxf(wave_sum(ps2) * inv_d - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        float* sq = s_qf + wave * 64;                              // wave-private: ordered by the wave's own lgkmcnt
+        sq[lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float qf[16];
+        const float* qp = sq + g * 16;
+        const float4 q0 = *(const float4*)qp, q1 = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
+        qf[0] = q0.x; qf[1] = q0.y; qf[2] = q0.z; qf[3] = q0.w; qf[4] = q1.x; qf[5] = q1.y; qf[6] = q1.z; qf[7] = q1.w;
+        qf[8] = q2.x; qf[9] = q2.y; qf[10] = q2.z; qf[11] = q2.w; qf[12] = q3.x; qf[13] = q3.y; qf[14] = q3.z; qf[15] = q3.w;
+        float am = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(qf[e]));
+        am = fmaxf(am, __shfl_xor(am, 16, 64));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        c1 = am > 0.f ? 448.0f / am : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) qf[e] *= c1;
+        aq0 = split3_e4m3(qf, r);
+        aq1 = split3_e4m3(qf + 8, r);
+    } else {
     if (wave == 0) {
         float qf[16];
         const float* qp = p.q + (size_t)b * D + h * 64 + g * 16;
-        if (FUSED) {
-            const float2 pt0 = *(const float2*)(p.pstats + ((size_t)min(lane, p.n_pstats - 1) * 16 + b) * 2);
-            const float2 pt1 = *(const float2*)(p.pstats + ((size_t)min(lane + 64, p.n_pstats - 1) * 16 + b) * 2);
-            const size_t col = (size_t)h * 64 + lane;
-            const float qa1 = p.qa[(size_t)b * D + col], qb1 = p.qb[(size_t)b * D + col], qw1 = p.qw[col], qc1 = p.qbias[col];
-            const float inv_d = 1.0f / (float)D;
-            const float ps1 = (lane < p.n_pstats ? pt0.x : 0.f) + (lane + 64 < p.n_pstats ? pt1.x : 0.f);
-            const float ps2 = (lane < p.n_pstats ? pt0.y : 0.f) + (lane + 64 < p.n_pstats ? pt1.y : 0.f);
-            const float mean = wave_sum(ps1) * inv_d;
-            const float var = fmaxf(wave_sum(ps2) * inv_d - mean * mean, 0.f);
-            const float rstd = 1.0f / sqrtf(var + 1e-5f);
-            s_qf[lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            qp = s_qf + g * 16;
-        }
         const float4 q0 = *(const float4*)qp, q1 = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
         qf[0] = q0.x; qf[1] = q0.y; qf[2] = q0.z; qf[3] = q0.w; qf[4] = q1.x; qf[5] = q1.y; qf[6] = q1.z; qf[7] = q1.w;
         qf[8] = q2.x; qf[9] = q2.y; qf[10] = q2.z; qf[11] = q2.w; qf[12] = q3.x; qf[13] = q3.y; qf[14] = q3.z; qf[15] = q3.w;
@@ -1749,8 +1773,10 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
         if (lane == 0) s_c1 = cq;
     }
     __syncthreads();
-    const long aq0 = s_aq[lane], aq1 = s_aq[64 + lane];
-    const float s_unscale = ks / s_c1;
+    aq0 = s_aq[lane]; aq1 = s_aq[64 + lane];
+    c1 = s_c1;
+    }
+    const float s_unscale = ks / c1;
     float sc[NSB][2], mx[NSB];
 #pragma unroll
     for (int s = 0; s < NSB; ++s) {
