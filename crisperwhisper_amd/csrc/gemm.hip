@@ -1172,6 +1172,13 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
                                                          const float* __restrict__ ln_b, EpiParams ep,
                                                          CombineParams cb, int m_base, int wpk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    if (gridDim.z > 1) {   // row groups inside one launch (the combining out-projection): block z takes rows z * rpb .. of the launch's Mb
+        const int rpb = (Mb + (int)gridDim.z - 1) / (int)gridDim.z;
+        const int mb0 = (int)blockIdx.z * rpb;
+        m_base += mb0;
+        Mb = min(rpb, Mb - mb0);
+        if (Mb <= 0) return;
+    }
     x += (size_t)m_base * K;                                  // this launch handles batch rows m_base .. m_base+Mb-1
     const int xs_stride = Kb + 8;
     bf16_t* xs = (bf16_t*)smem2;                              // [16][Kb+8]
@@ -1747,6 +1754,8 @@ void cw_gemm_set_gm(int gm) {   // experiments builds: tile order of the 8-phase
 }
 static int g_gemv_loop = -1;  // persistent column loop for very wide LayerNorm GEMVs (logits); -1: from the environment (CW_NO_GEMV_LOOP)
 void cw_gemv_set_loop(int on) { g_gemv_loop = on; }
+static int g_comb_rowgroups = -1;  // combining out-projection of <= 8 rows as (N / 32, ksplit, row groups); -1: from the environment (CW_COMB_NO_ROWGROUPS)
+void cw_gemv_set_comb_rowgroups(int on) { g_comb_rowgroups = on; }
 static int g_use_w128 = -1;  // four waves of 128 x 128 (round 4, measured slower: -DCW_EXPERIMENTS builds only); -1: from the environment (CW_GEMM_W128=1)
 void cw_gemm_set_w128(int on) { g_use_w128 = on; }
 
@@ -1956,6 +1965,22 @@ static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, co
     }
     const int Kb = K / ksplit;
     const size_t lds = (size_t)16 * (Kb + 8) * 2 + 4 * 4 * 64 * 4;
+    // combining GEMV of <= 8 rows (cross-attention out-projection): a block's bytes are the ATT_NS partial planes of its rows and K
+    // slice -- 8 rows x 640 x 4 B x 6 = 123 KB against 20 KB of weights, on 160 of 256 CUs, and a CU takes in ~60 B / ns
+    // (tools/gemv_stage_phase_probe.py: requests accepted at 1.9 us, reduce done at 3.1).  Same K slices (so every partial sum and
+    // every rounding is the one of the (N / 16, ksplit) grid: bit-identical), but two column tiles per block and the rows in up to
+    // three groups: grid (40, 2, 3) = 240 blocks of 46 KB of partials + 41 KB of weights.
+    if (EPI == EPI_RESID_F32 && cb.part_ml && ksplit > 1 && RPW == 2 && Mb > 1 && N % 32 == 0 && Kb > 256 && Kb <= 768 &&
+        (g_comb_rowgroups < 0 ? !cw_sw::cw_switches().comb_no_rowgroups : g_comb_rowgroups != 0)) {
+        int G = 256 / ((N / 32) * ksplit);
+        G = G < 1 ? 1 : (G > Mb ? Mb : G);
+        while (G > 1 && (Mb + G - 1) / G > 4) ++G;             // one row per wave (RPW = 1): at most four rows per group
+        if ((Mb + G - 1) / G <= 4) {
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, 1, true, true, 2, 3, 2>), dim3(N / 32, ksplit, G), dim3(256), lds + 4 * 4 * 64 * 4, st,
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
+            return;
+        }
+    }
     dim3 grid((N + 15) / 16, ksplit);
     if (Kb <= 256) launch_gemv2_shape<EPI, RPW, 1, 1>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base, wpk);
     else if (Kb <= 768) launch_gemv2_shape<EPI, RPW, 2, 3>(grid, lds, ksplit, x, Mb, K, Kb, W, N, ln_g, ln_b, ep, st, cb, m_base, wpk);

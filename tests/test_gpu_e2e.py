@@ -1218,6 +1218,44 @@ def test_logits_projection_persistent_column_loop_is_bit_identical(dt, rows):
         eng.close()
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("rows", [2, 5, 8])
+def test_combining_out_projection_in_row_groups_is_bit_identical(dt, rows):
+    """The cross-attention out-projection of <= 8 rows (gemm.hip: gemv2_bf16_kernel<.., COMBINE>: combines the six key-split
+    partials, TF modeling_whisper.py:286-300 + 496-503) as grid (N / 32, K slices, row groups) -- 240 blocks of 87 KB instead
+    of 160 of 145 KB -- against the (N / 16, K slices) launch: same K slices, same summation orders, so every logit of a
+    teacher-forced run over several positions is bit-identical (graph replay included: decode() without capture follows)."""
+    g, v = syn.large_v3_geometry()
+    g.enc_layers, g.dec_layers = 1, 3
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(3) for h in (0, 3, 7, 19, 11)][:15]
+    W = syn.random_weights(g, seed=23)
+    T = 12
+    clips = [syn.synth_audio(900 + i, 480000 - 9000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
+    rng = np.random.default_rng(7)
+    ids = np.concatenate([[v.sot, v.lang_id("en"), v.transcribe], [v.timestamp_begin], rng.integers(300, 50000, T - 4)])
+    forced = np.full((rows, T), -1, np.int32); forced[:, 3:] = ids[3:]
+    prompt = np.tile(ids[None, :3], (rows, 1))
+    eng = Engine(spec, dtype=dt, max_batch=rows)
+    try:
+        eng.load_state_dict(W)
+        eng.mel(clips)
+        eng.encode(list(range(rows)), [0] * rows, [3000] * rows)
+        res = {}
+        for on in (1, 0):
+            assert eng.lib.cw_test_set_option(b"comb_rowgroups", on) == 0
+            cap = eng.capture_logits(rows, T)
+            eng.decode(prompt, max_length=T, forced=forced)
+            res[on] = (cap[:T - 3].copy(), eng.alignment(rows, T - 1).copy())
+            eng.stop_capture()
+        assert np.isfinite(res[1][0]).all() and np.abs(res[1][0]).max() > 0
+        assert np.array_equal(res[1][0], res[0][0]), int((res[1][0] != res[0][0]).sum())
+        assert np.array_equal(res[1][1], res[0][1])
+    finally:
+        eng.lib.cw_test_set_option(b"comb_rowgroups", -1)
+        eng.close()
+
+
 @pytest.mark.parametrize("feature,rows,dt", [("qkv_self", 8, "bf16"), ("qkv_self", 8, "f16"), ("qkv_self", 5, "bf16"), ("qkv_self", 1, "bf16"),
                                              ("declayer", 8, "bf16"), ("declayer", 8, "f16"), ("declayer", 3, "bf16"),
                                              ("mlp_chain", 8, "bf16"), ("mlp_chain", 8, "f16"), ("mlp_chain", 5, "bf16"), ("mlp_chain", 1, "bf16")])
