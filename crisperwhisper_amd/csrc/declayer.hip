@@ -452,7 +452,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
         const dl_u64_t* g1 = p.gps + ((size_t)min(lane + 64, TD - 1) * 16 + qb_row) * 2;
         dl_u64_t va = 0, vb = 0, v00 = 0, v01 = 0, v10 = 0, v11 = 0;
         bool ready = !q_mine;
-        int npoll = 0;
+        int npoll = 0; (void)npoll;
 #pragma unroll 1
         for (int spins = 0; !ready; ++spins) {
             if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }

@@ -1623,35 +1623,50 @@ __global__ __launch_bounds__(256) void gemv_prep_kernel(const float* __restrict_
 // PREA (round 3): the activation fragments of all of the wave's K steps are requested up front as well (NSLOT x 4 x MT
 // fragments = up to 192 VGPRs; one wave per SIMD, the register file is there).  Fetched on demand inside the MFMA loop they
 // arrive a few at a time at L2 latency, and a 16-column block takes in three times as many activation bytes as weight bytes.
-template <int EPI, int MT, bool ATOMIC, int NSLOT, bool PREA = false>
+// NT / row groups (round 5): a block takes NT 16-column tiles and the MT row tiles blockIdx.z * MT .. of the activation rows.  At
+// 64 rows a 16-column block reads 160 KB of (replicated) activation fragments for 40 KB of weights; two column tiles x two of the
+// four row tiles is 80 + 80 KB for the same MFMAs.  Rows and column tiles are independent in the MFMA: every output element is
+// the sum it was, in the order it was -- bit-identical to the one-tile block.
+template <int EPI, int MT, bool ATOMIC, int NSLOT, bool PREA = false, int NT = 1>
 __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__ xf, int Mb, int K, int Kb,
                                                       const bf16_t* __restrict__ W, int N, EpiParams ep, int wpk) {
-    __shared__ float red[4 * MT * 4 * 64];
+    __shared__ float red[4 * NT * MT * 4 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16 * NT;
+    const int t0 = blockIdx.z * MT;                           // first row tile of this block
     const int kbase = blockIdx.y * Kb;
     const int steps = Kb >> 7, KS = K >> 5;
-    const int n = n0 + l15;
-    const int nc = n < N ? n : N - 1;
-    const float bias_v = ep.bias ? ep.bias[nc] : 0.f;
-
-    u32x4_t wq[NSLOT][4];
-    const bf16_t* wrow = W + (size_t)nc * K + kbase + g * 8;
+    int n[NT], nc[NT];
+    float bias_v[NT];
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
-        int step = wave + 4 * s;
-        step = step < steps ? step : steps - 1;               // clamped (unconditional) load, zeroed below
-        const u32x4_t* wp = wpk ? (const u32x4_t*)(W + ((((size_t)(nc >> 4) * (K >> 5)) + (kbase >> 5) + step * 4) * 64 + g * 16 + (nc & 15)) * 8)
-                                : (const u32x4_t*)(wrow + step * 128);
-        const int sj = wpk ? 64 : 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wq[s][j] = wp[j * sj];
+    for (int c = 0; c < NT; ++c) {
+        n[c] = n0 + c * 16 + l15;
+        nc[c] = n[c] < N ? n[c] : N - 1;
+        bias_v[c] = ep.bias ? ep.bias[nc[c]] : 0.f;
     }
-    f32x4_t acc[MT];
+
+    u32x4_t wq[NT][NSLOT][4];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NT; ++c) {
+        const bf16_t* wrow = W + (size_t)nc[c] * K + kbase + g * 8;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            int step = wave + 4 * s;
+            step = step < steps ? step : steps - 1;               // clamped (unconditional) load, zeroed below
+            const u32x4_t* wp = wpk ? (const u32x4_t*)(W + ((((size_t)(nc[c] >> 4) * (K >> 5)) + (kbase >> 5) + step * 4) * 64 + g * 16 + (nc[c] & 15)) * 8)
+                                    : (const u32x4_t*)(wrow + step * 128);
+            const int sj = wpk ? 64 : 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wq[c][s][j] = wp[j * sj];
+        }
+    }
+    f32x4_t acc[NT][MT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[c][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const u32x4_t* xq = (const u32x4_t*)xf;
     u32x4_t aq[PREA ? NSLOT : 1][4][MT];
     if (PREA) {
@@ -1662,7 +1677,7 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int t = 0; t < MT; ++t) aq[s][j][t] = xq[((size_t)t * KS + (kbase >> 5) + step * 4 + j) * 64 + lane];
+                for (int t = 0; t < MT; ++t) aq[s][j][t] = xq[((size_t)(t0 + t) * KS + (kbase >> 5) + step * 4 + j) * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);                     // every request is out before the first MFMA (hipcc otherwise sinks the loads to their uses)
     }
@@ -1673,35 +1688,45 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
         const int step = live ? step_raw : steps - 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            u32x4_t w = wq[s][j];
-            if (!live) w = (u32x4_t){0u, 0u, 0u, 0u};          // a dead slot contributes exactly zero
+            u32x4_t w[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                w[c] = wq[c][s][j];
+                if (!live) w[c] = (u32x4_t){0u, 0u, 0u, 0u};   // a dead slot contributes exactly zero
+            }
             const int ks = (kbase >> 5) + step * 4 + j;
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                const u32x4_t a = PREA ? aq[PREA ? s : 0][j][t] : xq[((size_t)t * KS + ks) * 64 + lane];
-                acc[t] = mfma16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, w), acc[t]);
+                const u32x4_t a = PREA ? aq[PREA ? s : 0][j][t] : xq[((size_t)(t0 + t) * KS + ks) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+                    acc[c][t] = mfma16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, w[c]), acc[c][t]);
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int c = 0; c < NT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * MT + t) * 4 + r) * 64 + lane] = acc[t][r];
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wave * NT + c) * MT + t) * 4 + r) * 64 + lane] = acc[c][t][r];
     __syncthreads();
     const int r = tid >> 6;
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[((w * MT + t) * 4 + r) * 64 + lane];
-        const int m = t * 16 + g * 4 + r;
-        if (m < Mb && n < N) {
+        for (int w = 0; w < 4; ++w) v += red[(((w * NT + c) * MT + t) * 4 + r) * 64 + lane];
+        const int m = (t0 + t) * 16 + g * 4 + r;
+        if (m < Mb && n[c] < N) {
             if (ATOMIC) {
-                atomicAdd(ep.outf + (size_t)m * ep.ldo + n, resid_grid(v + (blockIdx.y == 0 ? bias_v : 0.f)));
+                atomicAdd(ep.outf + (size_t)m * ep.ldo + n[c], resid_grid(v + (blockIdx.y == 0 ? bias_v[c] : 0.f)));
             } else {
                 EpiParams e2 = ep;
                 e2.bias = nullptr;
-                epi_store1<bf16_t, EPI>(e2, m, n, EPI == EPI_RESID_F32 ? resid_grid(v + bias_v) : v + bias_v);
+                epi_store1<bf16_t, EPI>(e2, m, n[c], EPI == EPI_RESID_F32 ? resid_grid(v + bias_v[c]) : v + bias_v[c]);
             }
         }
     }
@@ -1997,6 +2022,18 @@ static bool gemv2_ok(int epi, int Mb, int K, const float* ln_g, const EpiParams&
     return (K % ks == 0) && ((K / ks) % 128 == 0);
 }
 
+// which block shape the 33..64-row GEMV of an [N x K] projection takes (0 / 1 / 2 as below).  Measured at 64 and 40 rows through the
+// step's own launches (tools/mt_variant_probe.py, profiles/r05_b64_mt_variants.txt): two row groups x two column tiles wins
+// wherever that still leaves >= 160 blocks (q/k/v 10.6 -> 9.7 us, out-projection 6.3 -> 3.9, fc1 14.1 -> 11.1, fc2 9.9 -> 7.7);
+// the 80-tile cross-attention query projection takes the row groups alone (9.9 -> 7.3)
+static int cw_gemv_mt_pick(int N, int K, int ksplit) {
+    (void)K;
+    if (N % 32 == 0 && (N / 32) * ksplit * 2 >= 160) return 2;
+    return 1;
+}
+static int g_mt_variant = -2;   // -2: from the environment (CW_MT_VARIANT); -1: heuristic; 0: one tile per block; 1: two row groups; 2: two row groups x two column tiles
+void cw_gemv_set_mt_variant(int v) { g_mt_variant = v; }
+
 template <int EPI, int MT>
 static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N, const EpiParams& ep, bool allow_split,
                            hipStream_t st, int wpk) {
@@ -2010,6 +2047,30 @@ static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N
     dim3 grid((N + 15) / 16, ksplit);
     const bool atomic = EPI == EPI_RESID_F32 && ksplit > 1;
     const bool prea = !cw_sw::cw_switches().mt_no_prea;   // A/B: activation fragments fetched on demand
+    const int steps = Kb / 128;
+    // 33..64 rows: row groups / column-tile pairs (see the kernel).  Chosen per shape from the launch table of
+    // profiles/r05_b64_mt_variants.txt; CW_MT_VARIANT=0|1|2 forces one for A/B.
+    if (g_mt_variant == -2) g_mt_variant = cw_sw::cw_switches().mt_variant;
+    int variant = g_mt_variant;
+    if (variant < 0) variant = cw_gemv_mt_pick(N, K, ksplit);
+    if (MT >= 3 && prea && variant >= 1 && (variant == 1 || N % 32 == 0)) {
+        constexpr int MH = 2;                                  // row tiles per group: 33..64 rows in two groups
+        const int nt = variant == 2 ? 2 : 1;
+        dim3 g2((unsigned)((N + 16 * nt - 1) / (16 * nt)), (unsigned)ksplit, 2);
+#define CW_MT_LAUNCH2(NS, NTT)                                                                                        \
+        do {                                                                                                          \
+            if (atomic)                                                                                               \
+                hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, MH, true, NS, true, NTT>), g2, dim3(256), 0, st, xf, Mb, K, Kb, \
+                                   (const bf16_t*)W, N, ep, wpk);                                                     \
+            else                                                                                                      \
+                hipLaunchKernelGGL((gemv_mt_kernel<EPI, MH, false, NS, true, NTT>), g2, dim3(256), 0, st, xf, Mb, K, Kb, \
+                                   (const bf16_t*)W, N, ep, wpk);                                                     \
+        } while (0)
+        if (nt == 2) { if (steps <= 4) CW_MT_LAUNCH2(1, 2); else if (steps <= 8) CW_MT_LAUNCH2(2, 2); else CW_MT_LAUNCH2(3, 2); }
+        else { if (steps <= 4) CW_MT_LAUNCH2(1, 1); else if (steps <= 8) CW_MT_LAUNCH2(2, 1); else CW_MT_LAUNCH2(3, 1); }
+#undef CW_MT_LAUNCH2
+        return;
+    }
 #define CW_MT_LAUNCH(NS)                                                                                              \
     do {                                                                                                              \
         if (atomic && prea)                                                                                           \
@@ -2025,7 +2086,6 @@ static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N
             hipLaunchKernelGGL((gemv_mt_kernel<EPI, MT, false, NS, false>), grid, dim3(256), 0, st, xf, Mb, K, Kb,     \
                                (const bf16_t*)W, N, ep, wpk);                                                         \
     } while (0)
-    const int steps = Kb / 128;
     if (steps <= 4) CW_MT_LAUNCH(1);
     else if (steps <= 8) CW_MT_LAUNCH(2);
     else CW_MT_LAUNCH(3);

@@ -318,6 +318,7 @@ struct MelTables {
     void cw_gemm_set_gm(int gm); \
     void cw_gemm_set_w128(int on); \
     void cw_gemv_set_comb_rowgroups(int on); \
+    void cw_gemv_set_mt_variant(int v); \
     void cw_gemv_set_loop(int on); \
     int cw_launch_gemm_w128(int epi, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const EpiParams& ep, int tm2, int tn2, hipStream_t st); \
     void cw_cross_set_valu(int on); \

@@ -54,6 +54,8 @@ Switches read_switches() {
     s.mt_no_prea = flag("CW_MT_NO_PREA");
     s.gemv_loop_cap = num("CW_GEMV_LOOP_CAP", 512);
     s.fc2_ksplit = num("CW_FC2_KSPLIT", 0);
+    s.mt_variant = num("CW_MT_VARIANT", -1);
+    if (s.mt_variant < -1 || s.mt_variant > 2) s.mt_variant = -1;
     s.beam_topk_1block = flag("CW_BEAM_TOPK_1BLOCK");
     s.mel_valu = flag("CW_MEL_VALU");
     s.mel_dbg = num("CW_MEL_DBG", 0);

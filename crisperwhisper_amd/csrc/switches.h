@@ -17,7 +17,7 @@ struct Switches {
     int cross_lds_pad, cross8_nsb, dl_depth, dl_kvwait, mlp_chain_delay, qkv_self_dbg;
     // GEMM / GEMV launchers
     bool no_glds, no_gemm256, no_gemm_pp, no_gemm_8ph, gemm_w128, no_gemv_loop, comb_nt2, comb_no_rowgroups, mt_no_prea;
-    int gemv_loop_cap, fc2_ksplit;
+    int gemv_loop_cap, fc2_ksplit, mt_variant;
     // sampling, mel
     bool beam_topk_1block, mel_valu;
     int mel_dbg;

@@ -1218,6 +1218,43 @@ def test_logits_projection_persistent_column_loop_is_bit_identical(dt, rows):
         eng.close()
 
 
+@pytest.mark.parametrize("rows,dt", [(64, "bf16"), (40, "bf16"), (33, "f16")])
+def test_row_groups_and_tile_pairs_of_the_33_to_64_row_gemvs_are_bit_identical(rows, dt):
+    """gemm.hip: gemv_mt_kernel<.., NT> with row groups -- the decode projections of 33..64 rows as blocks of two column tiles x
+    two of the (up to four) row tiles (default where that leaves >= 160 blocks), as two row groups of one column tile, and as
+    the round-3 block (16 columns x every row tile): rows and column tiles are independent in the MFMA, so every logit of a
+    teacher-forced run is bit-identical across the three (TF modeling_whisper.py:448-505, the decoder layer's projections)."""
+    g, v = syn.large_v3_geometry()
+    g.enc_layers, g.dec_layers = 1, 2
+    spec = syn.model_spec(g, v, n_align=10)
+    spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19, 11)]
+    W = syn.random_weights(g, seed=29)
+    T = 8
+    clips = [syn.synth_audio(1200 + i, 480000 - 3000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
+    rng = np.random.default_rng(11)
+    ids = np.concatenate([[v.sot, v.lang_id("en"), v.transcribe], [v.timestamp_begin], rng.integers(300, 50000, T - 4)])
+    forced = np.full((rows, T), -1, np.int32); forced[:, 3:] = ids[3:]
+    prompt = np.tile(ids[None, :3], (rows, 1))
+    eng = Engine(spec, dtype=dt, max_batch=rows)
+    try:
+        eng.load_state_dict(W)
+        eng.mel(clips)
+        eng.encode(list(range(rows)), [0] * rows, [3000] * rows)
+        res = {}
+        for var in (-1, 0, 1, 2):
+            assert eng.lib.cw_test_set_option(b"mt_variant", var) == 0
+            cap = eng.capture_logits(rows, T)
+            eng.decode(prompt, max_length=T, forced=forced)
+            res[var] = cap[:T - 3].copy()
+            eng.stop_capture()
+        assert np.isfinite(res[0]).all() and np.abs(res[0]).max() > 0
+        for var in (-1, 1, 2):
+            assert np.array_equal(res[var], res[0]), (var, int((res[var] != res[0]).sum()))
+    finally:
+        eng.lib.cw_test_set_option(b"mt_variant", -1)
+        eng.close()
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("rows", [2, 5, 8])
 def test_combining_out_projection_in_row_groups_is_bit_identical(dt, rows):
