@@ -517,7 +517,7 @@ def main():
         r = max(singles, key=lambda r_: r_["avg_ms"] * r_["per_step"])
         PMC_NAMES = {"cross-attention": "attn_cross_mfma8" if a.cross_kv == "fp8" else "attn_cross_split_kernel", "qkv_self_kernel": "qkv_self_kernel",
                      "gemv_stack_kernel": "gemv_stack_kernel", "fc1": "gemv2_bf16_kernelILi1E", "fc2": "gemv2_bf16_kernelILi2ELi2ELb1ELb0",
-                     "out-projection (combines": "gemv2_bf16_kernelILi2ELi2ELb1ELb1", "logits": "gemv_loop_kernel"}
+                     "out-projection (combines": "gemv2_bf16_kernelILi2ELi1ELb1ELb1", "logits": "gemv_loop_kernel"}
 
         def pmc_of(kernel_label):
             for key, sub in PMC_NAMES.items():
