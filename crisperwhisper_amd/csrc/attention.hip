@@ -1343,6 +1343,8 @@ static void launch_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
 
 static int g_cross_valu = 0;
 void cw_cross_set_valu(int on) { g_cross_valu = on; }
+static int g_cross_per_row = 0;   // test option "cross_per_row" (same meaning as CW_CROSS_PER_ROW=1, switchable inside a process)
+void cw_cross_set_per_row(int on) { g_cross_per_row = on; }
 int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > 4 * (CROSS_THREADS / 8) || CROSS_THREADS != 512) return CW_ERR_INVALID;
     // every key split must own at least one key (the kernels clamp their loads to the split's last key)
@@ -1378,7 +1380,7 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
         hipLaunchKernelGGL((attn_cross_split_kernel<bf16_t, 1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), (size_t)lds_pad, st, p);
         return CW_OK;
     }
-    const bool per_row = cw_sw::cw_switches().cross_per_row;   // A/B: one block per row even under beam search
+    const bool per_row = cw_sw::cw_switches().cross_per_row || g_cross_per_row;   // A/B: one block per row even under beam search
     const int valu = cw_sw::cw_switches().cross_valu; // A/B: instruction-bound 8-lane-group kernel for 2..6 rows per K/V
     const bool no_tr = cw_sw::cw_switches().cross_no_tr; // A/B: 2-byte LDS reads instead of the transposing read
     if (bf16 && p.kv_div > 1 && p.kv_div <= 16 && p.B % p.kv_div == 0 && !per_row && !(valu || g_cross_valu) &&
@@ -1859,10 +1861,182 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same kernel for nq = 2..8 rows that share one e4m3 K/V (the hypotheses of one audio item under beam search).
+// grid (H, B / nq, ATT_NS): the block's 32 KB of cache bytes are read once for all of its rows instead of once per row out of L2.
+// A one-row block uses rows 0..2 of the 16-row A operand (the three e4m3 terms of its query) and lanes (j, 0) of the result;
+// here row 4 qq + term of A tile T carries term `term` of query 4 T + qq (row 4 qq + 3 is zero), so that lane (j, g) of the C
+// fragment -- rows 4 g .. 4 g + 3 -- holds the three row sums of query 4 T + g against key j: every query is a 16-lane row of
+// the wave, its maximum and its sum of exponentials are the row-local halves of wave_max / wave_sum (same DPP steps, same
+// order), and nothing moves across lanes.  NT = tiles of four queries (5 hypotheses: two).  Per row the arithmetic is the
+// one-row kernel's, operation for operation -- the MFMA rows are independent, scales, exponentials, the three-term recombination
+// and the w = 0..7 partial sums are the same expressions in the same order -- so a row's partial plane, (m, l) pair and
+// alignment row are bit-identical to a one-row launch (test_e4m3_cache_beam_rows_equal_one_row_blocks).
+// ---------------------------------------------------------------------------------------------------
+__device__ inline float row16_max(float v) {                  // lane 15 of every 16-lane row: the row's maximum (first four steps of wave_max)
+    v = fmaxf(v, dpp_mov<0x111, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_mov<0x112, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_mov<0x114, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_mov<0x118, 0xf>(-INFINITY, v));
+    return v;
+}
+__device__ inline float row16_sum(float v) {                  // lane 15 of every 16-lane row: the row's sum (first four steps of wave_sum)
+    v += dpp_mov<0x111, 0xf>(0.f, v);
+    v += dpp_mov<0x112, 0xf>(0.f, v);
+    v += dpp_mov<0x114, 0xf>(0.f, v);
+    v += dpp_mov<0x118, 0xf>(0.f, v);
+    return v;
+}
+template <int NT>
+__global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_rows_kernel(CrossSplitParams p, int nq) {
+    constexpr int NQM = 4 * NT;                                   // query slots of the block
+    __shared__ float s_max[8 * NQM];
+    __shared__ __attribute__((aligned(16))) float red[8 * NQM * 64];
+    __shared__ float red_l[8 * NQM];
+    __shared__ __attribute__((aligned(16))) float s_p[8 * NQM * 32];
+    __shared__ long s_aq[NT * 2 * 64];
+    __shared__ float s_c1[NQM];
+    const int h = blockIdx.x, b0 = blockIdx.y * nq, sp = blockIdx.z;
+    const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = wave * 32;
+    const int D = p.H * 64;
+    const size_t bh = (size_t)(b0 / p.kv_div) * p.H + h;
+    const int k_lo = sp * per, nk = min(p.n_keys, k_lo + per) - k_lo;
+    // every load of the block first
+    uint4 kf[2], vf[2];
+    {
+        const unsigned char* Kh = (const unsigned char*)p.K + (bh * p.n_keys + k_lo) * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) kf[t] = *(const uint4*)(Kh + (size_t)min(kb + t * 16 + r, nk - 1) * 64 + g * 16);
+        const unsigned char* Vf = (const unsigned char*)p.V + (bh * ATT_NS + sp) * X8_SPLIT_BYTES + (size_t)wave * 2048 + lane * 16;
+        vf[0] = *(const uint4*)Vf; vf[1] = *(const uint4*)(Vf + 1024);
+    }
+    const float ks = p.kv_scale[bh * 2], vs = p.kv_scale[bh * 2 + 1];
+    // wave T scales and splits the four queries of tile T (lane (r, g): query 4 T + r / 4, term r % 4, dims 16 g .. + 15); the
+    // others pick the fragments up from LDS behind a barrier that their own K / V loads are in flight across
+    if (wave < NT) {
+        const int qi = 4 * wave + (r >> 2), term = r & 3;
+        const float z = qi < nq ? 1.f : 0.f;                      // slots past the last row: zero queries, never stored
+        float qf[16];
+        const float* qp = p.q + (size_t)(b0 + min(qi, nq - 1)) * D + h * 64 + g * 16;
+        const float4 q0 = *(const float4*)qp, q1 = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
+        qf[0] = q0.x; qf[1] = q0.y; qf[2] = q0.z; qf[3] = q0.w; qf[4] = q1.x; qf[5] = q1.y; qf[6] = q1.z; qf[7] = q1.w;
+        qf[8] = q2.x; qf[9] = q2.y; qf[10] = q2.z; qf[11] = q2.w; qf[12] = q3.x; qf[13] = q3.y; qf[14] = q3.z; qf[15] = q3.w;
+        float am = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { qf[e] *= z; am = fmaxf(am, fabsf(qf[e])); }
+        am = fmaxf(am, __shfl_xor(am, 16, 64));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        const float cq = am > 0.f ? 448.0f / am : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) qf[e] *= cq;
+        s_aq[(wave * 2) * 64 + lane] = split3_e4m3(qf, term);     // term 3: zeros
+        s_aq[(wave * 2 + 1) * 64 + lane] = split3_e4m3(qf + 8, term);
+        if (g == 0 && term == 0) s_c1[qi] = cq;
+    }
+    __syncthreads();
+    const bool kval[2] = {kb + r < nk, kb + 16 + r < nk};
+    float sc[NT][2], mx[NT];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        const long aq0 = s_aq[(T * 2) * 64 + lane], aq1 = s_aq[(T * 2 + 1) * 64 + lane];
+        const float s_unscale = ks / s_c1[4 * T + g];
+        mx[T] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq0, (long)(((unsigned long)kf[t].y << 32) | kf[t].x), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq1, (long)(((unsigned long)kf[t].w << 32) | kf[t].z), c, 0, 0, 0);
+            const float v = ((c[2] * 0.0625f + c[1]) * 0.0625f + c[0]) * s_unscale;      // small terms first
+            sc[T][t] = kval[t] ? v : -INFINITY;
+            mx[T] = fmaxf(mx[T], sc[T][t]);
+        }
+        mx[T] = row16_max(mx[T]);
+        if (r == 15) s_max[wave * NQM + 4 * T + g] = mx[T];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        float m = s_max[4 * T + g];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, s_max[w * NQM + 4 * T + g]);
+        mx[T] = m;
+    }
+
+    const int slot = p.align_out ? p.align_slot[h] : -1;
+    float* spw = s_p + wave * (NQM * 32);
+    long ap[NT];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        const int qi = 4 * T + g;
+        float pk[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) pk[t] = kval[t] ? expf(sc[T][t] - mx[T]) : 0.f;
+        if (slot >= 0 && qi < nq) {                               // un-normalised; align_normalize_kernel finishes the row
+            const size_t rowi = ((size_t)(b0 + qi) * p.n_align + slot) * p.align_rows + p.pos[b0 + qi];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (kval[t]) p.align_out[rowi * p.n_keys + k_lo + kb + t * 16 + r] = pk[t];
+        }
+        const float lsum = row16_sum(pk[0] + pk[1]);
+        if (r == 15) red_l[wave * NQM + qi] = lsum;
+        // score fragment (query g, key r) -> A fragment (lane (r, g): query r / 4, term r % 4, keys 8 g .. + 7): a wave-private LDS row per query
+        spw[qi * 32 + r] = pk[0] * 256.f; spw[qi * 32 + 16 + r] = pk[1] * 256.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        const float* pp = spw + (4 * T + (r >> 2)) * 32 + g * 8;
+        const float4 p0 = *(const float4*)pp, p1 = *(const float4*)(pp + 4);
+        const float pf[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        ap[T] = split3_e4m3(pf, r & 3);
+    }
+    const unsigned vw[8] = {vf[0].x, vf[0].y, vf[0].z, vf[0].w, vf[1].x, vf[1].y, vf[1].z, vf[1].w};
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ap[T], (long)(((unsigned long)vw[2 * dt + 1] << 32) | vw[2 * dt]), c, 0, 0, 0);
+            red[(wave * NQM + 4 * T + g) * 64 + dt * 16 + r] = (c[2] * 0.0625f + c[1]) * 0.0625f + c[0];
+        }
+    __syncthreads();
+    for (int i = tid; i < nq * 64; i += CROSS_THREADS) {
+        const int q = i >> 6, c = i & 63;
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) a += red[(w * NQM + q) * 64 + c];
+        p.part_o[((size_t)sp * p.B + b0 + q) * D + h * 64 + c] = a * (vs * (1.0f / 256.0f));
+    }
+    if (tid < nq) {
+        const int q = tid;
+        float l = 0.f, m = s_max[q];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { l += red_l[w * NQM + q]; m = fmaxf(m, s_max[w * NQM + q]); }
+        float* ml = p.part_ml + (((size_t)(b0 + q) * p.H + h) * ATT_NS + sp) * 2;
+        ml[0] = m; ml[1] = l;
+        if (slot >= 0) {
+            const size_t rowi = ((size_t)(b0 + q) * p.n_align + slot) * p.align_rows + p.pos[b0 + q];
+            p.align_ml[(rowi * ATT_NS + sp) * 2] = m; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l;
+        }
+    }
+}
+
 int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > C8U * CROSS8_GROUPS || !p.kv_scale) return CW_ERR_INVALID;
     if (p.n_keys < 1 || (ATT_NS - 1) * ((p.n_keys + ATT_NS - 1) / ATT_NS) >= p.n_keys) return CW_ERR_INVALID;   // a split without a key
     if (cross8_mfma(p.n_keys)) {
+        // rows that share one cache (beam search): one block per (item, head, split) takes all of them (A/B: CW_CROSS_PER_ROW=1)
+        if (!p.qa && p.kv_div > 1 && p.kv_div <= 8 && p.B % p.kv_div == 0 && !cw_sw::cw_switches().cross_per_row && !g_cross_per_row) {
+            const dim3 grid(p.H, p.B / p.kv_div, ATT_NS);
+            if (p.kv_div <= 4) hipLaunchKernelGGL((attn_cross_mfma8_rows_kernel<1>), grid, dim3(CROSS_THREADS), 0, st, p, p.kv_div);
+            else hipLaunchKernelGGL((attn_cross_mfma8_rows_kernel<2>), grid, dim3(CROSS_THREADS), 0, st, p, p.kv_div);
+            return CW_OK;
+        }
         // CW_CROSS8_NSB=2 (A/B): two splits per block -- twice the bytes in flight per CU, measured equal (the memory system is the bound)
         const int f = cw_sw::cw_switches().cross8_nsb;
         if (p.qa) {   // fused stage in front: the kernel finishes the query

@@ -866,6 +866,54 @@ def test_bench_model_beam_search_16bit_engines(dt):
         eng.close()
 
 
+def test_bench_model_beam_search_over_the_e4m3_cache_rows_kernel_equals_one_row_blocks():
+    """5-beam search of the bench model with the opt-in e4m3 cross-attention cache: the hypotheses of an item go through
+    attn_cross_mfma8_rows_kernel (one block per (item, head, key split) for all five) -- against the same engine with one block per
+    hypothesis row (test option cross_per_row, the round-4 dispatch).  The partial planes are bit-identical per row, so sequences,
+    beam scores' order and token timestamps must be EQUAL, not close.  The reference texts of the bf16-cache golden are counted
+    but not asserted (the e4m3 cache is accuracy-gated, greedy 8 / 8 + 64 / 64; no beam golden exists for it)."""
+    import os
+    from crisperwhisper_amd import _native
+    path = os.path.join(os.path.dirname(__file__), "golden", "e2e_bench_beam_golden.json")
+    if not os.path.exists(path):
+        pytest.skip("bench-model beam golden not generated")
+    if os.environ.get("CW_CROSS8_VALU") or os.environ.get("CW_CROSS_PER_ROW"):
+        pytest.skip("the rows kernel is the matrix-core path of the default process")
+    gold = Hh.gold_json("e2e_bench_beam_golden.json")
+    g, v = syn.large_v3_geometry()
+    spec = syn.model_spec(g, v, n_align=15)
+    vocab = collate.Vocabulary.from_synthetic(v)
+    gk = gold["generate_kwargs"]
+    B = len(gold["clips"])
+    lib = _native.load()
+    eng = Engine(spec, dtype="bf16", max_batch=B * gk["num_beams"], cross_kv_dtype="fp8")
+    outs = {}
+    try:
+        for n, shape in syn.weight_shapes(g).items():
+            eng.load_tensor(n, syn.weight_tensor(g, n, shape, gold["weight_seed"], gold["weights"]))
+        clips = [syn.synth_audio(c["seed"], int(c["secs"] * 16000), c["kind"]) for c in gold["clips"]]
+        for per_row in (0, 1):
+            assert lib.cw_test_set_option(b"cross_per_row", per_row) == 0
+            _, nf = eng.mel(clips)
+            outs[per_row] = generation.generate(eng, B, nf, language=gk["language"], task=gk["task"], max_new_tokens=gk["max_new_tokens"],
+                                                min_new_tokens=gk["min_new_tokens"], num_beams=gk["num_beams"])
+    finally:
+        lib.cw_test_set_option(b"cross_per_row", 0)
+        eng.close()
+    a, b = outs[0], outs[1]
+    same_text = 0
+    for k, clip in enumerate(gold["clips"]):
+        assert list(a["sequences"][k]) == list(b["sequences"][k]), (k, a["sequences"][k][:12], b["sequences"][k][:12])
+        assert np.array_equal(np.asarray(a["token_timestamps"][k]), np.asarray(b["token_timestamps"][k])), k
+        n = len(a["token_timestamps"][k])
+        assert n > 8
+        text, words = collate.decode_asr(vocab, [{"tokens": a["sequences"][k][:n], "token_timestamps": a["token_timestamps"][k],
+                                                  "stride": (30.0, 0.0, 0.0)}])
+        assert isinstance(text, str) and len(words) > 0
+        same_text += int(text == clip["text"])
+    print(f"[e4m3 cache, 5 beams] {same_text} / {B} clips reproduce the bf16-cache reference text")
+
+
 def test_beam_search_bf16_engine_many_rows_tracks_f32_engine(tiny):
     """bf16 engine, 4 chunks x 5 beams = 20 decoder rows (the 17..64-row GEMV path + ancestry attention + the key-split
     cross-attention shared per item): runs, is well formed, and its first generate call picks the f32 engine's hypotheses

@@ -1,6 +1,8 @@
 """GPU parity tests, kernel level: every HIP kernel family against the oracle (numpy) on seeded
 inputs, through the C ABI.  Integer outputs (DTW paths) must match exactly; floating point within the
 tolerance written next to each check."""
+import os
+
 import numpy as np
 import pytest
 
@@ -36,7 +38,12 @@ def _round16(dt, *arrs):
 
 
 def rel_err(a, b):
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+    e = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+    log = os.environ.get("CW_TEST_ERRLOG")                       # tolerance audit: CW_TEST_ERRLOG=<file> records every measured error
+    if log:
+        with open(log, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{e:.3e}\n")
+    return e
 
 
 @pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
@@ -304,6 +311,37 @@ def test_cross_attention_over_the_e4m3_cache(engines, dt, path, B, H, S, kv_div)
     tol = 2e-4 if path == "mfma8" else 5e-6
     assert rel_err(got, ref) < tol, (dt, path, rel_err(got, ref))
     assert np.abs(al - pr[:, H - 1]).max() < tol, (dt, path, np.abs(al - pr[:, H - 1]).max())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("nq,H,S", [(5, 3, 1500), (2, 2, 1499), (3, 1, 50), (4, 2, 750), (8, 2, 1500), (7, 1, 301)])
+def test_e4m3_cache_beam_rows_equal_one_row_blocks(engines, dt, nq, H, S):
+    """Beam search over the e4m3 cache: attn_cross_mfma8_rows_kernel takes the nq hypotheses of an item in ONE block per (item,
+    head, key split) -- four queries x three e4m3 terms per 16-row A tile, a query = a 16-lane row of the C fragment.  Per row it
+    is the one-row kernel's arithmetic operation for operation, so the outputs and the captured alignment rows must be
+    BIT-identical to a launch in which every row owns a private copy of the cache (kv_div = 1)."""
+    import os
+    from crisperwhisper_amd import _native
+    if os.environ.get("CW_CROSS8_VALU") or os.environ.get("CW_CROSS_PER_ROW"):
+        pytest.skip("the rows kernel is the matrix-core path of the default process")
+    items = 2
+    B = items * nq
+    rng = np.random.default_rng(nq * 100 + S + H)
+    q = (rng.standard_normal((B, H, 64)) * 0.35).astype(np.float32)
+    q[1] *= 6.0                                                   # per-query e4m3 scales differ inside one tile
+    k = rng.standard_normal((items, H, S, 64)).astype(np.float32)
+    v = (rng.standard_normal((items, H, S, 64)) * np.linspace(0.5, 2.0, 64, dtype=np.float32)).astype(np.float32)
+    k, v = _round16(dt, k, v)
+    lib = _native.load()
+    assert lib.cw_test_set_option(b"cross_test_fp8", 1) == 0
+    try:
+        got, al = engines[dt].test_cross_attention(q, k, v, kv_div=nq, align_head=H - 1)
+        one, al1 = engines[dt].test_cross_attention(q, np.repeat(k, nq, axis=0), np.repeat(v, nq, axis=0), kv_div=1, align_head=H - 1)
+    finally:
+        lib.cw_test_set_option(b"cross_test_fp8", 0)
+    assert np.isfinite(got).all() and np.abs(got).max() > 0
+    assert np.array_equal(got, one), (dt, nq, S, float(np.abs(got - one).max()))
+    assert np.array_equal(al, al1), (dt, nq, S, float(np.abs(al - al1).max()))
 
 
 def test_cross_attention_rejects_key_counts_that_leave_a_split_empty(engines):
