@@ -1653,8 +1653,12 @@ __device__ inline void unpk4_e4m3(unsigned w, float* o) {
     const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), c = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
     o[0] = a[0]; o[1] = a[1]; o[2] = c[0]; o[3] = c[1];
 }
-// x[0..7] (|x| <= 448) = t0 + t1 / 16 + t2 / 256 with t_i on the e4m3 grid; returns term `term` (0..2) as 8 bytes, 0 otherwise
+// x[0..7] (|x| <= 448) = t0 + t1 / 16 + t2 / 256 with t_i on the e4m3 grid; returns term `term` (0..2) as 8 bytes, 0 otherwise.
+// Contraction is off in here: x is usually a product (query x scale), and hipcc fuses `x - t0` with that product in one inlining
+// context and not in the next (attn_cross_mfma8_rows_kernel got fma(q, c, -t0), the one-row kernel v_mul + v_sub: residuals one
+// rounding apart, scores a few units in the last place apart -- found by the bit-identity test of the two kernels).
 __device__ inline long split3_e4m3(const float* x, int term) {
+#pragma clang fp contract(off)
     float r[8], f[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = x[e];
