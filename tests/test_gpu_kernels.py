@@ -46,7 +46,9 @@ def rel_err(a, b):
     return e
 
 
-@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
+# tolerances: 2-3 x the largest error these seeded cases measure on MI355X (CW_TEST_ERRLOG audit, round 5: bf16 3.5e-3 -- the bf16
+# rounding of the stored output, 2^-9 of the largest element and up --, f16 4.1e-4, f32 5.9e-7); round 4 carried 2e-2 / 2.5e-3 / 2e-5
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-6), ("bf16", 8e-3), ("f16", 1.2e-3)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1000, 384, 256), (77, 51, 64)])
 def test_gemm(engines, dt, tol, M, N, K):
     rng = np.random.default_rng(M + N + K)
@@ -79,7 +81,7 @@ def test_gemm_256_tile_kernel(engines, M, N, K):
             if gelu:
                 ref = OMOD.gelu(ref.astype(np.float32)).astype(np.float64)
             got = eng.test_gemm(A, W, b, gelu)
-            assert rel_err(got, ref) < 2e-2, (M, N, K, gelu, rel_err(got, ref))
+            assert rel_err(got, ref) < 8e-3, (M, N, K, gelu, rel_err(got, ref))   # measured 2.8e-3 (bf16 output rounding)
     finally:
         eng.lib.cw_test_set_option(b"gemm256_min_tiles", 200)
 
@@ -140,7 +142,7 @@ def test_gemm_pingpong_schedule_is_bit_identical_to_lockstep(engines, M, N, K, s
         assert eng.lib.cw_test_set_option(b"gemm_pp", 0) == 0
         want = eng.test_gemm(A, W, b, True)
         ref = OMOD.gelu((A.astype(np.float64) @ W.astype(np.float64).T + b).astype(np.float32))
-        assert rel_err(want, ref) < 2e-2
+        assert rel_err(want, ref) < 8e-3                            # measured 3.8e-3
         assert eng.lib.cw_test_set_option(b"gemm_pp", 1) == 0
         assert eng.lib.cw_test_set_option(b"gemm_8ph", 1 if sched == "8phase" else 0) == 0
         assert eng.lib.cw_test_set_option(b"gemm_w128", 1 if sched == "w128" else 0) == 0
@@ -154,7 +156,8 @@ def test_gemm_pingpong_schedule_is_bit_identical_to_lockstep(engines, M, N, K, s
         eng.lib.cw_test_set_option(b"gemm_w128", 0)
 
 
-@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16", 2e-2), ("f16", 2.5e-3)])
+# measured (same audit): bf16 1.9e-3, f16 2.4e-4, f32 2.1e-7
+@pytest.mark.parametrize("dt,tol", [("f32", 1e-6), ("bf16", 6e-3), ("f16", 8e-4)])
 @pytest.mark.parametrize("Mb,N,K", [(1, 128, 128), (3, 200, 256), (8, 1769, 128), (16, 64, 1280), (20, 128, 512), (40, 96, 1280), (64, 80, 256),
                                      (8, 5120, 1280), (5, 4160, 256), (12, 5120, 1280)])   # the last three: two column tiles per block (wide LayerNorm GEMV)
 def test_gemv_with_layernorm(engines, dt, tol, Mb, N, K):
