@@ -2030,203 +2030,6 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_rows_kernel(Cr
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Many rows (17..64 greedy rows: H x B x ATT_NS = 2040..7680 items of 32 KB): the one-row kernel as a PERSISTENT block that walks
-// its items with the next item's cache bytes already requested.  With one block per item a CU holds four blocks and each of them
-// spends most of its lifetime in its fixed chain -- query split, three barriers, two reductions, the partial-plane stores -- during
-// which its quarter of the CU's request slots is idle: batch 64 measured 46 us per launch = 5.3 TB/s of e4m3 bytes where the bf16
-// kernel (twice the bytes behind the same chain) reaches 6.5.  Here the K / V fragments of item i + 1 go out before item i is
-// touched (two register sets, the loop is unrolled by two so that no register is copied), the query row and the two scales of
-// item i + 1 as soon as item i has consumed its own; hipcc's counted vmcnt keeps them in flight across the three barriers.  Per
-// item the arithmetic is attn_cross_mfma8_kernel<1, false>'s statement for statement (bit-identical: test_e4m3_cache_stream_kernel_
-// equals_one_block_per_item).  LDS is reused from item to item without an extra barrier: every buffer is rewritten only behind the
-// next item's first (s_max), second (red, red_l) barrier, or by its own wave (s_p), and s_aq / s_c1 are last read before barrier 2.
-// ---------------------------------------------------------------------------------------------------
-struct X8Item { int h, b, sp, k_lo, nk; size_t bh; };
-struct X8Regs { uint4 kf[2], vf[2]; };
-__global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_stream_kernel(CrossSplitParams p, int n_items) {
-    __shared__ float s_max[8];
-    __shared__ __attribute__((aligned(16))) float red[8 * 64];
-    __shared__ float red_l[8];
-    __shared__ __attribute__((aligned(16))) float s_p[8 * 32];
-    __shared__ long s_aq[2 * 64];
-    __shared__ __attribute__((aligned(16))) float s_qrow[64];
-    __shared__ float s_c1;
-    const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kb = wave * 32;
-    const int D = p.H * 64;
-    auto item = [&](int it) {
-        X8Item t;
-        t.h = it % p.H;
-        const int rest = it / p.H;
-        t.b = rest % p.B; t.sp = rest / p.B;
-        t.bh = (size_t)t.b * p.H + t.h;
-        t.k_lo = t.sp * per; t.nk = min(p.n_keys, t.k_lo + per) - t.k_lo;
-        return t;
-    };
-    auto issue = [&](const X8Item& t, X8Regs& x) {
-        const unsigned char* Kh = (const unsigned char*)p.K + (t.bh * p.n_keys + t.k_lo) * 64;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) x.kf[u] = *(const uint4*)(Kh + (size_t)min(kb + u * 16 + r, t.nk - 1) * 64 + g * 16);
-        const unsigned char* Vf = (const unsigned char*)p.V + (t.bh * ATT_NS + t.sp) * X8_SPLIT_BYTES + (size_t)wave * 2048 + lane * 16;
-        x.vf[0] = *(const uint4*)Vf; x.vf[1] = *(const uint4*)(Vf + 1024);
-    };
-    // the small per-item operands, one item ahead like the cache bytes and UNCONDITIONAL in every wave (a load under a branch makes
-    // every later counted wait conservative: hipcc must assume it was not issued): lane c's column of the query row (256 B per wave
-    // instruction; wave 0 redistributes it through LDS as the fused one-row kernel does), the two scales, the alignment slot of the
-    // head and the decoder position of the row
-    // (slot and position come back in lanes 0 and 1 of ONE load with a lane-dependent address and are read out by readlane where they
-    // are used: loaded from a uniform address hipcc moves them to scalar registers -- v_readfirstlane behind a wait -- on the spot)
-    float q1_n; float2 sc_n; int sm_n;
-    auto issue_q = [&](const X8Item& t) {
-        q1_n = p.q[(size_t)t.b * D + t.h * 64 + lane];
-        sc_n = *(const float2*)(p.kv_scale + t.bh * 2);
-        const int* src = lane == 0 ? p.align_slot + t.h : p.pos + t.b;
-        sm_n = *src;
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // one item out of register set x; `nx`: the item after it (or this one again behind the block's last item: a harmless re-request)
-    auto compute = [&](const X8Item& t, const X8Regs& x, const X8Item& nx) {
-        const float ks = sc_n.x, vs = sc_n.y, q1 = q1_n;
-        const int slot = p.align_out ? __builtin_amdgcn_readlane(sm_n, 0) : -1;
-        const size_t rowi = slot >= 0 ? ((size_t)t.b * p.n_align + slot) * p.align_rows + __builtin_amdgcn_readlane(sm_n, 1) : 0;
-        issue_q(nx);
-        if (wave == 0) {
-            s_qrow[lane] = q1;                                     // wave-private: ordered by the wave's own lgkmcnt
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float qf[16];
-            const float* qp = s_qrow + g * 16;
-            const float4 q0 = *(const float4*)qp, q1v = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
-            qf[0] = q0.x; qf[1] = q0.y; qf[2] = q0.z; qf[3] = q0.w; qf[4] = q1v.x; qf[5] = q1v.y; qf[6] = q1v.z; qf[7] = q1v.w;
-            qf[8] = q2.x; qf[9] = q2.y; qf[10] = q2.z; qf[11] = q2.w; qf[12] = q3.x; qf[13] = q3.y; qf[14] = q3.z; qf[15] = q3.w;
-            float am = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) am = fmaxf(am, fabsf(qf[e]));
-            am = fmaxf(am, __shfl_xor(am, 16, 64));
-            am = fmaxf(am, __shfl_xor(am, 32, 64));
-            const float cq = am > 0.f ? 448.0f / am : 1.0f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) qf[e] *= cq;
-            s_aq[lane] = split3_e4m3(qf, r);
-            s_aq[64 + lane] = split3_e4m3(qf + 8, r);
-            if (lane == 0) s_c1 = cq;
-        }
-        __syncthreads();
-        const long aq0 = s_aq[lane], aq1 = s_aq[64 + lane];
-        const float c1 = s_c1;
-        const float s_unscale = ks / c1;
-        float sc[2], mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq0, (long)(((unsigned long)x.kf[u].y << 32) | x.kf[u].x), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq1, (long)(((unsigned long)x.kf[u].w << 32) | x.kf[u].z), c, 0, 0, 0);
-            const float v = ((c[2] * 0.0625f + c[1]) * 0.0625f + c[0]) * s_unscale;      // small terms first
-            sc[u] = (g == 0 && kb + u * 16 + r < t.nk) ? v : -INFINITY;
-            mx = fmaxf(mx, sc[u]);
-        }
-        mx = wave_max(mx);
-        if (lane == 0) s_max[wave] = mx;
-        __syncthreads();
-        {
-            float m = s_max[0];
-#pragma unroll
-            for (int w = 1; w < 8; ++w) m = fmaxf(m, s_max[w]);
-            mx = m;
-        }
-        float* spw = s_p + wave * 32;
-        float pk[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int k = kb + u * 16 + r;
-            pk[u] = (g == 0 && k < t.nk) ? expf(sc[u] - mx) : 0.f;
-            if (slot >= 0 && g == 0 && k < t.nk) p.align_out[rowi * p.n_keys + t.k_lo + k] = pk[u];   // un-normalised; align_normalize_kernel finishes the row
-        }
-        const float lsum = wave_sum(pk[0] + pk[1]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // the previous item's reads of the row are done
-        if (g == 0) { spw[r] = pk[0] * 256.f; spw[16 + r] = pk[1] * 256.f; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float pf[8];
-        {
-            const float4 p0 = *(const float4*)(spw + g * 8), p1 = *(const float4*)(spw + g * 8 + 4);
-            pf[0] = p0.x; pf[1] = p0.y; pf[2] = p0.z; pf[3] = p0.w; pf[4] = p1.x; pf[5] = p1.y; pf[6] = p1.z; pf[7] = p1.w;
-        }
-        const long ap = split3_e4m3(pf, r);
-        const unsigned vw[8] = {x.vf[0].x, x.vf[0].y, x.vf[0].z, x.vf[0].w, x.vf[1].x, x.vf[1].y, x.vf[1].z, x.vf[1].w};
-        float o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            f32x4_t c = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ap, (long)(((unsigned long)vw[2 * dt + 1] << 32) | vw[2 * dt]), c, 0, 0, 0);
-            o[dt] = (c[2] * 0.0625f + c[1]) * 0.0625f + c[0];
-        }
-        if (g == 0) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) red[wave * 64 + dt * 16 + r] = o[dt];
-        }
-        if (lane == 0) red_l[wave] = lsum;
-        __syncthreads();
-        if (tid < 64) {
-            float a = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) a += red[w * 64 + tid];
-            p.part_o[((size_t)t.sp * p.B + t.b) * D + t.h * 64 + tid] = a * (vs * (1.0f / 256.0f));
-        } else if (tid == 64) {
-            float l = 0.f, m = s_max[0];
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { l += red_l[w]; m = fmaxf(m, s_max[w]); }
-            float* ml = p.part_ml + (((size_t)t.b * p.H + t.h) * ATT_NS + t.sp) * 2;
-            ml[0] = m; ml[1] = l;
-            if (slot >= 0) { p.align_ml[(rowi * ATT_NS + t.sp) * 2] = m; p.align_ml[(rowi * ATT_NS + t.sp) * 2 + 1] = l; }
-        }
-    };
-    int it = blockIdx.x;
-    if (it >= n_items) return;
-    X8Regs xa, xb;
-    X8Item cur = item(it);
-    issue(cur, xa);
-    issue_q(cur);
-    for (;;) {
-        int nxt = it + gridDim.x;
-        bool has = nxt < n_items;
-        X8Item nx = item(has ? nxt : it);
-        issue(nx, xb);
-        compute(cur, xa, nx);
-        if (!has) break;
-        it = nxt; cur = nx;
-        nxt = it + gridDim.x;
-        has = nxt < n_items;
-        nx = item(has ? nxt : it);
-        issue(nx, xa);
-        compute(cur, xb, nx);
-        if (!has) break;
-        it = nxt; cur = nx;
-    }
-}
-
-static int g_cross8_stream = -1;   // -1: from the environment (CW_CROSS8_NO_STREAM); test option "cross8_stream"
-void cw_cross8_set_stream(int on) { g_cross8_stream = on; }
-// blocks of the persistent kernel: what is resident at once, trimmed so that every block walks the same number of items (+- 1)
-static int cross8_stream_grid(int n_items) {
-    static int resident = 0;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t pr;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_cross_mfma8_stream_kernel, CROSS_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount < 1) pr.multiProcessorCount = 256;
-        resident = per_cu * pr.multiProcessorCount;
-    });
-    const int rounds = (n_items + resident - 1) / resident;
-    return (n_items + rounds - 1) / rounds;
-}
-
 int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st) {
     if ((p.n_keys + ATT_NS - 1) / ATT_NS > C8U * CROSS8_GROUPS || !p.kv_scale) return CW_ERR_INVALID;
     if (p.n_keys < 1 || (ATT_NS - 1) * ((p.n_keys + ATT_NS - 1) / ATT_NS) >= p.n_keys) return CW_ERR_INVALID;   // a split without a key
@@ -2247,13 +2050,9 @@ int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st) {
             else hipLaunchKernelGGL((attn_cross_mfma8_kernel<1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
             return CW_OK;
         }
-        // many independent rows: persistent blocks with the next item's bytes in flight (A/B: CW_CROSS8_NO_STREAM=1, test option cross8_stream)
-        const int n_items = p.H * p.B * ATT_NS;
-        if (g_cross8_stream < 0) g_cross8_stream = !cw_sw::cw_switches().cross8_no_stream;
-        if (g_cross8_stream && p.kv_div <= 1 && f != 2 && n_items >= 2048 && p.align_slot && p.pos) {
-            hipLaunchKernelGGL(attn_cross_mfma8_stream_kernel, dim3(cross8_stream_grid(n_items)), dim3(CROSS_THREADS), 0, st, p, n_items);
-            return CW_OK;
-        }
+        // (17..64 rows as persistent blocks with the next item's bytes in flight: bit-identical, measured slower -- 50.9 against 38.5 us
+        // per launch at 64 rows; four independent blocks per CU are the better prefetch.  profiles/r05_e4m3_stream_kernel_rejected.txt,
+        // the kernel is in commit 6a5babd)
         if (ATT_NS % 2 == 0 && f == 2)
             hipLaunchKernelGGL((attn_cross_mfma8_kernel<2, false>), dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
         else hipLaunchKernelGGL((attn_cross_mfma8_kernel<1, false>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);

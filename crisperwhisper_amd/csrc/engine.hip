@@ -2268,7 +2268,6 @@ int32_t cw_test_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "comb_rowgroups")) { cw_bf16::cw_gemv_set_comb_rowgroups(value); cw_f16::cw_gemv_set_comb_rowgroups(value); return CW_OK; }
     if (!strcmp(name, "gemm_w128")) { cw_bf16::cw_gemm_set_w128(value); cw_f16::cw_gemm_set_w128(value); return CW_OK; }
     if (!strcmp(name, "cross_valu")) { cw_bf16::cw_cross_set_valu(value); cw_f16::cw_cross_set_valu(value); return CW_OK; }
-    if (!strcmp(name, "cross8_stream")) { cw_bf16::cw_cross8_set_stream(value); cw_f16::cw_cross8_set_stream(value); return CW_OK; }
     if (!strcmp(name, "cross_per_row")) { cw_bf16::cw_cross_set_per_row(value); cw_f16::cw_cross_set_per_row(value); return CW_OK; }
     return CW_ERR_INVALID;
 }

@@ -323,7 +323,6 @@ struct MelTables {
     int cw_launch_gemm_w128(int epi, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const EpiParams& ep, int tm2, int tn2, hipStream_t st); \
     void cw_cross_set_valu(int on); \
     void cw_cross_set_per_row(int on); \
-    void cw_cross8_set_stream(int on); \
     int cw_launch_layernorm_fp8(const float* x, const float* g, const float* b, void* out8, float* scale, int rows, int d, hipStream_t st); \
     int cw_launch_quant_rows_fp8(const void* x, int rows, int K, void* out8, float* scale, hipStream_t st); \
     int cw_launch_gemm_fp8(int epi, const void* A8, int lda, const void* W8, int M, int N, int K, const float* sa, const float* sw, const EpiParams& ep, hipStream_t st); \

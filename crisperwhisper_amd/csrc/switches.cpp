@@ -37,7 +37,6 @@ Switches read_switches() {
     s.cross_no_tr = flag("CW_CROSS_NO_TR");
     s.cross8_valu = flag("CW_CROSS8_VALU");
     s.cross_mfma1 = flag("CW_CROSS_MFMA1");
-    s.cross8_no_stream = flag("CW_CROSS8_NO_STREAM");
     s.cross_lds_pad = num("CW_CROSS_LDS_PAD", 0);
     s.cross8_nsb = num("CW_CROSS8_NSB", 0);
     s.dl_depth = num("CW_DL_DEPTH", 16);

@@ -13,7 +13,7 @@ struct Switches {
     bool no_graph, no_ln_fold, no_fuse6, rows_ln, no_rows_hilo, no_stack_center, no_mid16, dtw_block, fuse_mlp, no_wpack, mlp_pair, mlp_pair_fence, declayer, no_qkv_self, mlp_chain;
     int skinny, prefetch, prefetch_wide, prefetch_what, stack_nt3, stack_nt5;
     // attention launchers
-    bool attn_v1, anc_attn_v1, cross_per_row, cross_valu, cross_no_tr, cross8_valu, cross_mfma1, cross8_no_stream;
+    bool attn_v1, anc_attn_v1, cross_per_row, cross_valu, cross_no_tr, cross8_valu, cross_mfma1;
     int cross_lds_pad, cross8_nsb, dl_depth, dl_kvwait, mlp_chain_delay, qkv_self_dbg;
     // GEMM / GEMV launchers
     bool no_glds, no_gemm256, no_gemm_pp, no_gemm_8ph, gemm_w128, no_gemv_loop, comb_nt2, comb_no_rowgroups, mt_no_prea;

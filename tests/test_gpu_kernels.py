@@ -347,41 +347,6 @@ def test_e4m3_cache_beam_rows_equal_one_row_blocks(engines, dt, nq, H, S):
     assert np.array_equal(al, al1), (dt, nq, S, float(np.abs(al - al1).max()))
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("B,H,S", [(40, 20, 1500), (18, 20, 1499), (64, 6, 50), (23, 15, 301)])
-def test_e4m3_cache_stream_kernel_equals_one_block_per_item(engines, dt, B, H, S):
-    """17..64 greedy rows over the e4m3 cache: attn_cross_mfma8_stream_kernel -- persistent blocks that walk the (head, row, key
-    split) items with the next item's cache bytes, query column, scales, alignment slot and position already requested -- against
-    one block per item (test option cross8_stream = 0).  Same arithmetic statement for statement: partial planes, (m, l) pairs and
-    alignment rows must be BIT-identical; item counts that do not divide by the grid, splits with keyless waves (S = 50)."""
-    import os
-    from crisperwhisper_amd import _native
-    if os.environ.get("CW_CROSS8_VALU") or os.environ.get("CW_CROSS8_NO_STREAM") or os.environ.get("CW_CROSS8_NSB"):
-        pytest.skip("the stream kernel is the matrix-core path of the default process")
-    assert B * H * 6 >= 2048                                      # below that the launcher keeps one block per item
-    rng = np.random.default_rng(B * 10 + H + S)
-    q = (rng.standard_normal((B, H, 64)) * 0.35).astype(np.float32)
-    q[B // 2] *= 5.0
-    k = rng.standard_normal((B, H, S, 64)).astype(np.float32)
-    v = (rng.standard_normal((B, H, S, 64)) * np.linspace(0.5, 2.0, 64, dtype=np.float32)).astype(np.float32)
-    k, v = _round16(dt, k, v)
-    lib = _native.load()
-    assert lib.cw_test_set_option(b"cross_test_fp8", 1) == 0
-    try:
-        assert lib.cw_test_set_option(b"cross8_stream", 1) == 0
-        got, al = engines[dt].test_cross_attention(q, k, v, kv_div=1, align_head=H - 1)
-        got2, al2 = engines[dt].test_cross_attention(q, k, v, kv_div=1, align_head=H - 1)
-        assert lib.cw_test_set_option(b"cross8_stream", 0) == 0
-        one, al1 = engines[dt].test_cross_attention(q, k, v, kv_div=1, align_head=H - 1)
-    finally:
-        lib.cw_test_set_option(b"cross8_stream", 1)
-        lib.cw_test_set_option(b"cross_test_fp8", 0)
-    assert np.isfinite(got).all() and np.abs(got).max() > 0
-    assert np.array_equal(got, got2) and np.array_equal(al, al2)
-    assert np.array_equal(got, one), (dt, B, H, S, float(np.abs(got - one).max()))
-    assert np.array_equal(al, al1), (dt, B, H, S, float(np.abs(al - al1).max()))
-
-
 def test_cross_attention_rejects_key_counts_that_leave_a_split_empty(engines):
     """7 keys over 6 splits of ceil(7 / 6) = 2: splits 4 and 5 would own no key (the kernels clamp loads to the split's last key);
     the launcher refuses instead of reading in front of the cache."""
