@@ -892,8 +892,9 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
     float qa1 = 0.f, qb1 = 0.f, qw1 = 0.f, qc1 = 0.f;
     if (FUSED) {                                                // loads only: using a value in here makes hipcc wait before the K/V loads go out
         const int Dm = p.H * 64;
-        pt0 = *(const float2*)(p.pstats + ((size_t)min(lane, p.n_pstats - 1) * 16 + b0) * 2);
-        pt1 = *(const float2*)(p.pstats + ((size_t)min(lane + 64, p.n_pstats - 1) * 16 + b0) * 2);
+        const float* ps = p.pstats + (size_t)(b0 >> 4) * p.n_pstats * 32;   // one [tiles][16][2] plane per group of 16 rows (gemv_stack_kernel)
+        pt0 = *(const float2*)(ps + ((size_t)min(lane, p.n_pstats - 1) * 16 + (b0 & 15)) * 2);
+        pt1 = *(const float2*)(ps + ((size_t)min(lane + 64, p.n_pstats - 1) * 16 + (b0 & 15)) * 2);
         const size_t col = (size_t)h * 64 + lane;
         qa1 = p.qa[(size_t)b0 * Dm + col]; qb1 = p.qb[(size_t)b0 * Dm + col];
         qw1 = p.qw[col]; qc1 = p.qbias[col];
@@ -1369,7 +1370,7 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
             return CW_OK;
         }
 #endif
-        if (!p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.B > 16) return CW_ERR_INVALID;
+        if (!p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.B > 64) return CW_ERR_INVALID;
         // A/B (CW_CROSS_LDS_PAD=bytes): unused dynamic LDS that limits how many blocks share a CU (the 960 blocks of a B = 8 launch
         // are all resident at once: their tails -- softmax, V pass, reductions -- then run together after the last byte landed)
         const int lds_pad = cw_sw::cw_switches().cross_lds_pad;
@@ -1704,8 +1705,9 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
     float2 pt0 = make_float2(0.f, 0.f), pt1 = pt0;
     float qa1 = 0.f, qb1 = 0.f, qw1 = 0.f, qc1 = 0.f;
     if (FUSED) {
-        pt0 = *(const float2*)(p.pstats + ((size_t)min(lane, p.n_pstats - 1) * 16 + b) * 2);
-        pt1 = *(const float2*)(p.pstats + ((size_t)min(lane + 64, p.n_pstats - 1) * 16 + b) * 2);
+        const float* ps = p.pstats + (size_t)(b >> 4) * p.n_pstats * 32;    // one [tiles][16][2] plane per group of 16 rows (gemv_stack_kernel)
+        pt0 = *(const float2*)(ps + ((size_t)min(lane, p.n_pstats - 1) * 16 + (b & 15)) * 2);
+        pt1 = *(const float2*)(ps + ((size_t)min(lane + 64, p.n_pstats - 1) * 16 + (b & 15)) * 2);
         const size_t col = (size_t)h * 64 + lane;
         qa1 = p.qa[(size_t)b * D + col]; qb1 = p.qb[(size_t)b * D + col]; qw1 = p.qw[col]; qc1 = p.qbias[col];
     }

@@ -108,7 +108,10 @@ int cw_launch_fold_rowvec(const float* A, const float* s, float scale, const flo
 template <int RPW, int NSLOT, int PER_LANE, int NT>
 __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
-    const int K = p.K, Mb = p.Mb;
+    // 17..64 rows (round 5): blockIdx.y = group of 16 rows; a group is a 16-row launch of its own over the same weights (its
+    // blocks follow the first group's on the same XCD: 240 % 8 == 0, so the tile's weights come out of that L2 from the second
+    // group on), per-row arithmetic unchanged -- rows m0 .. m0 + 15 of every operand, pstats one plane per group
+    const int K = p.K, m0 = blockIdx.y * 16, Mb = min(16, p.Mb - m0);
     const int xs_stride = K + 8;
     bf16_t* xs = (bf16_t*)smem_s;                               // [16][K+8]
     float* red = (float*)(smem_s + (size_t)16 * xs_stride * 2);  // [4 waves][NT][4][64]
@@ -119,14 +122,14 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
     int si = 0;                                                  // block-uniform segment
     if (p.nseg > 1 && bid >= p.seg[1].block0) si = 1;
     if (p.nseg > 2 && bid >= p.seg[2].block0) si = 2;
-    const float* __restrict__ x = SEG_PICK(x);
+    const float* __restrict__ x = SEG_PICK(x) + (size_t)m0 * K;
     const float* __restrict__ bias = SEG_PICK(bias);
     const int tile0 = SEG_PICK(tile0), n_tiles = SEG_PICK(n_tiles), block0 = SEG_PICK(block0), snt = SEG_PICK(nt);
     const int steps = K >> 7, nvec = K >> 2;
     const int tl0 = (bid - block0) * snt;                        // first tile of this block inside the segment
     const bf16_t* __restrict__ W = (const bf16_t*)p.W;
 
-    if (p.zero) {                                                // clear a buffer that a later launch accumulates into
+    if (p.zero && blockIdx.y == 0) {                             // clear a buffer that a later launch accumulates into
         const int zi = bid * 256 + tid;
         if (zi < p.zero_n4) ((float4*)p.zero)[zi] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -245,10 +248,13 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
     __syncthreads();
     const int epi = SEG_PICK(epi);
     const int ldo = n_tiles * 16;
-    float* __restrict__ out = SEG_PICK(out);
+    float* __restrict__ out = SEG_PICK(out) + (size_t)m0 * ldo;
     float* __restrict__ out2 = SEG_PICK(out2);
+    if (out2) out2 += (size_t)m0 * ldo;
     const float* __restrict__ resid = SEG_PICK(resid);
+    if (resid) resid += (size_t)m0 * ldo;
     float* __restrict__ pstats = SEG_PICK(pstats);
+    if (pstats) pstats += (size_t)blockIdx.y * ((n_tiles + snt - 1) / snt) * 32;   // [group][blocks of the segment][16][2]
     float ps1 = 0.f, ps2 = 0.f;                                 // this lane's share of (sum, sum of squares) of row g*4 + wave
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -294,9 +300,10 @@ static int launch_stack_nt(StackParams& p, hipStream_t st) {
     }
     if (p.zero && (long long)blocks * 256 < p.zero_n4) return CW_ERR_INVALID;
     const size_t lds = (size_t)16 * (p.K + 8) * 2 + (size_t)4 * NT * 4 * 64 * 4 + 16 * 4;
-    if (p.K <= 256) hipLaunchKernelGGL((gemv_stack_kernel<RPW, 1, 1, NT>), dim3(blocks), dim3(256), lds, st, p);
-    else if (p.K <= 768) hipLaunchKernelGGL((gemv_stack_kernel<RPW, 2, 3, NT>), dim3(blocks), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((gemv_stack_kernel<RPW, 3, 5, NT>), dim3(blocks), dim3(256), lds, st, p);
+    const dim3 grid(blocks, (p.Mb + 15) / 16);                  // y: groups of 16 rows
+    if (p.K <= 256) hipLaunchKernelGGL((gemv_stack_kernel<RPW, 1, 1, NT>), grid, dim3(256), lds, st, p);
+    else if (p.K <= 768) hipLaunchKernelGGL((gemv_stack_kernel<RPW, 2, 3, NT>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gemv_stack_kernel<RPW, 3, 5, NT>), grid, dim3(256), lds, st, p);
     return CW_OK;
 }
 
@@ -304,7 +311,7 @@ static int launch_stack_nt(StackParams& p, hipStream_t st) {
 // is one block per CU at most where possible
 int cw_launch_gemv_stack(const StackParams& p_in, int nt, hipStream_t st) {
     StackParams p = p_in;
-    if (p.Mb < 1 || p.Mb > 16 || p.K % 128 || p.K > 1280 || p.nseg < 1 || p.nseg > 3) return CW_ERR_INVALID;
+    if (p.Mb < 1 || p.Mb > 64 || p.K % 128 || p.K > 1280 || p.nseg < 1 || p.nseg > 3) return CW_ERR_INVALID;
     if (nt <= 0) {
         nt = 1;
         for (;;) {

@@ -155,6 +155,7 @@ struct cw_ctx {
     int *d_pos = nullptr, *d_cfg = nullptr;   // per-row decoder input position; [n_prompt, min_new, max_length, use_forced]
     hipGraphExec_t step_graph[65] = {};       // captured decode step (layers + logits + sampling) per batch size
     bool use_graph = true;
+    bool fuse_rows = true;                    // fused out-projection / cross-query stage at 17..64 greedy rows (CW_NO_FUSE_ROWS=1: off)
     cw_gen_cfg gen{};
     bool gen_set = false;
     bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
@@ -389,6 +390,7 @@ static int create_impl(cw_ctx* c) {
     }
 #endif
     c->use_graph = !sw.no_graph;
+    c->fuse_rows = !sw.no_fuse_rows;
     c->fold_enabled = !sw.no_ln_fold;
     c->fuse6_enabled = !sw.no_fuse6;
     c->rows_ln_enabled = sw.rows_ln;
@@ -546,7 +548,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->dmid, (size_t)Bm * F * 4));
     CWCHK(c, dmalloc(c, &c->dx1, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->dx2c, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->d_qa, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->d_qb, (size_t)Bm * D * 4));
-    CWCHK(c, dmalloc(c, &c->d_u1, (size_t)Bm * F * 4)); CWCHK(c, dmalloc(c, &c->d_pstats, (size_t)128 * 16 * 2 * 4));
+    CWCHK(c, dmalloc(c, &c->d_u1, (size_t)Bm * F * 4)); CWCHK(c, dmalloc(c, &c->d_pstats, (size_t)128 * 64 * 2 * 4));   // [group of 16 rows 4][tile <= 128][16][2]
     CWCHK(c, dmalloc(c, &c->d_rstats, (size_t)((D > F ? D : F) / 16 + 1) * 64 * 2 * 4));
     CWCHK(c, dmalloc(c, &c->d_bar, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_err, 4));
     {   // declayer.hip: granules are valid by tag only (never cleared); epoch 0 is never used
@@ -1130,7 +1132,12 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     // fused out-projection / cross-query stage (decfuse.hip): greedy rows of one MFMA half tile, 16-bit caches.  The residual
     // stream then alternates between two buffers: a layer reads x from `xin` and leaves x1, x2, x3 in `xalt`.
     // (e4m3 cache: the fp8 matrix-core kernel finishes the fused query too; its VALU fallback does not)
-    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && nb <= 16 && c->beam_K == 0 &&
+    // 17..64 greedy rows (round 5): the same stage in groups of 16 rows (gemv_stack_kernel's grid y) replaces out-projection,
+    // LayerNorm preparation and query projection -- three of the layer's twelve launches -- by one; the rest of the layer keeps its
+    // preparation + gemv_mt launches, on the alternating buffers.  CW_NO_FUSE_ROWS=1: the twelve launches (A/B).  Batch 64: decode
+    // 4.43 -> 4.28 ms per token step, 64 / 64 clips; over the e4m3 cache it measured flat (3.418 -> 3.411: the fused query costs its
+    // cross-attention kernel -- every wave of 7680 blocks finishes the query -- what the stage saves), so that mode keeps its launches
+    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && (nb <= 16 || (c->fuse_rows && nb <= 64 && !c->kv8)) && c->beam_K == 0 &&
                       (!c->kv8 || (KD(c, cw_cross8_is_mfma, CW_N_CTX) && !c->fuse_mlp)) && !((c->fuse_mlp || c->mlp_pair) && nb > 8);
     float *xin = c->dx, *xalt = c->dx1;
     // 17..64 rows without preparation launches (decfuse.hip: gemv_rows_kernel): the residual GEMVs own whole columns and leave
@@ -1228,14 +1235,16 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         }
         {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
-            if (frag) p.out_frag = (unsigned short*)c->d_xfrag2;
+            if (frag && !fuse) p.out_frag = (unsigned short*)c->d_xfrag2;   // the fused stage reads the f32 rows
             if (c->beam_K > 0) p.anc = c->d_anc;
             STG(DST_SELF_ATTN, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
         }
         }
         if (fuse) {
             const int TD = D / 16, TF = F / 16;
-            const int nt3 = c->stack_nt3 > 0 ? c->stack_nt3 : 1;   // column tiles per X1 block (3 * TD blocks at 1: 240 at large-v3)
+            // column tiles per X1 block (3 * TD blocks at 1: 240 at large-v3).  17..64 rows: two -- a block's 16 f32 rows are twice the bytes
+            // of a weight tile, and a pair of tiles shares them (64 rows, 4 groups: 11.2 us at one tile, 10.5 at two, 15.5 at three)
+            const int nt3 = c->stack_nt3 > 0 ? c->stack_nt3 : (nb > 16 ? 2 : 1);
             // rows <= 8: X1 and the cross-attention as ONE persistent launch (declayer.hip): the K/V rows are requested at kernel
             // entry and stream under the GEMV tile; qa / qb / the partial sums cross CUs as granules.  Bit-identical to the two launches.
             const bool dl = c->declayer && !c->kv8 && !c->fuse_mlp && nt3 == 1 && c->wpacked && nb <= 8 && 3 * TD <= c->n_cu &&
@@ -1286,6 +1295,16 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                     mp.x = xalt; mp.W1 = L.w1; mp.b1 = L.b1; mp.W2 = L.w2; mp.b2 = L.b2; mp.xio = xalt; mp.mid = c->d_xfrag2;
                     mp.flags = c->d_gflag; mp.epoch = c->d_epoch; mp.layer = l; mp.err = c->d_err; mp.Mb = nb; mp.D = D; mp.F = F;
                     STG(DST_MLP_CHAIN, KD(c, cw_launch_mlp_chain, mp, c->st));
+                } else if (frag) {
+                    // 17..64 rows: LayerNorm preparation + gemv_mt launches of the twelve-launch layer, on the alternating buffer
+                    {
+                        EpiParams ep = epi0(); ep.outf = c->dmid; ep.out = c->d_xfrag2; ep.bias = L.b1; ep.ldo = F;
+                        STG(DST_FC1, gemv_ln(c, EPI_GELU_FRAG, xalt, nb, D, L.w1, F, L.ln2_g, c->ln_folded ? nullptr : L.ln2_b, ep));
+                    }
+                    {
+                        EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.b2; ep.ldo = D;
+                        STG(DST_FC2, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag2, c->wpacked));
+                    }
                 } else {
                     // fc1 writes gelu(.) in the 16-bit type fc2 would round it to anyway (bit-identical): fc2's activation load halves
                     const bool mid16 = F > 1280 && c->mid16;

@@ -1402,13 +1402,14 @@ def test_persistent_decoder_layer_is_bit_identical(feature, rows, dt):
 
 
 @pytest.mark.parametrize("kv", [None, "fp8"])
-@pytest.mark.parametrize("rows", [3, 8, 12])
+@pytest.mark.parametrize("rows", [3, 8, 12, 17, 40, 64])
 def test_fused_decoder_stage_tracks_eight_launch_layer(rows, kv):
     """csrc/decfuse.hip: the out-projection + cross-query stage applied through the load-time product matrix (7 launches per
     layer) against the same engine with the stage switched off (CW_NO_FUSE6=1, 8 launches), large-v3 shapes on a 2+2-layer stack,
     teacher-forced, 1..16 rows (two or four rows per wave): logits within bf16 rounding of each other, same tokens, alignment
     rows within 2e-2 -- the two differ only in where the 16-bit roundings fall (x before the mean is subtracted, the product
-    W'q Wo rounded once).  kv = "fp8": the same over the e4m3 cross-attention cache, whose matrix-core kernel
+    W'q Wo rounded once).  17 / 40 / 64 rows (round 5): the stage in groups of 16 rows (gemv_stack_kernel's grid y, one statistics
+    plane per group) against the twelve-launch layer of the 17..64-row path.  kv = "fp8": the same over the e4m3 cross-attention cache, whose matrix-core kernel
     (attn_cross_mfma8_kernel<.., FUSED>) finishes the fused query like the bf16 kernel does."""
     import os
     g, v = syn.large_v3_geometry()
@@ -1417,7 +1418,7 @@ def test_fused_decoder_stage_tracks_eight_launch_layer(rows, kv):
     spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19)]
     W = syn.random_weights(g, seed=9)
     T = 10
-    clips = [syn.synth_audio(300 + i, 480000 - 15000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
+    clips = [syn.synth_audio(300 + i, 480000 - 15000 * (i % 12), ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
     rng = np.random.default_rng(2)
     ids = np.concatenate([[v.sot, v.lang_id("en"), v.transcribe], [v.timestamp_begin], rng.integers(300, 50000, T - 4)])
     forced = np.full((rows, T), -1, np.int32); forced[:, 3:] = ids[3:]
