@@ -597,7 +597,10 @@ def main():
                     per_step_ms = ms / calls
                 # streamed = what the kernels actually read: the fused out-projection / cross-query stage (csrc/decfuse.hip) adds a
                 # d x d product matrix per layer to the weight stream; the fraction is quoted on the ALGORITHMIC bytes
-                streamed = by + (g.dec_layers * g.d_model * g.d_model * 2.0 if (a.dtype in ("bf16", "f16") and B <= 16 and a.num_beams == 1 and not os.environ.get("CW_NO_FUSE6")) else 0.0)
+                # (rows <= 16, and 17..64 rows over the 16-bit cache: there the stage runs in groups of 16 rows, CW_NO_FUSE_ROWS=1 switches it off)
+                fused_stage = (a.dtype in ("bf16", "f16") and a.num_beams == 1 and not os.environ.get("CW_NO_FUSE6") and
+                               (B <= 16 or (B <= 64 and a.cross_kv == "bf16" and not os.environ.get("CW_NO_FUSE_ROWS"))))
+                streamed = by + (g.dec_layers * g.d_model * g.d_model * 2.0 if fused_stage else 0.0)
                 sr["decode_step"] = {"bound": "hbm", "algorithmic_bytes": by, "streamed_bytes": streamed, "ms_per_step": per_step_ms,
                                      "achieved_GBps": by / per_step_ms / 1e6, "frac_of_8TBps": by / per_step_ms / 1e6 / 8000.0,
                                      "launches_per_layer": (sum(1 for r_ in roof if 0 <= r_["stage"] < 100) if a.num_beams == 1 else (12 if B * a.num_beams > 16 else 8))}

@@ -1,4 +1,5 @@
-// Six-launch decoder layer of the 16-bit engine (batch rows <= 16): LayerNorm is linear up to two per-row scalars,
+// Six-launch decoder layer of the 16-bit engine (batch rows <= 16; 17..64 greedy rows run the same stage in groups of 16 rows,
+// gemv_stack_kernel's grid y, inside their ten-launch layer): LayerNorm is linear up to two per-row scalars,
 //     W LN(x) = rstd * (W' x - mean * (W' 1)) + b',      W' = W diag(gamma),  b' = b + W beta,
 // so a projection that follows "residual add -> LayerNorm" can be applied to the *summands* of the residual before
 // the statistics exist, and the statistics are applied by the consumer.  With x1 = x + Wo a + bo (self-attention
