@@ -1683,7 +1683,10 @@ __device__ inline long split3_e4m3(const float* x, int term) {
 // FUSED (fused out-projection / cross-query stage in front, decfuse.hip): wave 0 finishes the query exactly as
 // attn_cross_split_kernel<T, 1, true> does -- lane c = column c of the head, q = rstd(x1) (qa + qb - mean(x1) qw) + qbias from the
 // per-tile LayerNorm partial sums the producing GEMV left behind -- and hands the 16 columns of each lane over through LDS.
-template <int NSB, bool FUSED>
+// FUSED = 2 (17..64 rows behind the fused stage: thousands of blocks, a throughput problem): wave 0 alone fetches the six small
+// operands and finishes the query, the other waves pick the fragments up behind the block barrier like the plain kernel's -- same
+// arithmetic as FUSED = 1 (bit-identical), an eighth of its small loads.
+template <int NSB, int FUSED>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSplitParams p) {
     __shared__ float s_max[NSB * 8];
     __shared__ __attribute__((aligned(16))) float s_qf[FUSED ? 8 * 64 : 1];   // FUSED: a wave-private row each
@@ -1704,7 +1707,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
     // wave instruction) go out before the K / V rows so that they come back first
     float2 pt0 = make_float2(0.f, 0.f), pt1 = pt0;
     float qa1 = 0.f, qb1 = 0.f, qw1 = 0.f, qc1 = 0.f;
-    if (FUSED) {
+    if (FUSED == 1 || (FUSED == 2 && wave == 0)) {
         const float* ps = p.pstats + (size_t)(b >> 4) * p.n_pstats * 32;    // one [tiles][16][2] plane per group of 16 rows (gemv_stack_kernel)
         pt0 = *(const float2*)(ps + ((size_t)min(lane, p.n_pstats - 1) * 16 + (b & 15)) * 2);
         pt1 = *(const float2*)(ps + ((size_t)min(lane + 64, p.n_pstats - 1) * 16 + (b & 15)) * 2);
@@ -1733,7 +1736,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
     // LDS behind a barrier that their own K / V loads are in flight across
     long aq0, aq1;
     float c1;
-    if (FUSED) {
+    if (FUSED == 1) {
         __builtin_amdgcn_sched_barrier(0);                        // the K / V requests are out before the first wait
         const float inv_d = 1.0f / (float)D;
         const float ps1 = (lane < p.n_pstats ? pt0.x : 0.f) + (lane + 64 < p.n_pstats ? pt1.x : 0.f);
@@ -1764,7 +1767,19 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
     } else {
     if (wave == 0) {
         float qf[16];
-        const float* qp = p.q + (size_t)b * D + h * 64 + g * 16;
+        if (FUSED == 2) {                                          // the query row from the fused stage's summands, through wave 0's LDS row
+            const float inv_d = 1.0f / (float)D;
+            const float ps1 = (lane < p.n_pstats ? pt0.x : 0.f) + (lane + 64 < p.n_pstats ? pt1.x : 0.f);
+            const float ps2 = (lane < p.n_pstats ? pt0.y : 0.f) + (lane + 64 < p.n_pstats ? pt1.y : 0.f);
+            const float mean = wave_sum(ps1) * inv_d;
+            const float var = fmaxf(wave_sum(ps2) * inv_d - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            s_qf[lane] = ((qa1 + qb1) - mean * qw1) * rstd + qc1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const float* qp = FUSED == 2 ? s_qf + g * 16 : p.q + (size_t)b * D + h * 64 + g * 16;
         const float4 q0 = *(const float4*)qp, q1 = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
         qf[0] = q0.x; qf[1] = q0.y; qf[2] = q0.z; qf[3] = q0.w; qf[4] = q1.x; qf[5] = q1.y; qf[6] = q1.z; qf[7] = q1.w;
         qf[8] = q2.x; qf[9] = q2.y; qf[10] = q2.z; qf[11] = q2.w; qf[12] = q3.x; qf[13] = q3.y; qf[14] = q3.z; qf[15] = q3.w;
@@ -2048,16 +2063,17 @@ int cw_launch_attn_cross_split_fp8(const CrossSplitParams& p, hipStream_t st) {
         if (p.qa) {   // fused stage in front: the kernel finishes the query
             if (!p.qb || !p.qw || !p.qbias || !p.pstats || p.n_pstats < 1 || p.n_pstats > 128 || p.kv_div > 1) return CW_ERR_INVALID;
             if (ATT_NS % 2 == 0 && f == 2)
-                hipLaunchKernelGGL((attn_cross_mfma8_kernel<2, true>), dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
-            else hipLaunchKernelGGL((attn_cross_mfma8_kernel<1, true>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+                hipLaunchKernelGGL((attn_cross_mfma8_kernel<2, 1>), dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
+            else if (p.B > 16) hipLaunchKernelGGL((attn_cross_mfma8_kernel<1, 2>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+            else hipLaunchKernelGGL((attn_cross_mfma8_kernel<1, 1>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
             return CW_OK;
         }
         // (17..64 rows as persistent blocks with the next item's bytes in flight: bit-identical, measured slower -- 50.9 against 38.5 us
         // per launch at 64 rows; four independent blocks per CU are the better prefetch.  profiles/r05_e4m3_stream_kernel_rejected.txt,
         // the kernel is in commit 6a5babd)
         if (ATT_NS % 2 == 0 && f == 2)
-            hipLaunchKernelGGL((attn_cross_mfma8_kernel<2, false>), dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
-        else hipLaunchKernelGGL((attn_cross_mfma8_kernel<1, false>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
+            hipLaunchKernelGGL((attn_cross_mfma8_kernel<2, 0>), dim3(p.H, p.B, ATT_NS / 2), dim3(CROSS_THREADS), 0, st, p);
+        else hipLaunchKernelGGL((attn_cross_mfma8_kernel<1, 0>), dim3(p.H, p.B, ATT_NS), dim3(CROSS_THREADS), 0, st, p);
         return CW_OK;
     }
     if (p.qa) return CW_ERR_INVALID;                            // the VALU kernel takes a finished query

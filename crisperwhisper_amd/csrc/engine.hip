@@ -156,6 +156,7 @@ struct cw_ctx {
     hipGraphExec_t step_graph[65] = {};       // captured decode step (layers + logits + sampling) per batch size
     bool use_graph = true;
     bool fuse_rows = true;                    // fused out-projection / cross-query stage at 17..64 greedy rows (CW_NO_FUSE_ROWS=1: off)
+    bool fuse_rows8 = true;                   // ... over the e4m3 cache too (CW_NO_FUSE_ROWS8=1: that mode keeps its twelve launches)
     cw_gen_cfg gen{};
     bool gen_set = false;
     bool kv8 = false;                    // cross-attention reads the fp8 cache (cw_set_option "cross_kv_fp8")
@@ -391,6 +392,7 @@ static int create_impl(cw_ctx* c) {
 #endif
     c->use_graph = !sw.no_graph;
     c->fuse_rows = !sw.no_fuse_rows;
+    c->fuse_rows8 = !sw.no_fuse_rows8;
     c->fold_enabled = !sw.no_ln_fold;
     c->fuse6_enabled = !sw.no_fuse6;
     c->rows_ln_enabled = sw.rows_ln;
@@ -1135,9 +1137,9 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     // 17..64 greedy rows (round 5): the same stage in groups of 16 rows (gemv_stack_kernel's grid y) replaces out-projection,
     // LayerNorm preparation and query projection -- three of the layer's twelve launches -- by one; the rest of the layer keeps its
     // preparation + gemv_mt launches, on the alternating buffers.  CW_NO_FUSE_ROWS=1: the twelve launches (A/B).  Batch 64: decode
-    // 4.43 -> 4.28 ms per token step, 64 / 64 clips; over the e4m3 cache it measured flat (3.418 -> 3.411: the fused query costs its
-    // cross-attention kernel -- every wave of 7680 blocks finishes the query -- what the stage saves), so that mode keeps its launches
-    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && (nb <= 16 || (c->fuse_rows && nb <= 64 && !c->kv8)) && c->beam_K == 0 &&
+    // 4.43 -> 4.28 ms per token step, 64 / 64 clips; over the e4m3 cache 3.47 -> 3.41 once the cross-attention kernel lets wave 0 alone
+    // finish the query (attn_cross_mfma8_kernel<1, 2>; every wave doing it, as at <= 16 rows, measured flat).  CW_NO_FUSE_ROWS8=1: A/B
+    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && (nb <= 16 || (c->fuse_rows && nb <= 64 && (!c->kv8 || c->fuse_rows8))) && c->beam_K == 0 &&
                       (!c->kv8 || (KD(c, cw_cross8_is_mfma, CW_N_CTX) && !c->fuse_mlp)) && !((c->fuse_mlp || c->mlp_pair) && nb > 8);
     float *xin = c->dx, *xalt = c->dx1;
     // 17..64 rows without preparation launches (decfuse.hip: gemv_rows_kernel): the residual GEMVs own whole columns and leave

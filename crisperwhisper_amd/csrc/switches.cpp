@@ -25,6 +25,7 @@ Switches read_switches() {
     s.no_qkv_self = flag("CW_NO_QKV_SELF");
     s.mlp_chain = flag("CW_MLP_CHAIN");
     s.no_fuse_rows = flag("CW_NO_FUSE_ROWS");
+    s.no_fuse_rows8 = flag("CW_NO_FUSE_ROWS8");
     s.skinny = num("CW_SKINNY", 0);
     s.prefetch = num("CW_PREFETCH", 0);
     s.prefetch_wide = num("CW_PREFETCH_WIDE", 0);
