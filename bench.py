@@ -563,7 +563,8 @@ def main():
     roof = []
     if a.num_beams == 1:
         for st in eng.time_decode_stages(B, a.kernel_iters):
-            roof.append({"kernel": st["kernel"], "stage": st["stage"], "avg_ms": st["avg_ms"], "algo_bytes": st["algo_bytes"], "per_step": g.dec_layers})
+            roof.append({"kernel": st["kernel"], "stage": st["stage"], "avg_ms": st["avg_ms"], "algo_bytes": st["algo_bytes"], "per_step": g.dec_layers,
+                         "launches": st.get("launches", 1)})
         ms, by = eng.time_kernel(7, B, a.kernel_iters)
         roof.append({"kernel": "LayerNorm + logits projection (gemv_loop_kernel)", "stage": 100, "avg_ms": ms, "algo_bytes": by, "per_step": 1})
     else:   # beam rows: the two kernels of the greedy layer that dominate it (the beam layer's own launches are in the rocprofv3 table)
@@ -679,13 +680,16 @@ def main():
                     per_step_ms = ms / calls
                 # streamed = what the kernels actually read: the fused out-projection / cross-query stage (csrc/decfuse.hip) adds a
                 # d x d product matrix per layer to the weight stream; the fraction is quoted on the ALGORITHMIC bytes
-                # (rows <= 16, and 17..64 rows over the 16-bit cache: there the stage runs in groups of 16 rows, CW_NO_FUSE_ROWS=1 switches it off)
+                # (rows <= 16, and 17..64 rows over either cache: there the stage runs in groups of 16 rows; CW_NO_FUSE_ROWS=1 / CW_NO_FUSE_ROWS8=1 switch it off)
+                # (engine.hip decode_step: `fuse`)
                 fused_stage = (a.dtype in ("bf16", "f16") and a.num_beams == 1 and not os.environ.get("CW_NO_FUSE6") and
-                               (B <= 16 or (B <= 64 and a.cross_kv == "bf16" and not os.environ.get("CW_NO_FUSE_ROWS"))))
+                               (B <= 16 or (B <= 64 and not os.environ.get("CW_NO_FUSE_ROWS") and
+                                            (a.cross_kv != "fp8" or not os.environ.get("CW_NO_FUSE_ROWS8")))))
                 streamed = by + (g.dec_layers * g.d_model * g.d_model * 2.0 if fused_stage else 0.0)
                 sr["decode_step"] = {"bound": "hbm", "algorithmic_bytes": by, "streamed_bytes": streamed, "ms_per_step": per_step_ms,
                                      "achieved_GBps": by / per_step_ms / 1e6, "frac_of_8TBps": by / per_step_ms / 1e6 / 8000.0,
-                                     "launches_per_layer": (sum(1 for r_ in roof if 0 <= r_["stage"] < 100) if a.num_beams == 1 else (12 if B * a.num_beams > 16 else 8))}
+                                     # kernel launches (a 17..64-row LayerNorm / combining GEMV is a preparation launch + the GEMV: counted as two)
+                                     "launches_per_layer": (sum(r_.get("launches", 1) for r_ in roof if 0 <= r_["stage"] < 100) if a.num_beams == 1 else (12 if B * a.num_beams > 16 else 8))}
                 if a.num_beams > 1:
                     sr["decode_step"]["rows"] = B * a.num_beams
                 line["roofline"]["step_frac"] = sr["decode_step"]["frac_of_8TBps"]

@@ -107,6 +107,8 @@ _SIGS = {
     "cw_time_decode_stage": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "cw_decode_stage_name": (C.c_char_p, [_I]),
     "cw_handoff_fallbacks": (_I, [_P]),
+    "cw_handoff_resumes": (_I, [_P]),
+    "cw_decode_stage_launches": (_I, [_P, _I]),
 }
 
 _lib = None

@@ -117,14 +117,16 @@ def decode_flac(data: bytes):
     limit_s = _max_decoded_seconds()
     max_frames = limit_s * min(max(int(sr.value), 1), 48000)
     if total.value > max_frames:
-        raise ValueError(f"FLAC stream declares {total.value} sample frames: more than the {limit_s} s this path accepts (raise CW_MAX_AUDIO_SECONDS)")
+        raise ValueError(f"FLAC stream declares {total.value} sample frames: more than the {max_frames} frames this path accepts "
+                         f"(CW_MAX_AUDIO_SECONDS = {limit_s} s x min(sample rate {sr.value}, 48000) Hz; raise CW_MAX_AUDIO_SECONDS)")
     cap = int(total.value)
     if cap <= 0:
         if lib.cw_flac_decode(ptr, len(buf), None, max_frames, C.byref(n)) != 0:
             raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())
         cap = int(n.value)
         if cap > max_frames:
-            raise ValueError(f"FLAC stream decodes to {cap} sample frames: more than the {limit_s} s this path accepts (raise CW_MAX_AUDIO_SECONDS)")
+            raise ValueError(f"FLAC stream decodes to {cap} sample frames: more than the {max_frames} frames this path accepts "
+                             f"(CW_MAX_AUDIO_SECONDS = {limit_s} s x min(sample rate {sr.value}, 48000) Hz; raise CW_MAX_AUDIO_SECONDS)")
     out = np.empty((cap, int(ch.value)), dtype=np.int32)
     if lib.cw_flac_decode(ptr, len(buf), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)) != 0:
         raise ValueError("malformed FLAC stream: " + (lib.cw_flac_last_error() or b"?").decode())

@@ -90,6 +90,7 @@ struct DlRaw8 {   // 8 consecutive 16-bit elements held raw so that the load is 
     __device__ inline void cvt(float* o) const { h16_unpack8(a, o); }
 };
 
+#ifdef CW_EXPERIMENTS   // stage A: measured slower than its two launches (profiles/r05_declayer_phases.txt); A/B builds only (CW_DECLAYER=1)
 // ---------------------------------------------------------------------------------------------------
 // stage A: [W'q_c ; W'q_c Wo ; Wo] tile (chain waves) -> granules -> cross-attention items (all waves)
 // ---------------------------------------------------------------------------------------------------
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
         int npoll = 0; (void)npoll;
 #pragma unroll 1
         for (int spins = 0; !ready; ++spins) {
-            if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }
+            if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicCAS(p.err, 0, 1); break; }
             va = dl_gran_ld(ga); vb = dl_gran_ld(gb);
             v00 = dl_gran_ld(g0); v01 = dl_gran_ld(g0 + 1);
             v10 = dl_gran_ld(g1); v11 = dl_gran_ld(g1 + 1);
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(DL_THREADS) void dec_layer_a_kernel(DecLayerParams 
     dl_cross_items(p, it, kr, vr, grp, gw, gt, lane, c_q, c_smax, c_redl, c_red);
 }
 #undef DL_KV_LOAD
+#endif  // CW_EXPERIMENTS (stage A)
 
 // ---------------------------------------------------------------------------------------------------
 // q/k/v projection + self-attention in ONE launch (rows <= 8): grid = 3 D / 16 tiles, 512 threads.
@@ -654,9 +656,19 @@ __global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
         const dl_u64_t* gkp = p.gkv + ((size_t)(lane >> 5) * 16 + ib) * (K >> 1) + ih * 32 + (lane & 31);
         dl_u64_t vq = 0, vk = 0;
         bool ready = false;
+        // `err` holds 1 + the decoder position of the FIRST forward in which a wait gave up (0: none): forwards run one after the
+        // other and the first writer wins, so everything before that position is good and the engine resumes there on the
+        // launch-per-stage kernels (engine.hip: decode_once).  Once it is set every later wait gives up after at most 256 polls
+        // instead of DL_SPIN_LIMIT: those forwards are discarded anyway.
+        const int give_up_tag = p.pos[0] + 1;
+        const bool forced_fail = p.fail_pos >= 0 && p.pos[0] == p.fail_pos && p.layer == 0;   // test hook (cw_test_set_option "handoff_fail_pos")
 #pragma unroll 1
         for (int spins = 0; !ready; ++spins) {
-            if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }
+            if (forced_fail || spins > DL_SPIN_LIMIT || ((spins & 255) == 255 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (lane == 0) atomicCAS(p.err, 0, give_up_tag);
+                if (forced_fail) { vq = 0x3f800000ull; vk = 0; }     // the garbage a starved poll would leave
+                break;
+            }
             vq = dl_gran_ld(gqp); vk = dl_gran_ld(gkp);
             ready = __all((unsigned)(vq >> 32) == tag && (unsigned)(vk >> 32) == tag);
         }
@@ -818,10 +830,19 @@ __global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
     }
 }
 
+// blocks of qkv_self_kernel a CU holds at once (LDS and thread limits); the engine enables the kernel only where the whole grid --
+// 3 D / 16 blocks that wait for each other -- is resident at once on an otherwise idle chip
+int cw_qkv_self_blocks_per_cu(int D, int cap) {
+    const size_t lds = (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 64) * 4 + 2 * 64 * 2 + ((size_t)((cap + 63) & ~63) + QS_GROUPS * 64 + 64) * 4;
+    const int by_lds = (int)((size_t)160 * 1024 / lds), by_threads = 2048 / QS_THREADS;
+    return by_lds < by_threads ? by_lds : by_threads;
+}
+
 int cw_launch_qkv_self(const QkvSelfParams& p, hipStream_t st) {
     const int D = p.D;
     if (p.Mb < 1 || p.Mb > 8 || D % 128 || D > 1280 || p.H * 64 != D || p.cap < 1 || p.cap > 512) return CW_ERR_INVALID;
     if (p.Mb * p.H > 3 * (D / 16) || !p.gq || !p.gkv || !p.epoch || !p.err || !p.W || !p.x || !p.pos) return CW_ERR_INVALID;
+    if (p.layer < 0 || p.layer >= 64) return CW_ERR_INVALID;          // the granule tag is (epoch << 6) | layer
     const size_t lds = (size_t)16 * (D + 8) * 2 + (size_t)(4 * 4 * 64 + 64) * 4 + 2 * 64 * 2 +
                        ((size_t)((p.cap + 63) & ~63) + QS_GROUPS * 64 + 64) * 4;
     const dim3 grid(3 * (D / 16));
@@ -838,6 +859,7 @@ int cw_launch_qkv_self(const QkvSelfParams& p, hipStream_t st) {
     return CW_OK;
 }
 
+#ifdef CW_EXPERIMENTS   // fc1 + fc2 in one launch: measured slower (profiles/r05_mlp_chain_phases.txt); A/B builds only (CW_MLP_CHAIN=1)
 // ---------------------------------------------------------------------------------------------------
 // fc1 + fc2 in ONE launch (rows <= 8): grid = F / 32 fc1 blocks, then (D / 32) x KS fc2 blocks, 256 threads.
 //   fc1 block j:  LayerNorm + two 16-column tiles + GELU of gemv2_bf16_kernel<EPI_GELU, 2, false, false, NS1, PL1, 2> (gemm.hip),
@@ -1028,7 +1050,7 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainParams p) {
             bool ready = false;
 #pragma unroll 1
             for (int spins = 0; !ready; ++spins) {
-                if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicExch(p.err, 1); break; }
+                if (spins > DL_SPIN_LIMIT) { if (lane == 0) atomicCAS(p.err, 0, 1); break; }
                 dl_u64_t f[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) f[q] = dl_gran_ld(p.flags + min(lane + 64 * q, n1 - 1));
@@ -1160,5 +1182,12 @@ int cw_launch_dec_layer(const DecLayerParams& p, int n_cu, hipStream_t st) {
 #undef DL_LAUNCH
     return CW_OK;
 }
+
+#else   // default build: the two measured-slower persistent stages are not compiled; the engine never selects them (cw_create refuses their switches)
+bool cw_mlp_chain_ok(int, int, int) { return false; }
+int cw_launch_mlp_chain(const MlpChainParams&, hipStream_t) { return CW_ERR_INVALID; }
+size_t cw_dec_layer_lds(int) { return (size_t)1 << 30; }
+int cw_launch_dec_layer(const DecLayerParams&, int, hipStream_t) { return CW_ERR_INVALID; }
+#endif  // CW_EXPERIMENTS (mlp_chain_kernel, stage A launcher)
 
 }  // namespace CW_NS

@@ -98,7 +98,9 @@ struct cw_ctx {
     bool mlp_pair_fence = false;    // CW_MLP_PAIR_FENCE=1: round-3 hand-over (agent-scope acquire fence behind the group barrier)
     bool mlp_pair = false;          // CW_MLP_PAIR=1: fc1 + fc2 in one launch with an in-kernel group barrier (A/B: 23 us against 12.8 for two launches)
     unsigned int* d_bar = nullptr; int* d_err = nullptr;   // group barriers of mlp_pair_kernel; "a block gave up waiting" flag
-    int handoff_fallbacks = 0;      // times a call was repeated on the launch-per-stage path because an in-launch hand-off gave up
+    int handoff_fallbacks = 0;      // times this context left the in-launch hand-offs for the launch-per-stage path because a wait gave up
+    int handoff_resumes = 0;        // ... of which the decode call resumed at the failed position instead of starting over
+    int fail_pos = -1;              // test hook (option "handoff_fail_pos"): qkv_self_kernel gives up at this decoder position
     // persistent decoder-layer kernel (declayer.hip), rows <= 8: granule buffers, the epoch counter their tags carry, CU count
     bool declayer = false;          // CW_DECLAYER=1: stage A of declayer.hip (fused stage + cross-attention in one persistent launch; bit-identical,
                                     // measured SLOWER: 22-24 us against 18.4 for the two launches -- A/B and differential test only)
@@ -191,6 +193,7 @@ struct cw_ctx {
     // cw_time_decode_stage: one launch (stage_sel) of one layer (layer_sel) of decode_step; -1 = everything (the step itself)
     int stage_sel = -1, layer_sel = -1, stage_count = 0;
     int stage_kind[CW_MAX_DEC_STAGES] = {};
+    int stage_launches[CW_MAX_DEC_STAGES] = {};   // kernel launches behind each stage (2 where gemv_prep_kernel precedes gemv_mt_kernel)
     float stage_ms[CW_N_STAGES] = {};
     int stage_calls[CW_N_STAGES] = {};
 };
@@ -376,7 +379,7 @@ static int create_impl(cw_ctx* c) {
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[0], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_pf[1], hipEventDisableTiming));
 #endif
-    HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 1024 * sizeof(int), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_nunf, 2 * 1024 * sizeof(int), hipHostMallocDefault));   // [step]{running rows, hand-off failure word}
     if (d.dtype != CW_DTYPE_F32 && d.dtype != CW_DTYPE_BF16 && d.dtype != CW_DTYPE_F16) return fail(c, CW_ERR_INVALID, "unknown dtype %d", d.dtype);
     c->f16 = d.dtype == CW_DTYPE_F16;
     c->bf16 = d.dtype == CW_DTYPE_BF16 || c->f16;
@@ -384,7 +387,8 @@ static int create_impl(cw_ctx* c) {
 #ifndef CW_EXPERIMENTS
     {
         const struct { const char* name; bool set; } rejected[] = {{"CW_ROWS_LN", sw.rows_ln}, {"CW_FUSE_MLP", sw.fuse_mlp}, {"CW_MLP_PAIR", sw.mlp_pair},
-                                                                   {"CW_SKINNY", sw.skinny != 0}, {"CW_PREFETCH", sw.prefetch != 0}};
+                                                                   {"CW_SKINNY", sw.skinny != 0}, {"CW_PREFETCH", sw.prefetch != 0},
+                                                                   {"CW_DECLAYER", sw.declayer}, {"CW_MLP_CHAIN", sw.mlp_chain}};
         for (const auto& r : rejected)
             if (r.set)
                 return fail(c, CW_ERR_INVALID, "%s selects a measured-and-rejected kernel variant that is not in this build: make EXTRA=-DCW_EXPERIMENTS", r.name);
@@ -552,7 +556,7 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_qa, (size_t)Bm * D * 4)); CWCHK(c, dmalloc(c, &c->d_qb, (size_t)Bm * D * 4));
     CWCHK(c, dmalloc(c, &c->d_u1, (size_t)Bm * F * 4)); CWCHK(c, dmalloc(c, &c->d_pstats, (size_t)128 * 64 * 2 * 4));   // [group of 16 rows 4][tile <= 128][16][2]
     CWCHK(c, dmalloc(c, &c->d_rstats, (size_t)((D > F ? D : F) / 16 + 1) * 64 * 2 * 4));
-    CWCHK(c, dmalloc(c, &c->d_bar, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_err, 4));
+    CWCHK(c, dmalloc(c, &c->d_bar, 64 * 4));
     {   // declayer.hip: granules are valid by tag only (never cleared); epoch 0 is never used
         CWCHK(c, dmalloc(c, &c->d_gq, (size_t)2 * 16 * D * 8)); CWCHK(c, dmalloc(c, &c->d_gps, (size_t)(D / 16) * 16 * 2 * 8));
         CWCHK(c, dmalloc(c, &c->d_gq2, (size_t)16 * D * 8)); CWCHK(c, dmalloc(c, &c->d_gkv, (size_t)2 * 16 * (D / 2) * 8));
@@ -578,7 +582,8 @@ static int create_impl(cw_ctx* c) {
     CWCHK(c, dmalloc(c, &c->d_ids, (size_t)Bm * TGT * 4)); CWCHK(c, dmalloc(c, &c->d_forced, (size_t)Bm * TGT * 4));
     CWCHK(c, dmalloc(c, &c->d_argmax, (size_t)Bm * TGT * 4));
     CWCHK(c, dmalloc(c, &c->d_last_ts, Bm * 4)); CWCHK(c, dmalloc(c, &c->d_finished, Bm * 4));
-    CWCHK(c, dmalloc(c, &c->d_nunf, 4));
+    CWCHK(c, dmalloc(c, &c->d_nunf, 8));   // {rows still running, hand-off failure word}: one 8-byte copy per step brings both to the host
+    c->d_err = c->d_nunf + 1;
 #ifdef CW_EXPERIMENTS
     CWCHK(c, dmalloc(c, &c->d_pf_sink, 4));
 #endif
@@ -1139,7 +1144,10 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     // preparation + gemv_mt launches, on the alternating buffers.  CW_NO_FUSE_ROWS=1: the twelve launches (A/B).  Batch 64: decode
     // 4.43 -> 4.28 ms per token step, 64 / 64 clips; over the e4m3 cache 3.47 -> 3.41 once the cross-attention kernel lets wave 0 alone
     // finish the query (attn_cross_mfma8_kernel<1, 2>; every wave doing it, as at <= 16 rows, measured flat).  CW_NO_FUSE_ROWS8=1: A/B
-    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && (nb <= 16 || (c->fuse_rows && nb <= 64 && (!c->kv8 || c->fuse_rows8))) && c->beam_K == 0 &&
+    // (the rejected 17..64-row A/B variants of -DCW_EXPERIMENTS builds -- rows path, skinny GEMMs, full-key cross-attention -- keep their
+    // own twelve / nine launches: they read c->dx and d_xfrag, which the fused stage's alternating buffers would leave stale)
+    const bool ab17 = nb > 16 && (c->rows_ln_enabled || c->skinny_mode != 0);
+    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && !ab17 && (nb <= 16 || (c->fuse_rows && nb <= 64 && (!c->kv8 || c->fuse_rows8))) && c->beam_K == 0 &&
                       (!c->kv8 || (KD(c, cw_cross8_is_mfma, CW_N_CTX) && !c->fuse_mlp)) && !((c->fuse_mlp || c->mlp_pair) && nb > 8);
     float *xin = c->dx, *xalt = c->dx1;
     // 17..64 rows without preparation launches (decfuse.hip: gemv_rows_kernel): the residual GEMVs own whole columns and leave
@@ -1200,7 +1208,11 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
 #define STG(kind, call)                                                                             \
     do {                                                                                            \
         if (c->stage_sel < 0 || c->stage_sel == stage_no) CWCHK(c, call);                           \
-        if (stage_no < CW_MAX_DEC_STAGES) c->stage_kind[stage_no] = (kind);                         \
+        if (stage_no < CW_MAX_DEC_STAGES) {                                                         \
+            c->stage_kind[stage_no] = (kind);                                                       \
+            /* 17..64 rows: a LayerNorm / combining GEMV is gemv_prep_kernel + gemv_mt_kernel */    \
+            c->stage_launches[stage_no] = 1 + ((frag && !skinny && !rows && !xfull && ((kind) == DST_QKV || (kind) == DST_CROSS_Q || (kind) == DST_FC1 || (kind) == DST_CROSS_O)) ? 1 : 0); \
+        }                                                                                           \
         c->stage_count = ++stage_no;                                                                \
     } while (0)
     const int l_lo = c->layer_sel >= 0 ? c->layer_sel : 0, l_hi = c->layer_sel >= 0 ? c->layer_sel + 1 : c->d.dec_layers;
@@ -1214,12 +1226,14 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         }
         // rows <= 8, 16-bit engines: LN + q/k/v projection + self-attention as ONE launch (declayer.hip: qkv_self_kernel; the tiles
         // reach the attention blocks as granules, the history rows of the cache are requested at kernel entry); bit-identical
-        const bool qs = c->qkv_self && c->bf16 && c->ln_folded && c->wpacked && nb <= 8 && c->beam_K == 0 && D <= 1280 && nb * H <= 3 * (D / 16) && TGT <= 512;
+        // (its 3 D / 16 blocks wait for each other: only where the whole grid is resident at once on this part; layer < 64: granule tag)
+        const bool qs = c->qkv_self && c->bf16 && c->ln_folded && c->wpacked && nb <= 8 && c->beam_K == 0 && D <= 1280 && nb * H <= 3 * (D / 16) && TGT <= 512 &&
+                        c->d.dec_layers <= 64 && 3 * (D / 16) <= c->n_cu * KD(c, cw_qkv_self_blocks_per_cu, D, TGT);
         if (qs) {
             QkvSelfParams qp;
             memset(&qp, 0, sizeof(qp));
             qp.x = xin; qp.W = L.wqkv; qp.bias = L.bqkv; qp.sk = L.sk; qp.sv = L.sv; qp.cap = TGT; qp.pos = c->d_pos; qp.out = c->dattn;
-            qp.gq = c->d_gq2; qp.gkv = c->d_gkv; qp.epoch = c->d_epoch; qp.layer = l; qp.err = c->d_err; qp.Mb = nb; qp.D = D; qp.H = H;
+            qp.gq = c->d_gq2; qp.gkv = c->d_gkv; qp.epoch = c->d_epoch; qp.layer = l; qp.err = c->d_err; qp.Mb = nb; qp.D = D; qp.H = H; qp.fail_pos = c->fail_pos;
             const int dbg = cw_sw::cw_switches().qkv_self_dbg;   // 1: tiles fused, attention by attn_decode_kernel behind it (bisecting aid)
             if (dbg) { qp.q_plain = c->dq; qp.no_attn = 1; }
             STG(DST_QKV_SELF, KD(c, cw_launch_qkv_self, qp, c->st));
@@ -1484,11 +1498,12 @@ static int run_step(cw_ctx* c, int nb) {
 #define CW_HANDOFF_RETRY 0x7e57
 static void drop_step_graphs(cw_ctx* c);
 static bool handoffs_on(const cw_ctx* c) { return c->qkv_self || c->mlp_chain || c->declayer || c->mlp_pair; }
-static int handoff_gave_up(cw_ctx* c, bool* gave_up) {
+static int handoff_gave_up(cw_ctx* c, bool* gave_up, int* word = nullptr) {
     int e = 0;
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipMemcpy(&e, c->d_err, 4, hipMemcpyDeviceToHost));
     *gave_up = e != 0;
+    if (word) *word = e;
     if (e) { HIPCHK(c, hipMemset(c->d_err, 0, 4)); HIPCHK(c, hipMemset(c->d_bar, 0, 64 * 4)); }
     return CW_OK;
 }
@@ -1502,6 +1517,7 @@ static int handoffs_off(cw_ctx* c, const char* where) {
     return CW_OK;
 }
 int32_t cw_handoff_fallbacks(cw_ctx* c) { return c->handoff_fallbacks; }
+int32_t cw_handoff_resumes(cw_ctx* c) { return c->handoff_resumes; }
 
 static int decode_once(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt, int32_t max_length,
                        int32_t min_new_tokens, const int32_t* forced, int32_t* sequences, int32_t* lengths,
@@ -1558,36 +1574,68 @@ static int decode_once(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_p
     // *read* after step s+1 has been queued (one step of lag, so the GPU never waits for the host; at most one
     // harmless extra step runs: it only writes cache / alignment rows beyond the ones that are used), and it
     // is not even copied while no row can finish yet (fewer than min_new_tokens generated: eos is masked).
+    // The same 8-byte copy carries the hand-off failure word (d_err sits behind d_nunf): a wait that gave up (GPU shared
+    // with other work) is seen one step later, and the call RESUMES at the position of the first failed forward on the
+    // launch-per-stage kernels instead of running to the end on garbage and starting over.
     int first_copied = -1;
     for (;;) {
-        // forward at position t-1, logits, fused processors + argmax -> ids[t], x for position t, pos := t
-        CWCHK(c, run_step(c, nb));
-        if (c->logits_capture && step < c->logits_capture_steps)
-            HIPCHK(c, hipMemcpy2DAsync(c->logits_capture + (size_t)step * nb * V, (size_t)V * 4, c->dlogits, (size_t)c->Vpad * 4, (size_t)V * 4, nb, hipMemcpyDeviceToHost, c->st));
-        ++t;                               // sequence length is now t
-        const bool can_finish = (t - n_prompt) >= min_new_tokens;
-        if (can_finish) {
-            if (first_copied < 0) first_copied = step;
-            c->h_nunf[step] = 1;
-            HIPCHK(c, hipMemcpyAsync(c->h_nunf + step, c->d_nunf, 4, hipMemcpyDeviceToHost, c->st));
-            HIPCHK(c, hipEventRecord(c->ev_step[step & 1], c->st));
+        int gave_up_word = 0;
+        for (;;) {
+            // forward at position t-1, logits, fused processors + argmax -> ids[t], x for position t, pos := t
+            CWCHK(c, run_step(c, nb));
+            if (c->logits_capture && step < c->logits_capture_steps)
+                HIPCHK(c, hipMemcpy2DAsync(c->logits_capture + (size_t)step * nb * V, (size_t)V * 4, c->dlogits, (size_t)c->Vpad * 4, (size_t)V * 4, nb, hipMemcpyDeviceToHost, c->st));
+            ++t;                               // sequence length is now t
+            const bool can_finish = (t - n_prompt) >= min_new_tokens;
+            if (can_finish) {
+                if (first_copied < 0) first_copied = step;
+                c->h_nunf[2 * step] = 1; c->h_nunf[2 * step + 1] = 0;
+                HIPCHK(c, hipMemcpyAsync(c->h_nunf + 2 * step, c->d_nunf, 8, hipMemcpyDeviceToHost, c->st));
+                HIPCHK(c, hipEventRecord(c->ev_step[step & 1], c->st));
+            }
+            ++step;
+            if (t >= max_length) break;
+            if (first_copied >= 0 && step - 2 >= first_copied) {   // counter of the step before the one just queued
+                HIPCHK(c, hipEventSynchronize(c->ev_step[(step - 2) & 1]));
+                if (c->h_nunf[2 * (step - 2) + 1] != 0) { gave_up_word = c->h_nunf[2 * (step - 2) + 1]; break; }
+                if (c->h_nunf[2 * (step - 2)] == 0) break;
+            }
         }
-        ++step;
-        if (t >= max_length) break;
-        if (first_copied >= 0 && step - 2 >= first_copied) {   // counter of the step before the one just queued
-            HIPCHK(c, hipEventSynchronize(c->ev_step[(step - 2) & 1]));
-            if (c->h_nunf[step - 2] == 0) break;
+        HIPCHK(c, hipStreamSynchronize(c->st));
+        {   // a block of a launch with an in-kernel wait gave up (GPU shared with other work)
+            bool gave_up = false;
+            int word = 0;
+            CWCHK(c, handoff_gave_up(c, &gave_up, &word));
+            if (gave_up) gave_up_word = word;
         }
-    }
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    {   // a block of a launch with an in-kernel wait gave up (GPU shared with other work): cw_decode repeats the call
-        bool gave_up = false;
-        CWCHK(c, handoff_gave_up(c, &gave_up));
-        if (gave_up) { tm.stop(); return CW_HANDOFF_RETRY; }
+        if (!gave_up_word) break;
+        // word = 1 + decoder position P of the first forward that ran on a missed hand-off: ids[0 .. P], the cache rows and alignment
+        // rows below P are good.  Resume there when the sampler's state can be rebuilt from the ids alone (no log-probability sums, no
+        // logits capture, P inside the generated part); otherwise cw_decode repeats the whole call.
+        const int P = gave_up_word - 1;
+        if (P < n_prompt || P + 1 >= max_length || c->score_tokens || c->logits_capture) { tm.stop(); return CW_HANDOFF_RETRY; }
+        CWCHK(c, handoffs_off(c, "decode"));
+        HIPCHK(c, hipMemcpy(ids.data(), c->d_ids, ids.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<int> fin(nb), lts(nb);
+        const int tb = c->gen.no_timestamps_token_id + 1;
+        for (int b = 0; b < nb; ++b) {                                  // sample_kernel's per-row state after it wrote ids[P]
+            fin[b] = 0; lts[b] = -1;
+            for (int k = n_prompt; k <= P; ++k) {
+                const int tok = ids[(size_t)b * TGT + k];
+                if (!fin[b] && tok >= tb) lts[b] = tok;
+                if (tok == c->gen.eos_token_id) fin[b] = 1;
+            }
+        }
+        HIPCHK(c, hipMemcpy(c->d_finished, fin.data(), nb * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_last_ts, lts.data(), nb * 4, hipMemcpyHostToDevice));
+        CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, P, nb, c->st, c->d_epoch));
+        CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, P, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
+        t = P + 1; step = t - n_prompt; first_copied = -1;
+        ++c->handoff_resumes;
     }
     if (first_copied >= 0)                 // true end = first step after which no row was running
         for (int s2 = first_copied; s2 < step; ++s2)
-            if (c->h_nunf[s2] == 0) { t = n_prompt + s2 + 1; break; }
+            if (c->h_nunf[2 * s2] == 0) { t = n_prompt + s2 + 1; break; }
     KCHK(c);
     tm.stop();
     HIPCHK(c, hipMemcpy(ids.data(), c->d_ids, ids.size() * 4, hipMemcpyDeviceToHost));
@@ -2248,6 +2296,11 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
     if ((!strcmp(name, "rows_ln") || !strcmp(name, "skinny")) && value != 0)
         return fail(c, CW_ERR_INVALID, "option %s selects a measured-and-rejected kernel variant that is not in this build (make EXTRA=-DCW_EXPERIMENTS)", name);
 #endif
+    if (!strcmp(name, "handoff_fail_pos")) {   // test hook: the in-launch hand-off of qkv_self_kernel gives up at this decoder position (-1: never)
+        c->fail_pos = value;
+        for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // kernel arguments are baked into the graphs
+        return CW_OK;
+    }
     if (!strcmp(name, "rows_ln")) {   // 17..64-row decode: 0 = preparation launch in front of every GEMV (A/B, differential tests)
         c->rows_ln_enabled = value != 0;
         for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // graphs hold the kernel choice
@@ -2750,6 +2803,10 @@ int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, floa
     return CW_OK;
 }
 
+// kernel launches behind stage `stage` of the layer as last enumerated by cw_time_decode_stage (17..64 rows: 2 where a preparation launch precedes the GEMV)
+int32_t cw_decode_stage_launches(cw_ctx* c, int32_t stage) {
+    return (stage >= 0 && stage < c->stage_count && stage < CW_MAX_DEC_STAGES) ? c->stage_launches[stage] : 0;
+}
 const char* cw_decode_stage_name(int32_t kind) { return (kind >= 0 && kind < DST_N) ? kDecStageName[kind] : "?"; }
 
 // One launch of the decoder layer AS decode_step ISSUES IT at nb rows (same code path, same arguments), `iters` times back to back,
@@ -2759,8 +2816,13 @@ int32_t cw_time_decode_stage(cw_ctx* c, int32_t nb, int32_t stage, int32_t iters
                              int32_t* n_stages) {
     if (nb < 1 || nb > c->Bm || iters < 1 || stage < -1 || stage >= CW_MAX_DEC_STAGES) return fail(c, CW_ERR_INVALID, "time_decode_stage: bad args");
     if (c->beam_K > 0) return fail(c, CW_ERR_STATE, "time_decode_stage: greedy rows only");
+    // the launches run for real at decoder position 64: they append to the self-attention cache and write alignment rows there
+    if (c->d.max_target_positions <= 65) return fail(c, CW_ERR_INVALID, "time_decode_stage: needs max_target_positions > 65 (has %d)", c->d.max_target_positions);
+    CWCHK(c, cw_check_weights(c));
+    if (nb > c->nb_encoded) return fail(c, CW_ERR_STATE, "time_decode_stage: nb=%d but %d windows encoded (the cross-attention reads their K/V)", nb, c->nb_encoded);
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, NL = c->d.dec_layers;
-    struct Restore { cw_ctx* c; ~Restore() { c->stage_sel = -1; c->layer_sel = -1; } } restore{c};
+    // a hand-off that gave up while timing (shared GPU) must not send the next cw_decode to the fallback path: drain and clear
+    struct Restore { cw_ctx* c; ~Restore() { c->stage_sel = -1; c->layer_sel = -1; (void)hipStreamSynchronize(c->st); (void)hipMemset(c->d_err, 0, 4); } } restore{c};
     CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 64, nb, c->st, c->d_epoch));
     // which launches does a layer have at this row count?  (nothing is launched: no stage has this index)
     c->stage_sel = CW_MAX_DEC_STAGES; c->layer_sel = 0;

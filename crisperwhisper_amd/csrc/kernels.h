@@ -271,8 +271,9 @@ struct QkvSelfParams {
     unsigned long long* gkv;   // [2][16][D / 2] granules: this step's key / value rows, two 16-bit values each
     const unsigned int* epoch;
     int layer;
-    int* err;
+    int* err;                  // 0, or 1 + the decoder position of the first forward in which a wait gave up
     int Mb, D, H;
+    int fail_pos;              // test hook: the item of layer 0 gives up at this position (-1: never)
 };
 
 // declayer.hip: LayerNorm + fc1 + GELU and fc2 + residual of rows <= 8 in ONE launch (fc1 blocks publish a flag each, fc2 blocks
@@ -337,6 +338,7 @@ struct MelTables {
     bool cw_mlp_chain_ok(int Mb, int D, int F); \
     int cw_launch_mlp_chain(const MlpChainParams& p, hipStream_t st); \
     int cw_launch_qkv_self(const QkvSelfParams& p, hipStream_t st); \
+    int cw_qkv_self_blocks_per_cu(int D, int cap); \
     size_t cw_dec_layer_lds(int D); \
     int cw_launch_gemv_fc2x(const Fc2xParams& p, hipStream_t st); \
     int cw_launch_mlp_pair(const MlpPairParams& p, hipStream_t st); \

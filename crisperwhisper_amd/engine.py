@@ -441,5 +441,6 @@ class Engine:
         out.append({"stage": -1, "kernel": "whole decoder layer (all launches)", "avg_ms": ms.value, "algo_bytes": by.value})
         for s in range(ns.value):
             self._chk(self.lib.cw_time_decode_stage(self.ctx, nb, s, iters, C.byref(ms), C.byref(by), C.byref(kind), C.byref(ns)))
-            out.append({"stage": s, "kernel": self.lib.cw_decode_stage_name(kind.value).decode(), "avg_ms": ms.value, "algo_bytes": by.value})
+            out.append({"stage": s, "kernel": self.lib.cw_decode_stage_name(kind.value).decode(), "avg_ms": ms.value, "algo_bytes": by.value,
+                        "launches": int(self.lib.cw_decode_stage_launches(self.ctx, s))})
         return out

@@ -303,10 +303,19 @@ int32_t cw_time_kernel(cw_ctx* ctx, int32_t which, int32_t nb, int32_t iters, fl
 int32_t cw_time_decode_stage(cw_ctx* ctx, int32_t nb, int32_t stage, int32_t iters, float* avg_ms, double* algo_bytes,
                              int32_t* kind, int32_t* n_stages);
 const char* cw_decode_stage_name(int32_t kind);
+/* Kernel launches behind stage `stage` of the layer last enumerated by cw_time_decode_stage (2 at 17..64 rows where a preparation
+ * launch precedes the GEMV); 0 for an unknown stage. */
+int32_t cw_decode_stage_launches(cw_ctx* ctx, int32_t stage);
 /* Number of calls this context repeated on the launch-per-stage decoder kernels because blocks of one launch waited for each other
  * in vain (only when the GPU is shared with other work; 0 in normal operation).  After the first one the context stays on those
  * kernels; results are identical either way. */
 int32_t cw_handoff_fallbacks(cw_ctx* ctx);
+/* ... of which cw_decode did not start over: the decoder kernels record the position of the first forward that ran on a missed
+ * hand-off, the host sees it with the one-step lag of its "rows still running" read, rebuilds the sampler's per-row state from the
+ * token ids (/root/reference has no counterpart; the state is that of transformers' WhisperTimeStampLogitsProcessor +
+ * stopping criteria, generation_whisper.py / logits_process.py:1933-2048) and resumes at that position.  The whole call is
+ * repeated instead while a logprob threshold is set (its running sums cannot be rebuilt from ids). */
+int32_t cw_handoff_resumes(cw_ctx* ctx);
 
 #ifdef __cplusplus
 }
