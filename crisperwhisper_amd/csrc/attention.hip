@@ -1185,11 +1185,18 @@ __device__ inline void split3(const float* x, bf16x8_t& hi, bf16x8_t& mid, bf16x
     }
 }
 typedef short xm_v4s __attribute__((ext_vector_type(4)));
-template <bool TR>
+typedef unsigned int xm_u4 __attribute__((ext_vector_type(4)));
+// FUSED (round 6: the fused out-projection / cross-query stage of decfuse.hip under beam search): the rows arrive as the two halves
+// qa, qb of the un-normalised query and per-tile LayerNorm partial sums of x1 (gemv_stack_kernel), and the block finishes
+//     q = rstd(x1) (qa + qb - mean(x1) qw) + qbias
+// for its nq rows itself: every wave two of the up to 16 rows into a 4 KB LDS image, one block barrier, then every lane picks its
+// fragment (row r, columns g*16 .. +15) up.  See the load block in the kernel for why the operands are requested first and by all waves.
+template <bool TR, bool FUSED = false>
 __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma_kernel(CrossSplitParams p, int nq) {
     __shared__ __attribute__((aligned(16))) bf16_t s_v[8 * 32 * XM_VS];   // per wave: 32 V rows, later its 16 x 64 partial outputs
     __shared__ float s_max[8 * 16];
     __shared__ float red_l[8 * 16];
+    __shared__ __attribute__((aligned(16))) float s_qf[FUSED ? 16 * 64 : 4];
     const int h = blockIdx.x, b0 = blockIdx.y * nq, sp = blockIdx.z;
     const int bk = b0 / p.kv_div;
     const int per = (p.n_keys + ATT_NS - 1) / ATT_NS;
@@ -1200,18 +1207,72 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma_kernel(CrossSpl
     const int D = p.H * 64;
     const bf16_t* Kh = (const bf16_t*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64;
     const bf16_t* Vh = (const bf16_t*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64;
+    // FUSED: the query operands are requested BEFORE the K/V rows -- issued behind them they would queue behind the CU's own 256 KB
+    // of K/V requests and the block would sit at the barrier below until the stream has landed (27.3 us per launch against 15.6
+    // for a finished query) -- and by ALL waves, two rows each (wave w: rows 2 w, 2 w + 1; lane: row 2 w + lane / 32, columns
+    // 2 (lane % 32), + 1 and statistics tiles lane % 32, + 32, + 64): 7 eight-byte loads and 14 registers per lane.  (Wave 0 alone
+    // carrying the 16 x 64 values: 160 VGPRs, one block per CU instead of three.)
+    float2 fs[3], fa, fb, fw, fc;
+    const int qrow_l = 2 * wave + (lane >> 5), qcol = (lane & 31) * 2;
+    if (FUSED) {
+        const int row = b0 + min(qrow_l, nq - 1);
+        const float* ps = p.pstats + ((size_t)(row >> 4) * p.n_pstats * 16 + (row & 15)) * 2;   // [group of 16 rows][tile][16][2]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fs[i] = *(const float2*)(ps + (size_t)min((lane & 31) + 32 * i, p.n_pstats - 1) * 32);
+        const size_t col = (size_t)h * 64 + qcol;
+        fa = *(const float2*)(p.qa + (size_t)row * D + col); fb = *(const float2*)(p.qb + (size_t)row * D + col);
+        fw = *(const float2*)(p.qw + col); fc = *(const float2*)(p.qbias + col);
+    }
     // every load of the block first: 4 x 16 B of K (A fragments), 4 x 16 B of V (row-major), the lane's 16 query values
-    uint4 kf[2][2], vr[4];
+    // (ext-vector registers, not HIP's struct uint4: a struct copy is a memcpy, and across the query barrier of the FUSED form hipcc kept
+    // the four V rows in SCRATCH memory -- stored after the load, reloaded for the LDS write: 25.9 us per launch against 15.2)
+    xm_u4 kf[2][2], vr[4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const bf16_t* kp = Kh + (size_t)min(kb + t * 16 + r, nk - 1) * 64 + g * 16;
-        kf[t][0] = *(const uint4*)kp; kf[t][1] = *(const uint4*)(kp + 8);
+        kf[t][0] = *(const xm_u4*)kp; kf[t][1] = *(const xm_u4*)(kp + 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-        vr[u] = *(const uint4*)(Vh + (size_t)min(kb + (lane >> 3) + 8 * u, nk - 1) * 64 + (lane & 7) * 8);
+        vr[u] = *(const xm_u4*)(Vh + (size_t)min(kb + (lane >> 3) + 8 * u, nk - 1) * 64 + (lane & 7) * 8);
     float qf[2][8];
-    {
+    if (FUSED) {
+        __builtin_amdgcn_sched_barrier(0);                        // every request is out before the first wait
+        // (hipcc otherwise consumes the statistics BETWEEN the K and the V requests -- three waits in the middle of the issue sequence, to
+        // reuse their registers for the V rows: 25.9 us per launch against 15.2; the empty asm pins the operands behind the barrier)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(fs[i].x), "+v"(fs[i].y));
+        asm volatile("" : "+v"(fa.x), "+v"(fa.y), "+v"(fb.x), "+v"(fb.y), "+v"(fw.x), "+v"(fw.y), "+v"(fc.x), "+v"(fc.y));
+        {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float ok = ((lane & 31) + 32 * i < p.n_pstats) ? 1.f : 0.f;
+                s1 += ok * fs[i].x; s2 += ok * fs[i].y;
+            }
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }   // over the 32 lanes of the row
+            const float inv_d = 1.0f / (float)D;
+            const float mean = s1 * inv_d;
+            const float rstd = 1.0f / sqrtf(fmaxf(s2 * inv_d - mean * mean, 0.f) + 1e-5f);
+            float2 o;
+            o.x = ((fa.x + fb.x) - mean * fw.x) * rstd + fc.x;
+            o.y = ((fa.y + fb.y) - mean * fw.y) * rstd + fc.y;
+            *(float2*)(s_qf + qrow_l * 64 + qcol) = o;
+        }
+        // barrier WITHOUT the vmcnt drain of __syncthreads(): the K/V rows stay in flight across it -- the query was requested first and
+        // is long there; LDS traffic is ordered by lgkmcnt alone
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float* qp = s_qf + r * 64 + g * 16;
+        const float4 q0 = *(const float4*)qp, q1 = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
+        const float z = r < nq ? 1.f : 0.f;
+        qf[0][0] = q0.x * z; qf[0][1] = q0.y * z; qf[0][2] = q0.z * z; qf[0][3] = q0.w * z;
+        qf[0][4] = q1.x * z; qf[0][5] = q1.y * z; qf[0][6] = q1.z * z; qf[0][7] = q1.w * z;
+        qf[1][0] = q2.x * z; qf[1][1] = q2.y * z; qf[1][2] = q2.z * z; qf[1][3] = q2.w * z;
+        qf[1][4] = q3.x * z; qf[1][5] = q3.y * z; qf[1][6] = q3.z * z; qf[1][7] = q3.w * z;
+    } else {
         const float* qp = p.q + (size_t)(b0 + min(r, nq - 1)) * D + h * 64 + g * 16;
         const float4 q0 = *(const float4*)qp, q1 = *(const float4*)(qp + 4), q2 = *(const float4*)(qp + 8), q3 = *(const float4*)(qp + 12);
         const float z = r < nq ? 1.f : 0.f;                       // fragment columns past the last row: zero queries
@@ -1249,7 +1310,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma_kernel(CrossSpl
     // the wave's V rows into its LDS image (row-major, as loaded)
     bf16_t* sv = s_v + wave * (32 * XM_VS);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) *(uint4*)(sv + ((lane >> 3) + 8 * u) * XM_VS + (lane & 7) * 8) = vr[u];
+    for (int u = 0; u < 4; ++u) *(xm_u4*)(sv + ((lane >> 3) + 8 * u) * XM_VS + (lane & 7) * 8) = vr[u];
     __syncthreads();
     {
         float m = s_max[r];
@@ -1360,6 +1421,12 @@ int cw_launch_attn_cross_split(bool bf16, const CrossSplitParams& p, hipStream_t
         return CW_OK;
     }
 #endif
+    if (p.pstats && p.kv_div > 1) {   // fused stage under beam search: the hypotheses of an item in one block, query finished in the kernel
+        if (!bf16 || p.kv_div > 16 || p.B % p.kv_div || !p.qa || !p.qb || !p.qw || !p.qbias || p.xstat || p.q_planes > 1) return CW_ERR_INVALID;
+        if (p.n_pstats < 1 || p.n_pstats > 96 || p.B > 64 || (p.n_keys + ATT_NS - 1) / ATT_NS > 256) return CW_ERR_INVALID;
+        hipLaunchKernelGGL((attn_cross_mfma_kernel<true, true>), dim3(p.H, p.B / p.kv_div, ATT_NS), dim3(CROSS_THREADS), 0, st, p, p.kv_div);
+        return CW_OK;
+    }
     if (p.xstat || p.pstats) {   // fused out-projection / query stage: the query is finished in the kernel; 16-bit caches
         if (!bf16 || p.kv_div > 1 || p.H > 20 || !p.qa || !p.qb || !p.qw || !p.qbias || p.q_planes > 1) return CW_ERR_INVALID;
 #ifdef CW_EXPERIMENTS

@@ -100,6 +100,7 @@ struct cw_ctx {
     unsigned int* d_bar = nullptr; int* d_err = nullptr;   // group barriers of mlp_pair_kernel; "a block gave up waiting" flag
     int handoff_fallbacks = 0;      // times this context left the in-launch hand-offs for the launch-per-stage path because a wait gave up
     int handoff_resumes = 0;        // ... of which the decode call resumed at the failed position instead of starting over
+    long long forwards_since_reset = 0;   // upper bound of the decoder forwards since the granule epoch last started at 1 (epoch_hygiene)
     int fail_pos = -1;              // test hook (option "handoff_fail_pos"): qkv_self_kernel gives up at this decoder position
     // persistent decoder-layer kernel (declayer.hip), rows <= 8: granule buffers, the epoch counter their tags carry, CU count
     bool declayer = false;          // CW_DECLAYER=1: stage A of declayer.hip (fused stage + cross-attention in one persistent launch; bit-identical,
@@ -142,6 +143,8 @@ struct cw_ctx {
     // decoder state
     float *dx = nullptr, *dxn = nullptr, *dq = nullptr, *dattn = nullptr, *dmid = nullptr, *dlogits = nullptr;
     float *dx1 = nullptr, *dx2c = nullptr, *d_qa = nullptr, *d_qb = nullptr, *d_u1 = nullptr, *d_pstats = nullptr;   // fused decoder stages (decfuse.hip)
+    float *d_cvec = nullptr, *d_ostats = nullptr;             // 33..64 rows: row centres and per-(column pair, row) LayerNorm partial sums of the column-owning out-projection
+    bool own_cols = true;                                     // CW_NO_OWN_COLS=1: K-split out-projection + LayerNorm preparation launch (A/B)
     void *d_xfrag = nullptr, *d_xfrag2 = nullptr;             // bf16 [64][5120] fragment-major activations of the 17..64-row GEMV path
     int *d_ids = nullptr, *d_forced = nullptr, *d_argmax = nullptr, *d_last_ts = nullptr, *d_finished = nullptr,
         *d_nunf = nullptr, *d_align_slot = nullptr;
@@ -158,6 +161,7 @@ struct cw_ctx {
     hipGraphExec_t step_graph[65] = {};       // captured decode step (layers + logits + sampling) per batch size
     bool use_graph = true;
     bool fuse_rows = true;                    // fused out-projection / cross-query stage at 17..64 greedy rows (CW_NO_FUSE_ROWS=1: off)
+    bool fuse_beam = true;                    // ... and under beam search over the 16-bit cache (round 6; CW_NO_FUSE_BEAM=1: the twelve launches)
     bool fuse_rows8 = true;                   // ... over the e4m3 cache too (CW_NO_FUSE_ROWS8=1: that mode keeps its twelve launches)
     cw_gen_cfg gen{};
     bool gen_set = false;
@@ -397,6 +401,8 @@ static int create_impl(cw_ctx* c) {
     c->use_graph = !sw.no_graph;
     c->fuse_rows = !sw.no_fuse_rows;
     c->fuse_rows8 = !sw.no_fuse_rows8;
+    c->fuse_beam = !sw.no_fuse_beam;
+    c->own_cols = !sw.no_own_cols;
     c->fold_enabled = !sw.no_ln_fold;
     c->fuse6_enabled = !sw.no_fuse6;
     c->rows_ln_enabled = sw.rows_ln;
@@ -577,6 +583,7 @@ static int create_impl(cw_ctx* c) {
     }
 #endif
     CWCHK(c, dmalloc(c, &c->d_xfrag2, (size_t)64 * 5120 * 2));
+    CWCHK(c, dmalloc(c, &c->d_cvec, 64 * 4)); CWCHK(c, dmalloc(c, &c->d_ostats, (size_t)96 * 64 * 2 * 4));   // column-owning out-projection of 33..64 rows
     c->Vpad = (V + 3) & ~3;
     CWCHK(c, dmalloc(c, &c->dlogits, (size_t)Bm * c->Vpad * 4));
     CWCHK(c, dmalloc(c, &c->d_ids, (size_t)Bm * TGT * 4)); CWCHK(c, dmalloc(c, &c->d_forced, (size_t)Bm * TGT * 4));
@@ -1147,7 +1154,10 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     // (the rejected 17..64-row A/B variants of -DCW_EXPERIMENTS builds -- rows path, skinny GEMMs, full-key cross-attention -- keep their
     // own twelve / nine launches: they read c->dx and d_xfrag, which the fused stage's alternating buffers would leave stale)
     const bool ab17 = nb > 16 && (c->rows_ln_enabled || c->skinny_mode != 0);
-    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && !ab17 && (nb <= 16 || (c->fuse_rows && nb <= 64 && (!c->kv8 || c->fuse_rows8))) && c->beam_K == 0 &&
+    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && !ab17 && (nb <= 16 || (c->fuse_rows && nb <= 64 && (!c->kv8 || c->fuse_rows8))) &&
+                      // beam search (round 6): the hypotheses of an item share a cross-attention block that finishes their queries
+                      // (attn_cross_mfma_kernel<.., FUSED>, 16-bit cache); CW_NO_FUSE_BEAM=1: the twelve launches
+                      (c->beam_K == 0 || (c->fuse_beam && !c->kv8 && c->beam_K <= 16 && !c->fuse_mlp)) &&
                       (!c->kv8 || (KD(c, cw_cross8_is_mfma, CW_N_CTX) && !c->fuse_mlp)) && !((c->fuse_mlp || c->mlp_pair) && nb > 8);
     float *xin = c->dx, *xalt = c->dx1;
     // 17..64 rows without preparation launches (decfuse.hip: gemv_rows_kernel): the residual GEMVs own whole columns and leave
@@ -1202,6 +1212,10 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         return KD(c, cw_launch_gemv_rows, (int)EPI_RESID_F32, true, rp, c->st);
     };
     if (rows) CWCHK(c, KD(c, cw_launch_rows_prep, c->dx, nb, D, c->d_xfrag, c->d_rstats, lo_off, c->st));
+    // 33..64 rows behind the fused stage (round 6): the cross-attention out-projection owns whole columns (no K split, no atomics) and
+    // leaves fc1 its 16-bit rows and LayerNorm partial sums -- one preparation launch less per layer (gemm.hip: gemv_mt_kernel OWN / LNA)
+    const bool own = c->own_cols && fuse && frag && nb > 32 && !c->fuse_mlp && !c->mlp_pair && c->rows_ln_ready && D % 32 == 0 && D / 16 <= 96 && D <= 1536 &&
+                     D % 128 == 0 && F % 32 == 0;
     const bool pf = c->prefetch > 0 && c->bf16 && c->beam_K == 0 && !c->kv8;
     // cw_time_decode_stage runs ONE launch (stage_sel) of ONE layer (layer_sel) through this very code: the kernels it times are
     // the ones the step launches, with the step's arguments
@@ -1211,7 +1225,8 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
         if (stage_no < CW_MAX_DEC_STAGES) {                                                         \
             c->stage_kind[stage_no] = (kind);                                                       \
             /* 17..64 rows: a LayerNorm / combining GEMV is gemv_prep_kernel + gemv_mt_kernel */    \
-            c->stage_launches[stage_no] = 1 + ((frag && !skinny && !rows && !xfull && ((kind) == DST_QKV || (kind) == DST_CROSS_Q || (kind) == DST_FC1 || (kind) == DST_CROSS_O)) ? 1 : 0); \
+            c->stage_launches[stage_no] = 1 + ((frag && !skinny && !rows && !xfull && ((kind) == DST_QKV || (kind) == DST_CROSS_Q || (kind) == DST_FC1 || (kind) == DST_CROSS_O) && \
+                                                !(own && ((kind) == DST_FC1 || (kind) == DST_CROSS_O))) ? 1 : 0); \
         }                                                                                           \
         c->stage_count = ++stage_no;                                                                \
     } while (0)
@@ -1285,7 +1300,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             CrossSplitParams p{nullptr, L.ck, L.cv, CW_N_CTX, c->d_part_o, c->d_part_ml,
                                c->d.n_align > 0 ? c->d_align : nullptr, c->d_align_ml, c->d_align_slot + (size_t)l * H,
                                c->d_pos, c->d.n_align, TGT, nb, H};
-            p.kv_div = 1;
+            p.kv_div = c->beam_K > 0 ? c->beam_K : 1;
             p.qa = c->d_qa; p.qb = c->d_qb; p.qw = L.q_wsum; p.qbias = L.bq_c;
             p.pstats = c->d_pstats; p.n_pstats = (TD + nt3 - 1) / nt3;
             if (!c->fuse_mlp) {
@@ -1294,6 +1309,26 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
                     STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_cross_split_fp8, p, c->st));
                 } else
                 if (!dl) STG(DST_CROSS_ATTN, KD(c, cw_launch_attn_cross_split, true, p, c->st));
+                if (own) {
+                    // combine (+ the rows' centres) -> d_xfrag;  x2 = x1 + Wo_c a_c + bo_c in place, y = x2 - c -> d_xfrag2, partial sums;
+                    // fc1 normalises on its accumulator, GELU rows -> d_xfrag;  fc2 as before
+                    CombineParams cb{c->d_part_ml, H, nb * D, c->d_pstats, p.n_pstats, c->d_cvec};
+                    STG(DST_OTHER, KD(c, cw_launch_rows_combine, c->d_part_o, nb, D, cb, c->d_xfrag, c->st));
+                    {
+                        EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.bo_c; ep.ldo = D;
+                        STG(DST_CROSS_O, KD(c, cw_launch_gemv_own, c->d_xfrag, nb, D, L.wo_c, D, ep, c->d_cvec, c->d_xfrag2, c->d_ostats, c->st, c->wpacked));
+                    }
+                    {
+                        EpiParams ep = epi0(); ep.out = c->d_xfrag; ep.bias = L.b1; ep.ldo = F;
+                        STG(DST_FC1, KD(c, cw_launch_gemv_lna, c->d_xfrag2, nb, D, L.w1, F, ep, c->d_ostats, D / (16 * KD(c, cw_gemv_own_nt, D)), L.u1_wsum, c->st, c->wpacked));
+                    }
+                    {
+                        EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.b2; ep.ldo = D;
+                        STG(DST_FC2, KD(c, cw_launch_gemv, true, EPI_RESID_F32, nullptr, nb, F, L.w2, D, nullptr, nullptr, ep, c->st, nullptr, c->d_xfrag, c->wpacked));
+                    }
+                    float* t = xin; xin = xalt; xalt = t;
+                    continue;
+                }
                 {   // out-projection combines the key-split partials; x2 = x1 + Wo_c a_c + bo_c in place
                     EpiParams ep = epi0(); ep.outf = xalt; ep.resid = xalt; ep.bias = L.bo_c; ep.ldo = D;
                     CombineParams cb{c->d_part_ml, H, nb * D};
@@ -1519,6 +1554,24 @@ static int handoffs_off(cw_ctx* c, const char* where) {
 int32_t cw_handoff_fallbacks(cw_ctx* c) { return c->handoff_fallbacks; }
 int32_t cw_handoff_resumes(cw_ctx* c) { return c->handoff_resumes; }
 
+// The granule tag is (epoch << 6) | layer in 32 bits: 26 bits of the device's forward counter.  Granules are never cleared, so a
+// stale one from exactly 2^26 forwards ago (rows a smaller batch did not rewrite) would pass for valid -- about a day of continuous
+// decoding.  Entry points that run decoder forwards announce an upper bound here; long before the tag can repeat the granules are
+// zeroed (tag 0 = epoch 0, never used) and the counter starts again at 1.  Called with the stream idle or about to be synchronised.
+static int epoch_hygiene(cw_ctx* c, long long upcoming_forwards) {
+    c->forwards_since_reset += upcoming_forwards;
+    if (c->forwards_since_reset < (1ll << 25)) return CW_OK;
+    const int D = c->d.d_model;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipMemset(c->d_gq, 0, (size_t)2 * 16 * D * 8)); HIPCHK(c, hipMemset(c->d_gps, 0, (size_t)(D / 16) * 16 * 2 * 8));
+    HIPCHK(c, hipMemset(c->d_gq2, 0, (size_t)16 * D * 8)); HIPCHK(c, hipMemset(c->d_gkv, 0, (size_t)2 * 16 * (D / 2) * 8));
+    HIPCHK(c, hipMemset(c->d_gflag, 0, (size_t)512 * 8));
+    const unsigned int one = 1;
+    HIPCHK(c, hipMemcpy(c->d_epoch, &one, 4, hipMemcpyHostToDevice));
+    c->forwards_since_reset = upcoming_forwards;
+    return CW_OK;
+}
+
 static int decode_once(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_prompt, int32_t max_length,
                        int32_t min_new_tokens, const int32_t* forced, int32_t* sequences, int32_t* lengths,
                        int32_t* argmax_out);
@@ -1542,6 +1595,7 @@ static int decode_once(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_p
     if (max_length <= n_prompt || max_length > TGT) return fail(c, CW_ERR_INVALID, "max_length=%d out of range (n_prompt %d, max_target %d)", max_length, n_prompt, TGT);
     c->beam_K = 0;
     c->align_cur = c->d_align;
+    CWCHK(c, epoch_hygiene(c, 2 * (long long)max_length + 4));   // (a resumed call runs some positions twice)
     std::vector<int> ids((size_t)nb * TGT, c->gen.pad_token_id);
     for (int b = 0; b < nb; ++b)
         for (int t = 0; t < n_prompt; ++t) {
@@ -1690,6 +1744,7 @@ int32_t cw_no_speech_probs(cw_ctx* c, int32_t nb, int32_t sot_token, float* out)
     if (nb < 1 || nb > c->nb_encoded) return fail(c, CW_ERR_STATE, "nb=%d but %d windows encoded", nb, c->nb_encoded);
     const int tok = c->gen.no_timestamps_token_id - 1;
     if (sot_token < 0 || sot_token >= V || tok < 0) return fail(c, CW_ERR_INVALID, "no_speech_probs: token out of range");
+    CWCHK(c, epoch_hygiene(c, 4));
     c->beam_K = 0;
     c->align_cur = c->d_align;
     std::vector<int> ids((size_t)nb * TGT, c->gen.pad_token_id);
@@ -1781,6 +1836,7 @@ int32_t cw_beam_begin(cw_ctx* c, int32_t n_items, int32_t num_beams, const int32
     if (rows > c->Bm) return fail(c, CW_ERR_INVALID, "beam search needs max_batch >= items x beams = %d (context has %d)", rows, c->Bm);
     if (n_prompt < 1 || n_prompt >= TGT || max_length <= n_prompt || max_length > TGT) return fail(c, CW_ERR_INVALID, "beam_begin: n_prompt=%d max_length=%d out of range", n_prompt, max_length);
     CWCHK(c, beam_alloc(c));
+    CWCHK(c, epoch_hygiene(c, 2 * (long long)max_length + 4));
     std::vector<int> ids((size_t)rows * TGT, c->gen.pad_token_id), anc((size_t)rows * TGT);
     for (int r = 0; r < rows; ++r) {
         for (int t = 0; t < n_prompt; ++t) {
@@ -2685,6 +2741,7 @@ int32_t cw_stage_times(cw_ctx* c, float* ms, int32_t* calls, int32_t reset) {
 }
 
 int32_t cw_time_kernel(cw_ctx* c, int32_t which, int32_t nb, int32_t iters, float* avg_ms, double* algo_bytes) {
+    if (iters > 0) CWCHK(c, epoch_hygiene(c, (long long)iters + 8));
     if (which == 100 || which == 101) {
         // launch-boundary floor: a captured graph of `iters` dependent near-empty kernels (100), or the same
         // launched eagerly (101); avg_ms = time per kernel
@@ -2819,6 +2876,7 @@ int32_t cw_time_decode_stage(cw_ctx* c, int32_t nb, int32_t stage, int32_t iters
     // the launches run for real at decoder position 64: they append to the self-attention cache and write alignment rows there
     if (c->d.max_target_positions <= 65) return fail(c, CW_ERR_INVALID, "time_decode_stage: needs max_target_positions > 65 (has %d)", c->d.max_target_positions);
     CWCHK(c, cw_check_weights(c));
+    CWCHK(c, epoch_hygiene(c, (long long)iters + 8));
     if (nb > c->nb_encoded) return fail(c, CW_ERR_STATE, "time_decode_stage: nb=%d but %d windows encoded (the cross-attention reads their K/V)", nb, c->nb_encoded);
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, NL = c->d.dec_layers;
     // a hand-off that gave up while timing (shared GPU) must not send the next cw_decode to the fallback path: drain and clear

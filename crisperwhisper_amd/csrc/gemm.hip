@@ -1577,6 +1577,12 @@ __global__ __launch_bounds__(256) void gemv_prep_kernel(const float* __restrict_
             }
         }
     }
+    if (COMBINE && cb.cvec_out) {   // centre of the row for the column-owning out-projection behind this launch: mean(x1) from the stage's partial sums
+        const float* ps = cb.pstats + ((size_t)(m >> 4) * cb.n_pstats * 16 + (m & 15)) * 2;
+        const float s = tid < cb.n_pstats ? ps[(size_t)tid * 32] : 0.f;
+        const float tot = block_sum(s, s_red);
+        if (tid == 0) cb.cvec_out[m] = tot / (float)K;
+    }
     if (ln_g) {
         float4 gq[5], bq[5];                                   // issued before the reductions
 #pragma unroll
@@ -1627,10 +1633,29 @@ __global__ __launch_bounds__(256) void gemv_prep_kernel(const float* __restrict_
 // 64 rows a 16-column block reads 160 KB of (replicated) activation fragments for 40 KB of weights; two column tiles x two of the
 // four row tiles is 80 + 80 KB for the same MFMAs.  Rows and column tiles are independent in the MFMA: every output element is
 // the sum it was, in the order it was -- bit-identical to the one-tile block.
-template <int EPI, int MT, bool ATOMIC, int NSLOT, bool PREA = false, int NT = 1>
+// OWN (round 6: the cross-attention out-projection of 33..64 rows without a K split -- grid (N / 32, 1, row tiles), MT = 1, NT = 2): the
+// block owns its output elements, so besides x_new = resid + grid(acc + bias) it leaves what the NEXT LayerNorm projection needs and
+// a preparation launch used to produce: y = x_new - c[row] in the 16-bit type in fragment-major order (c = the row's mean one stage
+// earlier: y is centred to within the stage's own update, so its 16-bit rounding is that of the normalised row) and the partial sums
+// (sum y, sum y^2) of the block's 32 columns per row, plain stores, one slot per (column pair, row).
+// LNA (the consumer, fc1): the rows arrive as those y; the block sums the partials of its rows in a fixed order and applies the
+// LayerNorm on the accumulator -- rstd (acc - mean_y wsum[n]) + bias[n], wsum[n] = row sum of the folded 16-bit weights -- exactly the
+// algebra of gemv_stack_kernel / the <= 16-row fused stage.
+struct MtExtra {
+    const float* cvec;       // OWN: [rows] centre of every row
+    bf16_t* xf_out;          // OWN: fragment-major 16-bit y rows [.. x ldo]
+    float* stats_out;        // OWN: [N / 32][64][2] partial sums
+    const float* stats_in;   // LNA: the same plane
+    int n_stats;             // LNA: column pairs (N_producer / 32)
+    const float* wsum;       // LNA: [N] row sums of the folded weights
+};
+
+template <int EPI, int MT, bool ATOMIC, int NSLOT, bool PREA = false, int NT = 1, int MODE2 = 0 /* 1: OWN, 2: LNA */>
 __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__ xf, int Mb, int K, int Kb,
-                                                      const bf16_t* __restrict__ W, int N, EpiParams ep, int wpk) {
+                                                      const bf16_t* __restrict__ W, int N, EpiParams ep, int wpk, MtExtra ex) {
     __shared__ float red[4 * NT * MT * 4 * 64];
+    __shared__ float s_ln[MODE2 == 2 ? MT * 16 * 2 : 2];
+    __shared__ float s_lnp[MODE2 == 2 ? 8 * MT * 16 * 2 : 2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
@@ -1667,6 +1692,16 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
     for (int c = 0; c < NT; ++c)
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[c][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // LNA: thread (part = tid / (MT * 16), row = tid % (MT * 16)) takes column pairs part, part + PARTS, ... of its row (up to 12 loads
+    // in flight with everything else); fixed order, so the statistics are the same bits in every block
+    constexpr int LN_ROWS = MT * 16, LN_PARTS = 256 / LN_ROWS;
+    float2 lnv[MODE2 == 2 ? 12 : 1];
+    if (MODE2 == 2) {
+        const int lrow = tid % LN_ROWS, lpart = tid / LN_ROWS;
+        const float* sp = ex.stats_in + (size_t)(t0 * 16 + lrow) * 2;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) lnv[i] = *(const float2*)(sp + (size_t)min(lpart + LN_PARTS * i, ex.n_stats - 1) * 128);
+    }
     const u32x4_t* xq = (const u32x4_t*)xf;
     u32x4_t aq[PREA ? NSLOT : 1][4][MT];
     if (PREA) {
@@ -1710,23 +1745,71 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[(((wave * NT + c) * MT + t) * 4 + r) * 64 + lane] = acc[c][t][r];
-    __syncthreads();
-    const int r = tid >> 6;
+    if (MODE2 == 2) {   // partial sums of the block's rows -> (mean_y, rstd) per row
+        const int lrow = tid % LN_ROWS, lpart = tid / LN_ROWS;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < NT; ++c)
+        for (int i = 0; i < 12; ++i) {
+            const float ok = (lpart + LN_PARTS * i < ex.n_stats) ? 1.f : 0.f;
+            s1 += ok * lnv[i].x; s2 += ok * lnv[i].y;
+        }
+        s_lnp[(lpart * LN_ROWS + lrow) * 2] = s1; s_lnp[(lpart * LN_ROWS + lrow) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (MODE2 == 2) {
+        if (tid < LN_ROWS) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < LN_PARTS; ++q) { s1 += s_lnp[(q * LN_ROWS + tid) * 2]; s2 += s_lnp[(q * LN_ROWS + tid) * 2 + 1]; }
+            const float inv_k = 1.0f / (float)K;
+            const float mean = s1 * inv_k;
+            s_ln[tid * 2] = mean;
+            s_ln[tid * 2 + 1] = 1.0f / sqrtf(fmaxf(s2 * inv_k - mean * mean, 0.f) + 1e-5f);
+        }
+        __syncthreads();
+    }
+    const int r = tid >> 6;
+    float wsum_v[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) wsum_v[c] = (MODE2 == 2) ? ex.wsum[nc[c]] : 0.f;
+    static_assert(MODE2 != 2 || MT == 1 || MT == 2 || MT == 4, "LNA: the rows of a block must divide its 256 threads");
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[(((w * NT + c) * MT + t) * 4 + r) * 64 + lane];
         const int m = (t0 + t) * 16 + g * 4 + r;
-        if (m < Mb && n[c] < N) {
-            if (ATOMIC) {
-                atomicAdd(ep.outf + (size_t)m * ep.ldo + n[c], resid_grid(v + (blockIdx.y == 0 ? bias_v[c] : 0.f)));
-            } else {
-                EpiParams e2 = ep;
-                e2.bias = nullptr;
-                epi_store1<bf16_t, EPI>(e2, m, n[c], EPI == EPI_RESID_F32 ? resid_grid(v + bias_v[c]) : v + bias_v[c]);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[(((w * NT + c) * MT + t) * 4 + r) * 64 + lane];
+            const bool live = m < Mb && n[c] < N;
+            if (MODE2 == 2) {
+                const int lr = t * 16 + g * 4 + r;
+                v = (v - s_ln[lr * 2] * wsum_v[c]) * s_ln[lr * 2 + 1];
+            }
+            if (live) {
+                if (ATOMIC) {
+                    atomicAdd(ep.outf + (size_t)m * ep.ldo + n[c], resid_grid(v + (blockIdx.y == 0 ? bias_v[c] : 0.f)));
+                } else if (MODE2 == 1) {
+                    const size_t o = (size_t)m * ep.ldo + n[c];
+                    const float xn = ep.resid[o] + resid_grid(v + bias_v[c]);
+                    ep.outf[o] = xn;
+                    const float y = xn - ex.cvec[m];
+                    ex.xf_out[frag_index(m, n[c], ep.ldo)] = f32_to_bf16(y);
+                    s1 += y; s2 += y * y;
+                } else {
+                    EpiParams e2 = ep;
+                    e2.bias = nullptr;
+                    epi_store1<bf16_t, EPI>(e2, m, n[c], EPI == EPI_RESID_F32 ? resid_grid(v + bias_v[c]) : v + bias_v[c]);
+                }
+            }
+        }
+        if (MODE2 == 1) {   // sums over the block's NT x 16 columns: the lane's own tiles above, then the 16 lanes of the row
+#pragma unroll
+            for (int msk = 1; msk < 16; msk <<= 1) { s1 += __shfl_xor(s1, msk, 64); s2 += __shfl_xor(s2, msk, 64); }
+            if (l15 == 0 && m < Mb) {
+                float* so = ex.stats_out + ((size_t)blockIdx.x * 64 + m) * 2;
+                so[0] = s1; so[1] = s2;
             }
         }
     }
@@ -2061,10 +2144,10 @@ static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N
         do {                                                                                                          \
             if (atomic)                                                                                               \
                 hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, MH, true, NS, true, NTT>), g2, dim3(256), 0, st, xf, Mb, K, Kb, \
-                                   (const bf16_t*)W, N, ep, wpk);                                                     \
+                                   (const bf16_t*)W, N, ep, wpk, MtExtra{});                                                     \
             else                                                                                                      \
                 hipLaunchKernelGGL((gemv_mt_kernel<EPI, MH, false, NS, true, NTT>), g2, dim3(256), 0, st, xf, Mb, K, Kb, \
-                                   (const bf16_t*)W, N, ep, wpk);                                                     \
+                                   (const bf16_t*)W, N, ep, wpk, MtExtra{});                                                     \
         } while (0)
         if (nt == 2) { if (steps <= 4) CW_MT_LAUNCH2(1, 2); else if (steps <= 8) CW_MT_LAUNCH2(2, 2); else CW_MT_LAUNCH2(3, 2); }
         else { if (steps <= 4) CW_MT_LAUNCH2(1, 1); else if (steps <= 8) CW_MT_LAUNCH2(2, 1); else CW_MT_LAUNCH2(3, 1); }
@@ -2075,16 +2158,16 @@ static void launch_gemv_mt(const bf16_t* xf, int Mb, int K, const void* W, int N
     do {                                                                                                              \
         if (atomic && prea)                                                                                           \
             hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, MT, true, NS, true>), grid, dim3(256), 0, st, xf, Mb, K, Kb, \
-                               (const bf16_t*)W, N, ep, wpk);                                                         \
+                               (const bf16_t*)W, N, ep, wpk, MtExtra{});                                                         \
         else if (atomic)                                                                                              \
             hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, MT, true, NS, false>), grid, dim3(256), 0, st, xf, Mb, K, Kb, \
-                               (const bf16_t*)W, N, ep, wpk);                                                         \
+                               (const bf16_t*)W, N, ep, wpk, MtExtra{});                                                         \
         else if (prea)                                                                                                \
             hipLaunchKernelGGL((gemv_mt_kernel<EPI, MT, false, NS, true>), grid, dim3(256), 0, st, xf, Mb, K, Kb,      \
-                               (const bf16_t*)W, N, ep, wpk);                                                         \
+                               (const bf16_t*)W, N, ep, wpk, MtExtra{});                                                         \
         else                                                                                                          \
             hipLaunchKernelGGL((gemv_mt_kernel<EPI, MT, false, NS, false>), grid, dim3(256), 0, st, xf, Mb, K, Kb,     \
-                               (const bf16_t*)W, N, ep, wpk);                                                         \
+                               (const bf16_t*)W, N, ep, wpk, MtExtra{});                                                         \
     } while (0)
     if (steps <= 4) CW_MT_LAUNCH(1);
     else if (steps <= 8) CW_MT_LAUNCH(2);
@@ -2145,6 +2228,43 @@ static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void*
         hipLaunchKernelGGL((gemv_f32_kernel<EPI>), dim3((N + 3) / 4), dim3(256), 0, st, x, Mb, K, (const float*)W, N,
                            ep);
     }
+    return CW_OK;
+}
+
+// 33..64 rows (round 6): x_new = resid + W a + b WITHOUT a K split or atomics -- gemv_mt_kernel OWN, grid (N / 32, 1, row tiles): two
+// column tiles x one row tile per block (80 KB of weights + 40 KB of activation fragments at K = 1280) -- leaving the next LayerNorm
+// projection's 16-bit rows and partial sums behind (see the kernel).  The consumer is cw_launch_gemv_lna.
+// column tiles per block of the column-owning GEMV = partial-sum slots per row N / (16 nt); CW_OWN_NT=1|2 (A/B)
+int cw_gemv_own_nt(int N) {
+    (void)N;   // one tile (80 slots at d = 1280, grid (80, 1, row tiles)): 2.366 ms per beam step at 8 x 5 rows against 2.411 at two, batch 40 3.227 against 3.260
+    return cw_sw::cw_switches().own_nt == 2 ? 2 : 1;
+}
+int cw_launch_gemv_own(const void* xf, int Mb, int K, const void* W, int N, const EpiParams& ep, const float* cvec, void* xf_out,
+                       float* stats_out, hipStream_t st, bool wpacked) {
+    if (Mb < 17 || Mb > GV_MAXM || K % 128 || K > 1536 || N % 32 || N / 16 > 96 || !xf || !cvec || !xf_out || !stats_out) return CW_ERR_INVALID;
+    if (!ep.outf || !ep.resid || ep.ldo != N || xf == xf_out) return CW_ERR_INVALID;
+    const int steps = K / 128, wpk = wpacked ? 1 : 0;
+    const MtExtra ex{cvec, (bf16_t*)xf_out, stats_out, nullptr, 0, nullptr};
+    const int nt = cw_gemv_own_nt(N);
+    const dim3 grid((unsigned)(N / (16 * nt)), 1, (unsigned)((Mb + 15) / 16));
+#define CW_OWN_LAUNCH(NS, NTT) hipLaunchKernelGGL((gemv_mt_kernel<EPI_RESID_F32, 1, false, NS, true, NTT, 1>), grid, dim3(256), 0, st, (const bf16_t*)xf, Mb, K, K, (const bf16_t*)W, N, ep, wpk, ex)
+    if (nt == 2) { if (steps <= 4) CW_OWN_LAUNCH(1, 2); else if (steps <= 8) CW_OWN_LAUNCH(2, 2); else CW_OWN_LAUNCH(3, 2); }
+    else { if (steps <= 4) CW_OWN_LAUNCH(1, 1); else if (steps <= 8) CW_OWN_LAUNCH(2, 1); else CW_OWN_LAUNCH(3, 1); }
+#undef CW_OWN_LAUNCH
+    return CW_OK;
+}
+
+// ... and the LayerNorm projection behind it (fc1 + GELU -> fragment-major rows): the rows arrive as y = x - c in 16 bits, the
+// LayerNorm is applied on the accumulator from the producer's partial sums (gemv_mt_kernel LNA); block shape of the 33..64-row GEMVs
+int cw_launch_gemv_lna(const void* xf, int Mb, int K, const void* W, int N, const EpiParams& ep, const float* stats_in, int n_stats,
+                       const float* wsum, hipStream_t st, bool wpacked) {
+    if (Mb < 33 || Mb > GV_MAXM || K % 128 || K > 1536 || N % 32 || !xf || !stats_in || !wsum || n_stats < 1 || n_stats > 96 || !ep.out) return CW_ERR_INVALID;
+    const int steps = K / 128, wpk = wpacked ? 1 : 0;
+    const dim3 grid((unsigned)(N / 32), 1, 2);
+    const MtExtra ex{nullptr, nullptr, nullptr, stats_in, n_stats, wsum};
+    if (steps <= 4) hipLaunchKernelGGL((gemv_mt_kernel<EPI_GELU_FRAG, 2, false, 1, true, 2, 2>), grid, dim3(256), 0, st, (const bf16_t*)xf, Mb, K, K, (const bf16_t*)W, N, ep, wpk, ex);
+    else if (steps <= 8) hipLaunchKernelGGL((gemv_mt_kernel<EPI_GELU_FRAG, 2, false, 2, true, 2, 2>), grid, dim3(256), 0, st, (const bf16_t*)xf, Mb, K, K, (const bf16_t*)W, N, ep, wpk, ex);
+    else hipLaunchKernelGGL((gemv_mt_kernel<EPI_GELU_FRAG, 2, false, 3, true, 2, 2>), grid, dim3(256), 0, st, (const bf16_t*)xf, Mb, K, K, (const bf16_t*)W, N, ep, wpk, ex);
     return CW_OK;
 }
 

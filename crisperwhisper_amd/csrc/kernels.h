@@ -118,6 +118,11 @@ struct CombineParams {     // activations of a GEMV = combination of ATT_NS atte
     const float* part_ml;  // null: plain activations
     int H;                 // heads
     int plane;             // elements per partial plane (B * K)
+    // 33..64 rows, column-owning out-projection behind this combine (gemv_mt_kernel OWN): the preparation launch also leaves the
+    // row's mean one stage earlier, from the per-tile LayerNorm partial sums of gemv_stack_kernel ([group of 16 rows][tile][16][2])
+    const float* pstats;   // null: not wanted
+    int n_pstats;
+    float* cvec_out;       // [rows]
 };
 
 // decfuse.hip: one launch over a row-stacked weight matrix W [sum n_tiles * 16][K]; up to 3 segments
@@ -329,6 +334,9 @@ struct MelTables {
     int cw_launch_gemm_fp8(int epi, const void* A8, int lda, const void* W8, int M, int N, int K, const float* sa, const float* sw, const EpiParams& ep, hipStream_t st); \
     int cw_launch_fold_layernorm(const float* Wf, int N, int K, const float* g, const float* beta, float scale, void* w_out, float* bias, hipStream_t st); \
     int cw_launch_gemv(bool bf16, int epi, const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb = nullptr, void* scratch = nullptr, bool wpacked = false); \
+    int cw_gemv_own_nt(int N); \
+    int cw_launch_gemv_own(const void* xf, int Mb, int K, const void* W, int N, const EpiParams& ep, const float* cvec, void* xf_out, float* stats_out, hipStream_t st, bool wpacked); \
+    int cw_launch_gemv_lna(const void* xf, int Mb, int K, const void* W, int N, const EpiParams& ep, const float* stats_in, int n_stats, const float* wsum, hipStream_t st, bool wpacked); \
     size_t cw_wfrag_elems(int N, int K); \
     int cw_launch_wfrag_pack(const void* src, int N, int K, void* dst, hipStream_t st); \
     int cw_launch_fold_product(const float* A, const float* s, float scale, const float* B, int N, int J, int K, void* C16, hipStream_t st); \

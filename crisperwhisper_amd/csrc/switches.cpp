@@ -26,6 +26,8 @@ Switches read_switches() {
     s.mlp_chain = flag("CW_MLP_CHAIN");
     s.no_fuse_rows = flag("CW_NO_FUSE_ROWS");
     s.no_fuse_rows8 = flag("CW_NO_FUSE_ROWS8");
+    s.no_fuse_beam = flag("CW_NO_FUSE_BEAM");
+    s.no_own_cols = flag("CW_NO_OWN_COLS");
     s.skinny = num("CW_SKINNY", 0);
     s.prefetch = num("CW_PREFETCH", 0);
     s.prefetch_wide = num("CW_PREFETCH_WIDE", 0);
@@ -57,6 +59,7 @@ Switches read_switches() {
     s.gemv_loop_cap = num("CW_GEMV_LOOP_CAP", 512);
     s.fc2_ksplit = num("CW_FC2_KSPLIT", 0);
     s.mt_variant = num("CW_MT_VARIANT", -1);
+    s.own_nt = num("CW_OWN_NT", 1);
     if (s.mt_variant < -1 || s.mt_variant > 2) s.mt_variant = -1;
     s.beam_topk_1block = flag("CW_BEAM_TOPK_1BLOCK");
     s.mel_valu = flag("CW_MEL_VALU");

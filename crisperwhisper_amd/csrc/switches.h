@@ -10,14 +10,14 @@ namespace cw_sw {
 
 struct Switches {
     // engine (cw_create)
-    bool no_graph, no_ln_fold, no_fuse6, rows_ln, no_rows_hilo, no_stack_center, no_mid16, dtw_block, fuse_mlp, no_wpack, mlp_pair, mlp_pair_fence, declayer, no_qkv_self, mlp_chain, no_fuse_rows, no_fuse_rows8;
+    bool no_graph, no_ln_fold, no_fuse6, rows_ln, no_rows_hilo, no_stack_center, no_mid16, dtw_block, fuse_mlp, no_wpack, mlp_pair, mlp_pair_fence, declayer, no_qkv_self, mlp_chain, no_fuse_rows, no_fuse_rows8, no_fuse_beam, no_own_cols;
     int skinny, prefetch, prefetch_wide, prefetch_what, stack_nt3, stack_nt5;
     // attention launchers
     bool attn_v1, anc_attn_v1, cross_per_row, cross_valu, cross_no_tr, cross8_valu, cross_mfma1;
     int cross_lds_pad, cross8_nsb, dl_depth, dl_kvwait, mlp_chain_delay, qkv_self_dbg;
     // GEMM / GEMV launchers
     bool no_glds, no_gemm256, no_gemm_pp, no_gemm_8ph, gemm_w128, no_gemv_loop, comb_nt2, comb_no_rowgroups, mt_no_prea;
-    int gemv_loop_cap, fc2_ksplit, mt_variant;
+    int gemv_loop_cap, fc2_ksplit, mt_variant, own_nt;
     // sampling, mel
     bool beam_topk_1block, mel_valu;
     int mel_dbg;

@@ -17,7 +17,10 @@ from crisperwhisper_amd import synthetic as syn
 from tests.golden import hf_synth as H
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-N_CLIPS, N_TOK = 4, 40
+# defaults = the committed e2e_bench_beam_golden.json; round 6 adds the bench shape itself (what `bench.py --num-beams 5` decodes):
+#     CW_GOLD_CLIPS=8 CW_GOLD_TOKENS=128 CW_GOLD_NAME=e2e_bench_beam128_golden.json python -m tests.golden.gen_golden_bench_beam
+N_CLIPS, N_TOK = int(os.environ.get("CW_GOLD_CLIPS", "4")), int(os.environ.get("CW_GOLD_TOKENS", "40"))
+NAME = os.environ.get("CW_GOLD_NAME", "e2e_bench_beam_golden.json")
 GEN_KW = {"num_beams": 5, "language": "<|en|>", "task": "transcribe", "max_new_tokens": N_TOK, "min_new_tokens": N_TOK}
 
 
@@ -43,7 +46,7 @@ def main():
         print("clip", seed, "%.0f s" % (time.time() - t0), len(res["chunks"]), "words", flush=True)
         meta["clips"].append({"seed": seed, "kind": "noise", "secs": 30, "text": res["text"],
                               "chunks": [{"text": c["text"], "timestamp": list(c["timestamp"])} for c in res["chunks"]]})
-        json.dump(meta, open(os.path.join(OUT, "e2e_bench_beam_golden.json"), "w"), ensure_ascii=True, indent=0)
+        json.dump(meta, open(os.path.join(OUT, NAME), "w"), ensure_ascii=True, indent=0)
 
 
 if __name__ == "__main__":
