@@ -2078,10 +2078,19 @@ static void launch_gemv2(const float* x, int Mb, int K, const void* W, int N, co
     // (tools/gemv_stage_phase_probe.py: requests accepted at 1.9 us, reduce done at 3.1).  Same K slices (so every partial sum and
     // every rounding is the one of the (N / 16, ksplit) grid: bit-identical), but two column tiles per block and the rows in up to
     // three groups: grid (40, 2, 3) = 240 blocks of 46 KB of partials + 41 KB of weights.
-    if (EPI == EPI_RESID_F32 && cb.part_ml && ksplit > 1 && RPW == 2 && Mb > 1 && N % 32 == 0 && Kb > 256 && Kb <= 768 &&
+    // 9..16 rows (round 6; RPW = 4 callers): the same -- 16 rows x 640 x 4 B x 6 = 246 KB of partials per 16-column block on 160 CUs
+    // became grid (40, 2, 4) = 320 blocks of 61 + 41 KB: 8.18 us per launch at 16 rows before (the reference's batch_size)
+    if (EPI == EPI_RESID_F32 && cb.part_ml && ksplit > 1 && (RPW == 2 || RPW == 4) && Mb > 1 && N % 32 == 0 && Kb > 256 && Kb <= 768 &&
         (g_comb_rowgroups < 0 ? !cw_sw::cw_switches().comb_no_rowgroups : g_comb_rowgroups != 0)) {
         int G = 256 / ((N / 32) * ksplit);
         G = G < 1 ? 1 : (G > Mb ? Mb : G);
+        // 13..16 rows: three groups of <= 6 rows, two rows per wave (240 blocks, one per CU) rather than four groups of four
+        // (320 blocks: 64 CUs would take two); CW_COMB_G4=1 keeps the four groups (A/B)
+        if (RPW == 4 && Mb > 12 && (Mb + G - 1) / G <= 8 && !cw_sw::cw_switches().comb_g4) {
+            hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, 2, true, true, 2, 3, 2>), dim3(N / 32, ksplit, G), dim3(256), lds + 4 * 4 * 64 * 4, st,
+                               x, Mb, K, Kb, (const bf16_t*)W, N, ln_g, ln_b, ep, cb, m_base, wpk);
+            return;
+        }
         while (G > 1 && (Mb + G - 1) / G > 4) ++G;             // one row per wave (RPW = 1): at most four rows per group
         if ((Mb + G - 1) / G <= 4) {
             hipLaunchKernelGGL((gemv2_bf16_kernel<EPI_RESID_F32, 1, true, true, 2, 3, 2>), dim3(N / 32, ksplit, G), dim3(256), lds + 4 * 4 * 64 * 4, st,

@@ -55,6 +55,7 @@ Switches read_switches() {
     s.no_gemv_loop = flag("CW_NO_GEMV_LOOP");
     s.comb_nt2 = flag("CW_COMB_NT2");
     s.comb_no_rowgroups = flag("CW_COMB_NO_ROWGROUPS");
+    s.comb_g4 = flag("CW_COMB_G4");
     s.mt_no_prea = flag("CW_MT_NO_PREA");
     s.gemv_loop_cap = num("CW_GEMV_LOOP_CAP", 512);
     s.fc2_ksplit = num("CW_FC2_KSPLIT", 0);

@@ -16,7 +16,7 @@ struct Switches {
     bool attn_v1, anc_attn_v1, cross_per_row, cross_valu, cross_no_tr, cross8_valu, cross_mfma1;
     int cross_lds_pad, cross8_nsb, dl_depth, dl_kvwait, mlp_chain_delay, qkv_self_dbg;
     // GEMM / GEMV launchers
-    bool no_glds, no_gemm256, no_gemm_pp, no_gemm_8ph, gemm_w128, no_gemv_loop, comb_nt2, comb_no_rowgroups, mt_no_prea;
+    bool no_glds, no_gemm256, no_gemm_pp, no_gemm_8ph, gemm_w128, no_gemv_loop, comb_nt2, comb_no_rowgroups, mt_no_prea, comb_g4;
     int gemv_loop_cap, fc2_ksplit, mt_variant, own_nt;
     // sampling, mel
     bool beam_topk_1block, mel_valu;

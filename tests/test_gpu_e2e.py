@@ -1351,7 +1351,7 @@ def test_row_groups_and_tile_pairs_of_the_33_to_64_row_gemvs_are_bit_identical(r
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("rows", [2, 5, 8])
+@pytest.mark.parametrize("rows", [2, 5, 8, 11, 16])
 def test_combining_out_projection_in_row_groups_is_bit_identical(dt, rows):
     """The cross-attention out-projection of <= 8 rows (gemm.hip: gemv2_bf16_kernel<.., COMBINE>: combines the six key-split
     partials, TF modeling_whisper.py:286-300 + 496-503) as grid (N / 32, K slices, row groups) -- 240 blocks of 87 KB instead
