@@ -1121,7 +1121,7 @@ def test_longform_600s_at_bench_geometry_vs_transformers(dtype):
     transformers.pipeline(chunk_length_s=30, batch_size=4) on the CPU (tests/golden/gen_golden_bench2.py longform: 30 chunks, 5 s
     strides, 29 seams merged by _decode_asr) and through the drop-in pipeline with the same arguments.  f32 engine: word for
     word; 16-bit engines (free-running over 30 chunks; f16 is the reference's own GPU dtype, REF/transcribe.py:10): >= 98.5 % of
-    the reference words reproduced within one frame (measured: bf16 1104, f16 1100 of 1113; gpurun_out/parity_longform_*.json), measured by the longest common word subsequence so
+    the reference words reproduced within one frame (measured, round 6: bf16 1104 of 1113, f16 1113 of 1113 with identical text; gpurun_out/parity_longform_*.json), measured by the longest common word subsequence so
     that a single divergent chunk cannot shift everything after it.  Why not 100 %: profiles/r04_longform_divergence.txt lists
     every decoder row that parts from the reference with the f32 engine's logit margin at that token -- 0.0009-0.039 on a logit
     range of 17, inside the 16-bit engines' own rounding noise (rms 0.011 / 0.003): ties, broken differently."""
