@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-PMC_FILE = "r05_pmc_traffic_B8.json"     # latest committed PMC pass (tools/ab/run_gpu_pmc.sh + profiles/summarize_pmc.py)
+PMC_FILE = "r06_pmc_traffic_B8.json"     # latest committed PMC pass (tools/ab/run_gpu_pmc.sh + profiles/summarize_pmc.py)
 
 
 def parse():
