@@ -883,6 +883,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
     const T* Kh = (const T*)p.K + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
     const T* Vh = (const T*)p.V + (((size_t)bk * p.H + h) * p.n_keys + k_lo) * 64 + sub * 8;
     constexpr int G = CROSS_THREADS / 8;                       // 64 key groups
+
     // FUSED: every wave finishes the query itself -- lane c takes column c of the head: two 8-byte loads of the per-block
     // LayerNorm partial sums the producing GEMV left behind (decfuse.hip, StackSeg::pstats) and four 4-byte loads (256 B per
     // wave instruction: a quarter of the address-unit time of a 16 B-per-lane load), a wave-local reduction, and a trip
@@ -905,6 +906,13 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
 #pragma unroll
     for (int u = 0; u < 4; ++u) vr[u].ld(Vh + (size_t)min(grp + u * G, nk - 1) * 64);
     if (FUSED) __builtin_amdgcn_sched_barrier(0);              // every load is out before the first wait (hipcc otherwise holds two V loads back)
+    // block-uniform scalars of the alignment capture, requested HERE -- behind the K/V requests, under their flight: left at their uses
+    // hipcc emits `s_load_dword` + `s_waitcnt lgkmcnt(0)` behind the first barrier and inside the V pass (scalar-cache round trips on
+    // the block's critical path); in front of the K/V requests they would delay the stream by two dependent round trips
+    const int slot = p.align_out ? p.align_slot[h] : -1;
+    int apos[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) apos[q] = (slot >= 0) ? p.pos[b0 + q] : 0;
     float qv[NQ][8];
     if (FUSED) {
         const float inv_d = 1.0f / (float)(p.H * 64);
@@ -955,7 +963,6 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
         mx[q] = m;
     }
 
-    const int slot = p.align_out ? p.align_slot[h] : -1;
     float acc[NQ][8];
     float lsum[NQ];
 #pragma unroll
@@ -975,7 +982,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
             if (sub == 0 && k < nk) {
                 lsum[q] += pk;
                 if (slot >= 0) {                               // un-normalised; align_normalize_kernel finishes the row
-                    const size_t rowi = ((size_t)(b0 + q) * p.n_align + slot) * p.align_rows + p.pos[b0 + q];
+                    const size_t rowi = ((size_t)(b0 + q) * p.n_align + slot) * p.align_rows + apos[q];
                     p.align_out[rowi * p.n_keys + k_lo + k] = pk;
                 }
             }
@@ -1013,7 +1020,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_split_kernel(CrossSp
         float* ml = p.part_ml + (((size_t)(b0 + q) * p.H + h) * ATT_NS + sp) * 2;
         ml[0] = mx[q]; ml[1] = l;
         if (slot >= 0) {
-            const size_t rowi = ((size_t)(b0 + q) * p.n_align + slot) * p.align_rows + p.pos[b0 + q];
+            const size_t rowi = ((size_t)(b0 + q) * p.n_align + slot) * p.align_rows + apos[q];
             p.align_ml[(rowi * ATT_NS + sp) * 2] = mx[q]; p.align_ml[(rowi * ATT_NS + sp) * 2 + 1] = l;
         }
     }
