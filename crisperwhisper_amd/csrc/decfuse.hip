@@ -106,7 +106,10 @@ int cw_launch_fold_rowvec(const float* A, const float* s, float scale, const flo
 // ---------------------------------------------------------------------------------------------------
 #define SEG_PICK(field) (si == 0 ? p.seg[0].field : (si == 1 ? p.seg[1].field : p.seg[2].field))
 
-template <int RPW, int NSLOT, int PER_LANE, int NT>
+// UNI (round 6): every segment streams NT tiles per block from fragment-major weights -- the shape of every launch of the default
+// engine.  The weight requests then sit under no branch (`t < snt` and `wpk` are run-time values otherwise: hipcc wraps each tile's
+// loads in a block-uniform branch and must answer the first wait behind them with vmcnt(0)).  Same arithmetic.
+template <int RPW, int NSLOT, int PER_LANE, int NT, bool UNI = false>
 __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
     // 17..64 rows (round 5): blockIdx.y = group of 16 rows; a group is a 16-row launch of its own over the same weights (its
@@ -164,16 +167,17 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
     u32x4_t wq[NT][NSLOT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (t < snt) {                                           // block-uniform: a lighter segment streams fewer tiles
+        if (UNI || t < snt) {                                    // block-uniform: a lighter segment streams fewer tiles
             const int tl = tl0 + t < n_tiles ? tl0 + t : n_tiles - 1;
             const bf16_t* wrow = W + ((size_t)(tile0 + tl) * 16 + l15) * K + g * 8;
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 int step = wave + 4 * s;
                 step = step < steps ? step : steps - 1;
-                const u32x4_t* wp = p.wpk ? (const u32x4_t*)(W + ((((size_t)(tile0 + tl) * (K >> 5)) + step * 4) * 64 + lane) * 8)
-                                          : (const u32x4_t*)(wrow + step * 128);
-                const int sj = p.wpk ? 64 : 4;
+                const bool wpk = UNI || p.wpk;
+                const u32x4_t* wp = wpk ? (const u32x4_t*)(W + ((((size_t)(tile0 + tl) * (K >> 5)) + step * 4) * 64 + lane) * 8)
+                                        : (const u32x4_t*)(wrow + step * 128);
+                const int sj = wpk ? 64 : 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wq[t][s][j] = wp[j * sj];
             }
@@ -304,7 +308,12 @@ static int launch_stack_nt(StackParams& p, hipStream_t st) {
     const dim3 grid(blocks, (p.Mb + 15) / 16);                  // y: groups of 16 rows
     if (p.K <= 256) hipLaunchKernelGGL((gemv_stack_kernel<RPW, 1, 1, NT>), grid, dim3(256), lds, st, p);
     else if (p.K <= 768) hipLaunchKernelGGL((gemv_stack_kernel<RPW, 2, 3, NT>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((gemv_stack_kernel<RPW, 3, 5, NT>), grid, dim3(256), lds, st, p);
+    else {
+        bool uni = p.wpk != 0;
+        for (int s = 0; s < p.nseg; ++s) uni = uni && p.seg[s].nt == NT;
+        if (uni) hipLaunchKernelGGL((gemv_stack_kernel<RPW, 3, 5, NT, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gemv_stack_kernel<RPW, 3, 5, NT>), grid, dim3(256), lds, st, p);
+    }
     return CW_OK;
 }
 

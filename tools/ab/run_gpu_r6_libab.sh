@@ -1,4 +1,7 @@
-B="--steps 5 --warmup 2 --no-cpu-baseline --no-longform --no-config3"
+#!/bin/bash
+# same-box A/B of two builds of the library: the in-tree one ("old") against crisperwhisper_amd/libcw_new.so (make BUILD=build_new OUT=../libcw_new.so);
+# usage: run_gpu_r6_libab.sh [extra bench args]   (three alternations)
+B="--steps 5 --warmup 2 --no-cpu-baseline --no-longform --no-config3 $@"
 for i in 1 2 3; do
 for v in old new; do
   E="X=1"; [ $v = new ] && E="CW_LIB_PATH=$PWD/crisperwhisper_amd/libcw_new.so"
