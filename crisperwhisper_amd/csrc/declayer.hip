@@ -543,9 +543,11 @@ __global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
     const bf16_t* Vh = (const bf16_t*)p.sv + ((size_t)ib * H + ih) * cap * 64;
 
     float bias_v = 0.f;
-    float4 xv[2][PER_LANE];
+    int pos_m = 0;                                                   // cache row of tile row m = g * 4 + wave (waves 0..3): FIRST in the queue --
+    float4 xv[2][PER_LANE];                                          // vmcnt retires in order, and behind the history rows its wait would be vmcnt(0)
     dl_u32x4_t wq[NSLOT][4];
     if (wave < 4) {
+        pos_m = p.pos[min(g * 4 + wave, Mb - 1)];
         bias_v = p.bias ? p.bias[ncl] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -575,7 +577,12 @@ __global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
 #pragma unroll
     for (int u = 0; u < QS_PRE; ++u) vpre[u].ld(Vh + (size_t)min(grp + u * QS_GROUPS, cap - 1) * 64 + sub * 8);
     const int n_keys = p.pos[ib] + 1;
+    // (the position the give-up word needs, requested here with everything else: at its use it is a scalar round trip in front of wave
+    // 4's first poll.  The epilogue's cache row pos_m is requested at the head of the queue above: left at its use it was a dependent
+    // load + `s_waitcnt vmcnt(0)` in front of the granule stores, the hand-off every attention item waits for)
+    const int pos0 = p.pos[0];
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(pos_m));                                  // (pins the first use behind the fence: hipcc otherwise sign-extends it -- and waits for it -- in front of the history requests)
 
     // ---- tile: LayerNorm (gamma / beta folded into W / bias), rows -> 16 bit -> LDS, MFMA, cross-wave sum
     if (wave < 4) {
@@ -643,8 +650,8 @@ __global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
             } else {
                 const int hh = rc >> 6, dd = rc & 63;
                 bf16_t* base = (bf16_t*)(which == 1 ? p.sk : p.sv);
-                base[(((size_t)m * H + hh) * cap + p.pos[m]) * 64 + dd] = (bf16_t)h16;
-                if (!(l15 & 1)) dl_gran_st(p.gkv + ((size_t)(which - 1) * 16 + m) * (K >> 1) + (rc >> 1), tag, h16 | (other << 16));
+                if (!(l15 & 1)) dl_gran_st(p.gkv + ((size_t)(which - 1) * 16 + m) * (K >> 1) + (rc >> 1), tag, h16 | (other << 16));   // the hand-off first
+                base[(((size_t)m * H + hh) * cap + pos_m) * 64 + dd] = (bf16_t)h16;
             }
         }
     }
@@ -660,8 +667,8 @@ __global__ __launch_bounds__(QS_THREADS) void qkv_self_kernel(QkvSelfParams p) {
         // other and the first writer wins, so everything before that position is good and the engine resumes there on the
         // launch-per-stage kernels (engine.hip: decode_once).  Once it is set every later wait gives up after at most 256 polls
         // instead of DL_SPIN_LIMIT: those forwards are discarded anyway.
-        const int give_up_tag = p.pos[0] + 1;
-        const bool forced_fail = p.fail_pos >= 0 && p.pos[0] == p.fail_pos && p.layer == 0;   // test hook (cw_test_set_option "handoff_fail_pos")
+        const int give_up_tag = pos0 + 1;
+        const bool forced_fail = p.fail_pos >= 0 && pos0 == p.fail_pos && p.layer == 0;   // test hook (cw_test_set_option "handoff_fail_pos")
 #pragma unroll 1
         for (int spins = 0; !ready; ++spins) {
             if (forced_fail || spins > DL_SPIN_LIMIT || ((spins & 255) == 255 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
