@@ -1084,7 +1084,9 @@ int32_t cw_get_encoder_output(cw_ctx* c, float* out, int32_t nb) {
 // ------------------------------------------------------------------------------------------------
 static int gemv_ln(cw_ctx* c, int epi, const float* x, int Mb, int K, const void* W, int N, const float* g,
                    const float* b, const EpiParams& ep) {
-    if (c->bf16 || !g) return KD(c, cw_launch_gemv, c->bf16, epi, x, Mb, K, W, N, g, b, ep, c->st, nullptr, c->d_xfrag, c->bf16 && c->wpacked);
+    // (17..64 rows over row-major weights -- CW_NO_WPACK=1, or a geometry pack_decoder_weights does not take: no scratch, i.e. groups of
+    // 16 rows on the <= 16-row kernels; gemv_mt_kernel reads fragment-major weights only)
+    if (c->bf16 || !g) return KD(c, cw_launch_gemv, c->bf16, epi, x, Mb, K, W, N, g, b, ep, c->st, nullptr, (Mb <= 16 || c->wpacked) ? c->d_xfrag : nullptr, c->bf16 && c->wpacked);
     int r = KD(c, cw_launch_layernorm_f32, x, g, b, c->dxn, Mb, K, c->st);   // f32 parity mode: unfused LN
     if (r != CW_OK) return r;
     return KD(c, cw_launch_gemv, false, epi, c->dxn, Mb, K, W, N, nullptr, nullptr, ep, c->st);
@@ -1142,7 +1144,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, V = c->d.vocab_size;
     const int TGT = c->d.max_target_positions;
     // 17..64 rows (bf16): producers hand activations to the next GEMV already in MFMA fragment order (no prep launch)
-    const bool frag = c->bf16 && nb > 16;
+    const bool frag = c->bf16 && nb > 16 && c->wpacked;      // (row-major weights: groups of 16 rows on the <= 16-row kernels, see gemv_ln)
     // fused out-projection / cross-query stage (decfuse.hip): greedy rows of one MFMA half tile, 16-bit caches.  The residual
     // stream then alternates between two buffers: a layer reads x from `xin` and leaves x1, x2, x3 in `xalt`.
     // (e4m3 cache: the fp8 matrix-core kernel finishes the fused query too; its VALU fallback does not)
@@ -1154,7 +1156,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
     // (the rejected 17..64-row A/B variants of -DCW_EXPERIMENTS builds -- rows path, skinny GEMMs, full-key cross-attention -- keep their
     // own twelve / nine launches: they read c->dx and d_xfrag, which the fused stage's alternating buffers would leave stale)
     const bool ab17 = nb > 16 && (c->rows_ln_enabled || c->skinny_mode != 0);
-    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && !ab17 && (nb <= 16 || (c->fuse_rows && nb <= 64 && (!c->kv8 || c->fuse_rows8))) &&
+    const bool fuse = c->bf16 && c->fuse6_ready && c->fuse6_enabled && c->ln_folded && !ab17 && (nb <= 16 || frag) && (nb <= 16 || (c->fuse_rows && nb <= 64 && (!c->kv8 || c->fuse_rows8))) &&
                       // beam search (round 6): the hypotheses of an item share a cross-attention block that finishes their queries
                       // (attn_cross_mfma_kernel<.., FUSED>, 16-bit cache); CW_NO_FUSE_BEAM=1: the twelve launches
                       (c->beam_K == 0 || (c->fuse_beam && !c->kv8 && c->beam_K <= 16 && !c->fuse_mlp)) &&
@@ -1444,7 +1446,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             if (rows) {
                 STG(DST_OTHER, KD(c, cw_launch_rows_combine, c->d_part_o, nb, D, cb, c->d_xfrag2, c->st));
                 STG(DST_CROSS_O, rows_produce(L.wo_c, D, L.bo_c));
-            } else STG(DST_CROSS_O, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, c->d_xfrag, c->wpacked));
+            } else STG(DST_CROSS_O, KD(c, cw_launch_gemv, true, EPI_RESID_F32, c->d_part_o, nb, D, L.wo_c, D, nullptr, nullptr, ep, c->st, &cb, (nb <= 16 || frag) ? c->d_xfrag : nullptr, c->wpacked));
         } else {
             DecAttnParams p = dec_attn(c->dq, L.ck, L.cv, CW_N_CTX, CW_N_CTX, c->d_pos, c->dattn, nb, H);
             p.align_out = c->d.n_align > 0 ? c->d_align : nullptr; p.align_slot = c->d_align_slot + (size_t)l * H;

@@ -1672,19 +1672,21 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
         bias_v[c] = ep.bias ? ep.bias[nc[c]] : 0.f;
     }
 
+    // Fragment-major weights ONLY (round 6; the launchers refuse row-major ones and the engine then runs 17..64 rows as groups of 16 on
+    // gemv2_bf16_kernel).  With the layout a run-time flag hipcc unswitched the unrolled request loop on it slot by slot -- every group
+    // of four requests under its own pair of branches (ISA) -- and neither the flag by arithmetic nor one branch around the whole block
+    // was as fast as no flag: batch 64 4.229 -> 4.177 ms per token step, beam step 2.389 -> 2.337.  156 instantiations: no second copy.
+    (void)wpk;
     u32x4_t wq[NT][NSLOT][4];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
-        const bf16_t* wrow = W + (size_t)nc[c] * K + kbase + g * 8;
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
             int step = wave + 4 * s;
             step = step < steps ? step : steps - 1;               // clamped (unconditional) load, zeroed below
-            const u32x4_t* wp = wpk ? (const u32x4_t*)(W + ((((size_t)(nc[c] >> 4) * (K >> 5)) + (kbase >> 5) + step * 4) * 64 + g * 16 + (nc[c] & 15)) * 8)
-                                    : (const u32x4_t*)(wrow + step * 128);
-            const int sj = wpk ? 64 : 4;
+            const u32x4_t* wp = (const u32x4_t*)(W + ((((size_t)(nc[c] >> 4) * (K >> 5)) + (kbase >> 5) + step * 4) * 64 + g * 16 + (nc[c] & 15)) * 8);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wq[c][s][j] = wp[j * sj];
+            for (int j = 0; j < 4; ++j) wq[c][s][j] = wp[j * 64];
         }
     }
     f32x4_t acc[NT][MT];
@@ -2189,6 +2191,7 @@ template <int EPI>
 static int launch_gemv_large(const float* x, int Mb, int K, const void* W, int N, const float* ln_g, const float* ln_b,
                              const EpiParams& ep, hipStream_t st, const CombineParams* comb, void* scratch, int wpk) {
     if (K > 5120 || K % 128 != 0) return CW_ERR_INVALID;
+    if (!wpk) return CW_ERR_INVALID;                           // gemv_mt_kernel reads fragment-major weights only (see the kernel)
     bf16_t* xf = (bf16_t*)scratch;
     CombineParams cb{nullptr, 0, 0};
     if (comb) cb = *comb;
@@ -2250,7 +2253,7 @@ int cw_gemv_own_nt(int N) {
 }
 int cw_launch_gemv_own(const void* xf, int Mb, int K, const void* W, int N, const EpiParams& ep, const float* cvec, void* xf_out,
                        float* stats_out, hipStream_t st, bool wpacked) {
-    if (Mb < 17 || Mb > GV_MAXM || K % 128 || K > 1536 || N % 32 || N / 16 > 96 || !xf || !cvec || !xf_out || !stats_out) return CW_ERR_INVALID;
+    if (Mb < 17 || Mb > GV_MAXM || K % 128 || K > 1536 || N % 32 || N / 16 > 96 || !xf || !cvec || !xf_out || !stats_out || !wpacked) return CW_ERR_INVALID;
     if (!ep.outf || !ep.resid || ep.ldo != N || xf == xf_out) return CW_ERR_INVALID;
     const int steps = K / 128, wpk = wpacked ? 1 : 0;
     const MtExtra ex{cvec, (bf16_t*)xf_out, stats_out, nullptr, 0, nullptr};
@@ -2267,7 +2270,7 @@ int cw_launch_gemv_own(const void* xf, int Mb, int K, const void* W, int N, cons
 // LayerNorm is applied on the accumulator from the producer's partial sums (gemv_mt_kernel LNA); block shape of the 33..64-row GEMVs
 int cw_launch_gemv_lna(const void* xf, int Mb, int K, const void* W, int N, const EpiParams& ep, const float* stats_in, int n_stats,
                        const float* wsum, hipStream_t st, bool wpacked) {
-    if (Mb < 33 || Mb > GV_MAXM || K % 128 || K > 1536 || N % 32 || !xf || !stats_in || !wsum || n_stats < 1 || n_stats > 96 || !ep.out) return CW_ERR_INVALID;
+    if (Mb < 33 || Mb > GV_MAXM || K % 128 || K > 1536 || N % 32 || !xf || !stats_in || !wsum || n_stats < 1 || n_stats > 96 || !ep.out || !wpacked) return CW_ERR_INVALID;
     const int steps = K / 128, wpk = wpacked ? 1 : 0;
     const dim3 grid((unsigned)(N / 32), 1, 2);
     const MtExtra ex{nullptr, nullptr, nullptr, stats_in, n_stats, wsum};

@@ -1543,6 +1543,51 @@ def test_fused_decoder_stage_tracks_eight_launch_layer(rows, kv):
     assert (lf.argmax(-1) == le.argmax(-1)).mean() > 0.95
     assert np.abs(af - ae).max() < 2e-2
 
+@pytest.mark.parametrize("rows", [20, 40])
+def test_row_major_decoder_weights_above_16_rows_track_the_packed_path(rows):
+    """gemv_mt_kernel (17..64 decoder rows) reads fragment-major weights only since round 6 (a run-time layout flag cost 1.2-2.2 % per
+    step: hipcc unswitched the request loop on it).  A context whose decoder weights stay row-major (CW_NO_WPACK=1; geometries
+    pack_decoder_weights does not take) runs those rows as groups of 16 on the <= 16-row kernels, unfused.  Same model, same forced
+    tokens, large-v3 shapes on a 2 + 2-layer stack: logits within bf16 rounding of the default path, same argmax, alignment rows within
+    2e-2 (the two differ in where the 16-bit roundings fall, exactly like the fused stage against the eight-launch layer)."""
+    import os
+    g, v = syn.large_v3_geometry()
+    g.enc_layers = g.dec_layers = 2
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(2) for h in (0, 3, 7, 19)]
+    W = syn.random_weights(g, seed=9)
+    T = 10
+    clips = [syn.synth_audio(300 + i, 480000 - 15000 * (i % 12), ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
+    rng = np.random.default_rng(2)
+    ids = np.concatenate([[v.sot, v.lang_id("en"), v.transcribe], [v.timestamp_begin], rng.integers(300, 50000, T - 4)])
+    forced = np.full((rows, T), -1, np.int32); forced[:, 3:] = ids[3:]
+    prompt = np.tile(ids[None, :3], (rows, 1))
+    res = {}
+    for mode in ("packed", "row_major"):
+        if mode == "row_major":
+            os.environ["CW_NO_WPACK"] = "1"
+        try:
+            eng = Engine(spec, dtype="bf16", max_batch=rows)
+        finally:
+            os.environ.pop("CW_NO_WPACK", None)
+        try:
+            eng.load_state_dict(W)
+            eng.mel(clips)
+            eng.encode(list(range(rows)), [0] * rows, [3000] * rows)
+            cap = eng.capture_logits(rows, T)
+            eng.decode(prompt, max_length=T, forced=forced)
+            res[mode] = (cap[:T - 3].copy(), eng.alignment(rows, T - 1))
+            eng.stop_capture()
+        finally:
+            eng.close()
+    (lp, ap), (lr, ar) = res["packed"], res["row_major"]
+    assert np.isfinite(lr).all() and np.abs(lr).max() > 0
+    rel = np.abs(lp - lr).max() / np.abs(lr).max()
+    assert rel < 0.03, rel
+    assert (lp.argmax(-1) == lr.argmax(-1)).mean() > 0.95
+    assert np.abs(ap - ar).max() < 2e-2
+
+
 def test_fused_decoder_stage_on_rows_with_a_large_mean():
     """The fused out-projection / cross-query stage multiplies the UN-normalised residual row by W'q and lets the consumer
     apply the LayerNorm (csrc/decfuse.hip).  A row whose mean is far from zero (outlier channels, drifting residual streams:
