@@ -260,6 +260,8 @@ struct EpiParams {
     int d_model;          // columns per `which`
     const int* row_pos;   // EPI_QKV_CACHE: [batch] device array, cache row to write for each batch row
     int x16;              // decode GEMV: the activation rows are 16-bit (a producer's EPI_GELU output) instead of f32
+    int row_pos_pre;      // EPI_QKV_CACHE with row_pos == nullptr: the cache row, read by the kernel at entry (the decode GEMVs: a
+                          // dependent load + vmcnt(0) in the epilogue otherwise -- one L2 round trip per stored row tile)
 };
 
 // MFMA 16x16x32 A-operand fragment-major position of activation (row m, column k) of a [rows][K] matrix:
@@ -299,7 +301,8 @@ __device__ inline void epi_store1(const EpiParams& p, int m, int n, float acc) {
         } else {
             int h = r >> 6, dd = r & 63;
             T* base = (T*)(which == 1 ? p.out1 : p.out2);
-            Act<T>::st(base + (((size_t)m * p.H + h) * p.S_pad + p.row_pos[m]) * 64 + dd, v);
+            const int rpos = p.row_pos ? p.row_pos[m] : p.row_pos_pre;
+            Act<T>::st(base + (((size_t)m * p.H + h) * p.S_pad + rpos) * 64 + dd, v);
         }
     }
 }

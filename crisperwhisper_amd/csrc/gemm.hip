@@ -1201,6 +1201,9 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
     float bias_v[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias_v[t] = ep.bias ? ep.bias[ncl[t]] : 0.f;
+    // EPI_QKV_CACHE: the cache row of the batch row this thread stores (m = g * 4 + wave), requested at the head of the queue
+    int rpos_pre = 0;
+    if (EPI == EPI_QKV_CACHE) rpos_pre = ep.row_pos[m_base + min(g * 4 + wave, Mb - 1)];
 
     // activation rows -> registers
     constexpr int PER8 = (PER_LANE + 1) / 2;                  // X16: 8 elements per 16-byte load
@@ -1394,6 +1397,7 @@ __global__ __launch_bounds__(256) void gemv2_bf16_kernel(const float* __restrict
             } else {
                 EpiParams e2 = ep;
                 e2.bias = nullptr;                       // bias was prefetched at kernel entry
+                if (EPI == EPI_QKV_CACHE) { e2.row_pos = nullptr; e2.row_pos_pre = rpos_pre; }   // ... and so was the cache row
                 epi_store1<bf16_t, EPI>(e2, m_base + m, n, EPI == EPI_RESID_F32 ? resid_grid(v + bias_v[t]) : v + bias_v[t]);
             }
         }
@@ -1671,6 +1675,11 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
         nc[c] = n[c] < N ? n[c] : N - 1;
         bias_v[c] = ep.bias ? ep.bias[nc[c]] : 0.f;
     }
+    // EPI_QKV_CACHE: the cache rows of the batch rows this thread stores (m = (t0 + t) * 16 + g * 4 + tid / 64), requested at the head
+    // of the queue -- the epilogue otherwise fetches each one behind a vmcnt(0): MT serial L2 round trips (found in the ISA, round 6)
+    int rpos_pre[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) rpos_pre[t] = (EPI == EPI_QKV_CACHE) ? ep.row_pos[min((t0 + t) * 16 + g * 4 + (tid >> 6), Mb - 1)] : 0;
 
     // Fragment-major weights ONLY (round 6; the launchers refuse row-major ones and the engine then runs 17..64 rows as groups of 16 on
     // gemv2_bf16_kernel).  With the layout a run-time flag hipcc unswitched the unrolled request loop on it slot by slot -- every group
@@ -1802,6 +1811,7 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
                 } else {
                     EpiParams e2 = ep;
                     e2.bias = nullptr;
+                    if (EPI == EPI_QKV_CACHE) { e2.row_pos = nullptr; e2.row_pos_pre = rpos_pre[t]; }
                     epi_store1<bf16_t, EPI>(e2, m, n[c], EPI == EPI_RESID_F32 ? resid_grid(v + bias_v[c]) : v + bias_v[c]);
                 }
             }
@@ -2215,7 +2225,9 @@ template <int EPI>
 static int launch_gemv_epi(bool bf16, const float* x, int Mb, int K, const void* W, int N, const float* ln_g,
                            const float* ln_b, const EpiParams& ep, hipStream_t st, const CombineParams* comb,
                            void* scratch, int wpk) {
-    if (bf16 && Mb > 16 && scratch) return launch_gemv_large<EPI>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
+    // (row-major weights: gemv_mt_kernel reads fragment-major ones only -- the groups of 16 rows below)
+    if (bf16 && Mb > 16 && scratch && wpk) return launch_gemv_large<EPI>(x, Mb, K, W, N, ln_g, ln_b, ep, st, comb, scratch, wpk);
+    if (bf16 && Mb > 16 && !x) return CW_ERR_INVALID;          // fragment-major activations have no other consumer
     if (comb && !(bf16 && gemv2_ok(EPI, Mb, K, ln_g, ep) && EPI == EPI_RESID_F32)) return CW_ERR_INVALID;
     if (bf16) {
         if (gemv2_ok(EPI, Mb, K, ln_g, ep)) {
