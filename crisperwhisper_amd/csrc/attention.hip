@@ -1805,6 +1805,11 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
         vf[s][0] = *(const uint4*)Vf; vf[s][1] = *(const uint4*)(Vf + 1024);
     }
     const float ks = p.kv_scale[bh * 2], vs = p.kv_scale[bh * 2 + 1];
+    // block-uniform values of the alignment capture, requested HERE with everything else (round 6): at their use hipcc fetches each by a
+    // uniform-address vector load + `s_waitcnt vmcnt(0)` + v_readfirstlane right behind the first barrier -- in EVERY block (align_out
+    // is set whenever the engine decodes): one L2 round trip on the block's critical path, and the wait drains the V rows as well
+    const int slot = p.align_out ? p.align_slot[h] : -1;
+    const int apos = (p.align_out && p.pos) ? p.pos[b] : 0;
     // the query fragments are the same for all eight waves: wave 0 loads the row (16 B-per-lane loads cost the CU's address
     // unit 16 clocks each whatever they fetch), scales it to the e4m3 range and splits it; the others pick the 16 bytes up from
     // LDS behind a barrier that their own K / V loads are in flight across
@@ -1899,8 +1904,7 @@ __global__ __launch_bounds__(CROSS_THREADS) void attn_cross_mfma8_kernel(CrossSp
         mx[s] = m;
     }
 
-    const int slot = p.align_out ? p.align_slot[h] : -1;
-    const size_t rowi = slot >= 0 ? ((size_t)b * p.n_align + slot) * p.align_rows + p.pos[b] : 0;
+    const size_t rowi = slot >= 0 ? ((size_t)b * p.n_align + slot) * p.align_rows + apos : 0;
     float* spw = s_p + wave * 32;
 #pragma unroll
     for (int s = 0; s < NSB; ++s) {
