@@ -1675,6 +1675,19 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
         nc[c] = n[c] < N ? n[c] : N - 1;
         bias_v[c] = ep.bias ? ep.bias[nc[c]] : 0.f;
     }
+    // operands of the OWN / LNA epilogues, requested at the head of the queue (left at their uses they are dependent loads behind the
+    // MFMA loop: an L2 round trip on the tail of every block): the residual elements and row centres this thread updates, the row sums
+    // of the folded weights of its columns
+    float resid_v[NT][MT], cvec_v[MT], wsum_v[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) wsum_v[c] = (MODE2 == 2) ? ex.wsum[nc[c]] : 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int mr = min((t0 + t) * 16 + g * 4 + (tid >> 6), Mb - 1);
+        cvec_v[t] = (MODE2 == 1) ? ex.cvec[mr] : 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) resid_v[c][t] = (MODE2 == 1) ? ep.resid[(size_t)mr * ep.ldo + nc[c]] : 0.f;
+    }
     // EPI_QKV_CACHE: the cache rows of the batch rows this thread stores (m = (t0 + t) * 16 + g * 4 + tid / 64), requested at the head
     // of the queue -- the epilogue otherwise fetches each one behind a vmcnt(0): MT serial L2 round trips (found in the ISA, round 6)
     int rpos_pre[MT];
@@ -1780,9 +1793,6 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
         __syncthreads();
     }
     const int r = tid >> 6;
-    float wsum_v[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) wsum_v[c] = (MODE2 == 2) ? ex.wsum[nc[c]] : 0.f;
     static_assert(MODE2 != 2 || MT == 1 || MT == 2 || MT == 4, "LNA: the rows of a block must divide its 256 threads");
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -1803,9 +1813,9 @@ __global__ __launch_bounds__(256) void gemv_mt_kernel(const bf16_t* __restrict__
                     atomicAdd(ep.outf + (size_t)m * ep.ldo + n[c], resid_grid(v + (blockIdx.y == 0 ? bias_v[c] : 0.f)));
                 } else if (MODE2 == 1) {
                     const size_t o = (size_t)m * ep.ldo + n[c];
-                    const float xn = ep.resid[o] + resid_grid(v + bias_v[c]);
+                    const float xn = resid_v[c][t] + resid_grid(v + bias_v[c]);
                     ep.outf[o] = xn;
-                    const float y = xn - ex.cvec[m];
+                    const float y = xn - cvec_v[t];
                     ex.xf_out[frag_index(m, n[c], ep.ldo)] = f32_to_bf16(y);
                     s1 += y; s2 += y * y;
                 } else {
