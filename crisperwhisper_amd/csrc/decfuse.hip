@@ -150,6 +150,20 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
         bias_v[t] = bias ? bias[ncl] : 0.f;
         wsum_v[t] = wsum ? wsum[ncl] : 0.f;
     }
+    // the residual elements the x1 segment's epilogue adds to (epi == 1), requested at the head of the queue: at their use they are a
+    // dependent load behind the MFMA loop -- an L2 round trip on the tail of the blocks that end the launch.  Unconditional (other
+    // segments read an element of their own input instead: a load under a branch would make every later counted wait conservative)
+    float resid_pre[NT];
+    {
+        const float* rsd = SEG_PICK(resid);
+        const int ldo_ = n_tiles * 16, mr = min(g * 4 + (tid >> 6), Mb - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int nl = nloc[t] >= 0 ? nloc[t] : 0;
+            const float* rp = rsd ? rsd + (size_t)(m0 + mr) * ldo_ + nl : x;
+            resid_pre[t] = *rp;
+        }
+    }
     // activation rows -> registers
     float4 xv[RPW][PER_LANE];
 #pragma unroll
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256) void gemv_stack_kernel(StackParams p) {
             } else if (epi == 2) {
                 atomicAdd(out + o, v + bias_v[t] + back);
             } else {
-                const float rv = resid[o] + resid_grid(v + bias_v[t]);
+                const float rv = resid_pre[t] + resid_grid(v + bias_v[t]);
                 out[o] = rv;
                 if (out2) out2[o] = rv;
                 ps1 += rv; ps2 += rv * rv;
