@@ -448,3 +448,31 @@ def test_pipeline_default_num_beams_wins_over_the_checkpoints_generation_config(
             model.generation_config.num_beams = nb
         pipe = H.build_pipeline(model, H.build_tokenizer(v), H.build_feature_extractor(g), batch_size=1)
         assert pipe.generation_config.num_beams == P.DEFAULT_NUM_BEAMS == 5, (nb, pipe.generation_config.num_beams)
+
+
+def test_bench_longform_parity_measure_and_goldens_describe_the_bench_workload():
+    """bench.py's configs[2] comparison (`longform.parity` of the driver line): longest common word subsequence against the committed
+    transformers output, words of it within 20 ms, identical text -- on the golden itself (word for word), with one word replaced (a
+    divergence must not shift what follows it) and with a timestamp moved by 40 ms; and the goldens the bench legs load describe the
+    workloads they are compared with (same recording, aligned weights, token count; 8 beam clips at 5 beams x 128 tokens)."""
+    import copy
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "e2e_bench_longform_golden.json")))
+    assert gold["audio"] == {"seed": 1000, "kind": "mixed", "secs": 600} and gold["weights"] == "aligned"
+    same = bench.longform_parity({"text": gold["text"], "chunks": gold["chunks"]}, gold)
+    n = len(gold["chunks"])
+    assert same["word_for_word"] and same["ok"] and same["words_within_20ms"] == n == same["reference_words"]
+    other = copy.deepcopy(gold["chunks"])
+    other[100]["text"] = other[100]["text"] + "x"                       # one divergent word
+    other[500]["timestamp"] = [other[500]["timestamp"][0] + 0.04, other[500]["timestamp"][1]]
+    r = bench.longform_parity({"text": gold["text"].replace(gold["chunks"][100]["text"], other[100]["text"], 1), "chunks": other}, gold)
+    assert r["words_in_common_order"] == n - 1 and r["words_within_20ms"] == n - 2 and not r["word_for_word"] and r["ok"]
+    short = bench.longform_parity({"text": "", "chunks": other[: n // 2]}, gold)
+    assert not short["ok"]
+    beam = bench.load_beam_goldens(128, "aligned", 5)
+    assert sorted(beam) == list(range(8)) and all(len(c["chunks"]) > 50 for c in beam.values())
+    assert bench.load_beam_goldens(64, "aligned", 5) == {} and bench.load_beam_goldens(128, "aligned", 3) == {}
+    greedy = bench.load_bench_goldens(128, "aligned")
+    assert sorted(greedy) == list(range(64))
