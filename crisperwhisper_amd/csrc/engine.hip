@@ -2354,6 +2354,10 @@ int32_t cw_set_option(cw_ctx* c, const char* name, int32_t value) {
     if ((!strcmp(name, "rows_ln") || !strcmp(name, "skinny")) && value != 0)
         return fail(c, CW_ERR_INVALID, "option %s selects a measured-and-rejected kernel variant that is not in this build (make EXTRA=-DCW_EXPERIMENTS)", name);
 #endif
+    if (!strcmp(name, "test_epoch_forwards")) {   // test hook: pretend this many decoder forwards have run since the granule epoch last started (epoch_hygiene)
+        c->forwards_since_reset = (long long)value;
+        return CW_OK;
+    }
     if (!strcmp(name, "handoff_fail_pos")) {   // test hook: the in-launch hand-off of qkv_self_kernel gives up at this decoder position (-1: never)
         c->fail_pos = value;
         for (auto& ge : c->step_graph) if (ge) { hipGraphExecDestroy(ge); ge = nullptr; }   // kernel arguments are baked into the graphs

@@ -1497,6 +1497,39 @@ def test_lost_handoff_costs_a_step_not_a_call(min_new, fail_pos):
     assert int(max(la)) - 1 > fail_pos          # the disturbed position was inside the decoded range
 
 
+def test_granule_epoch_restart_is_invisible():
+    """The granule tag of qkv_self_kernel's hand-offs carries 26 bits of the device's forward counter; granules are never cleared, so
+    long before the tag can repeat (2^25 announced forwards) the entry points zero the granule buffers and restart the counter at 1
+    (engine.hip: epoch_hygiene).  The test hook `test_epoch_forwards` puts a context just below the threshold: the next decode call
+    performs the restart, the one after runs on the restarted counter -- tokens, alignment rows and timestamps of both equal those of
+    a fresh context bit for bit, no hand-off gives up."""
+    g, v = syn.large_v3_geometry()
+    g.enc_layers, g.dec_layers = 1, 3
+    spec = syn.model_spec(g, v, n_align=15)
+    spec.alignment_heads = [[l, h] for l in range(3) for h in (0, 3, 7, 11, 19)]
+    W = syn.random_weights(g, seed=35)
+    rows, T = 6, 120
+    clips = [syn.synth_audio(950 + i, 480000 - 25000 * i, ("noise", "chirp", "mixed")[i % 3]) for i in range(rows)]
+    prompt = np.tile(np.array([[v.sot, v.lang_id("en"), v.transcribe, v.timestamp_begin]], np.int32), (rows, 1))
+    eng = Engine(spec, dtype="bf16", max_batch=rows)
+    try:
+        eng.load_state_dict(W)
+        eng.mel(clips)
+        eng.encode(list(range(rows)), [0] * rows, [3000] * rows)
+        outs = []
+        for call in range(3):
+            if call == 1:
+                eng._chk(eng.lib.cw_set_option(eng.ctx, b"test_epoch_forwards", (1 << 25) - 10))
+            seqs, lens, _ = eng.decode(prompt, max_length=T, min_new_tokens=T - 4)
+            L = int(max(lens)) - 1
+            outs.append((seqs.copy(), eng.alignment(rows, L).copy(), eng.token_timestamps(rows, L, 4, [3000] * rows).copy()))
+        assert int(eng.lib.cw_handoff_fallbacks(eng.ctx)) == 0
+        for k in (1, 2):
+            assert np.array_equal(outs[0][0], outs[k][0]) and np.array_equal(outs[0][1], outs[k][1]) and np.array_equal(outs[0][2], outs[k][2])
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("kv", [None, "fp8"])
 @pytest.mark.parametrize("rows", [3, 8, 12, 17, 40, 64])
 def test_fused_decoder_stage_tracks_eight_launch_layer(rows, kv):
