@@ -641,7 +641,12 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_anc_kernel(DecAttnPar
 // entries of a lane's two keys are fetched first (clamped to valid cache rows: entries beyond the current position are
 // stale), then K AND V rows, nothing depends on the device-side position -- and only longer histories or alignment capture
 // fall back to attn_decode_anc above (serial table lookups, scores through LDS: 9.6 us per layer at 8 items x 5 hypotheses).
-template <typename T, bool ANC>
+// PRE (round 6): 8-lane-group keys requested up front.  2 = 128 keys, the whole history of a typical decode; 1 = 64 keys, chosen by the
+// host while every row's history is at most 64 keys long (it knows the step index): at 17..64 rows the launch is bound by the bytes of
+// the 128 unconditionally requested rows per (row, head), half of them stale in the first 64 steps of a generate call.  Keys beyond
+// PRE x 64 take the on-demand path below either way, so a wrong hint costs time, not correctness; for <= 64 keys the PRE = 2 form
+// masks its second key per group out, i.e. both forms do the same arithmetic in the same order (bit-identical).
+template <typename T, bool ANC, int PRE = DEC_PRE>
 __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams p) {
     extern __shared__ float dsm[];          // scores [cap rounded] | red [DEC_GROUPS][64] | scratch [64]
     const int h = blockIdx.x, b = blockIdx.y;
@@ -656,43 +661,43 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
     const T* Vh = (const T*)p.V + ((size_t)bk * p.H + h) * p.cap * 64;
     float qv[8];
     Row8<float>::ld(p.q + (size_t)b * p.H * 64 + h * 64 + sub * 8, qv);
-    int arow[DEC_PRE];
+    int arow[PRE];
     if (ANC) {
 #pragma unroll
-        for (int u = 0; u < DEC_PRE; ++u) arow[u] = p.anc[(size_t)b * p.cap + min(grp + u * DEC_GROUPS, p.cap - 1)];
+        for (int u = 0; u < PRE; ++u) arow[u] = p.anc[(size_t)b * p.cap + min(grp + u * DEC_GROUPS, p.cap - 1)];
     }
-    // The first DEC_PRE keys of every 8-lane group (128 keys in all: the whole self-attention history of a typical
+    // The first PRE keys of every 8-lane group (128 keys in all: the whole self-attention history of a typical
     // decode) are fetched before anything else, K AND V, with the row clamped to the cache capacity instead of to
     // n_keys: the loads then depend neither on the device-side position nor on the softmax, which takes two memory
     // round trips (pos -> K rows, softmax -> V rows) out of this latency-bound kernel.  Rows >= n_keys hold stale but
     // addressable data and are masked out below.
-    Raw8<T> kpre[DEC_PRE], vpre[DEC_PRE];
+    Raw8<T> kpre[PRE], vpre[PRE];
     if (ANC) {
 #pragma unroll
-        for (int u = 0; u < DEC_PRE; ++u) {
+        for (int u = 0; u < PRE; ++u) {
             const size_t ro = (((size_t)min(max(arow[u], 0), p.B - 1) * p.H + h) * p.cap + min(grp + u * DEC_GROUPS, p.cap - 1)) * 64 + sub * 8;
             kpre[u].ld((const T*)p.K + ro);
             vpre[u].ld((const T*)p.V + ro);
         }
     } else {
 #pragma unroll
-        for (int u = 0; u < DEC_PRE; ++u) kpre[u].ld(Kh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
+        for (int u = 0; u < PRE; ++u) kpre[u].ld(Kh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
 #pragma unroll
-        for (int u = 0; u < DEC_PRE; ++u) vpre[u].ld(Vh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
+        for (int u = 0; u < PRE; ++u) vpre[u].ld(Vh + (size_t)min(grp + u * DEC_GROUPS, p.cap - 1) * 64 + sub * 8);
     }
     const int n_keys = p.pos ? (p.n_keys > 0 ? p.n_keys : p.pos[b] + 1) : p.n_keys;
-    if (ANC && (n_keys > DEC_PRE * DEC_GROUPS || p.align_out)) { attn_decode_anc<T>(p, h, b); return; }
+    if (ANC && (n_keys > PRE * DEC_GROUPS || p.align_out)) { attn_decode_anc<T>(p, h, b); return; }
 
-    if (n_keys <= DEC_PRE * DEC_GROUPS && !p.align_out) {
+    if (n_keys <= PRE * DEC_GROUPS && !p.align_out) {
         // Short history (<= 128 keys: every key row is already in registers): scores stay in registers, the only block-wide
         // exchanges are the 8 wave maxima and the final 8 x 64 partial outputs -- 2 barriers instead of 7 and no 64-deep
         // serial LDS reduction (same structure as attn_cross_split_kernel).
         float* s_max = scratch;               // [8]
         float* red8 = red;                    // [8][64] + [8] sums behind it
         const int lane = tid & 63, wave = tid >> 6;
-        float d[DEC_PRE], mxl = -INFINITY;
+        float d[PRE], mxl = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < DEC_PRE; ++u) {
+        for (int u = 0; u < PRE; ++u) {
             float kv[8];
             kpre[u].cvt(kv);
             float t = 0.f;
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
         float acc[8] = {};
         float lsum = 0.f;
 #pragma unroll
-        for (int u = 0; u < DEC_PRE; ++u) {
+        for (int u = 0; u < PRE; ++u) {
             if (grp + u * DEC_GROUPS < n_keys) {          // stale rows may hold non-finite bit patterns: skip, not scale
                 const float pk = expf(d[u] - mxl);
                 if (sub == 0) lsum += pk;
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
 
     float mx = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < DEC_PRE; ++u) {
+    for (int u = 0; u < PRE; ++u) {
         const int k = grp + u * DEC_GROUPS;
         float kv[8];
         kpre[u].cvt(kv);
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
         }
     }
     // remaining keys: 4 key rows per thread in flight (unrolled by 4 x DEC_GROUPS keys)
-    for (int k0 = grp + DEC_PRE * DEC_GROUPS; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
+    for (int k0 = grp + PRE * DEC_GROUPS; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
         float kv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {   // unconditional loads (clamped row): no exec-masked blocks, all in flight
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
 
     float acc[8] = {};
 #pragma unroll
-    for (int u = 0; u < DEC_PRE; ++u) {
+    for (int u = 0; u < PRE; ++u) {
         const int k = grp + u * DEC_GROUPS;
         float vv[8];
         vpre[u].cvt(vv);
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(DEC_THREADS) void attn_decode_kernel(DecAttnParams 
             for (int e = 0; e < 8; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
         }
     }
-    for (int k0 = grp + DEC_PRE * DEC_GROUPS; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
+    for (int k0 = grp + PRE * DEC_GROUPS; k0 < n_keys; k0 += 4 * DEC_GROUPS) {
         float vv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -840,9 +845,12 @@ int cw_launch_attn_decode(bool bf16, const DecAttnParams& p, hipStream_t st) {
         if (bf16) hipLaunchKernelGGL((attn_decode_anc_kernel<bf16_t>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
         else hipLaunchKernelGGL((attn_decode_anc_kernel<float>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
     } else if (p.anc) {
-        if (bf16) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, true>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+        if (bf16 && p.short_hist && !p.align_out) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, true, 1>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+        else if (bf16) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, true>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
         else hipLaunchKernelGGL((attn_decode_kernel<float, true>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
-    } else if (bf16)
+    } else if (bf16 && p.short_hist && !p.align_out && p.pos && p.n_keys <= 0)
+        hipLaunchKernelGGL((attn_decode_kernel<bf16_t, false, 1>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
+    else if (bf16)
         hipLaunchKernelGGL((attn_decode_kernel<bf16_t, false>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);
     else
         hipLaunchKernelGGL((attn_decode_kernel<float, false>), dim3(p.H, p.B), dim3(DEC_THREADS), lds, st, p);

@@ -158,7 +158,9 @@ struct cw_ctx {
     bool align_unnormalized = false;
     int* h_nunf = nullptr;  // pinned
     int *d_pos = nullptr, *d_cfg = nullptr;   // per-row decoder input position; [n_prompt, min_new, max_length, use_forced]
-    hipGraphExec_t step_graph[65] = {};       // captured decode step (layers + logits + sampling) per batch size
+    hipGraphExec_t step_graph[130] = {};      // captured decode step (layers + logits + sampling) per batch size; + 65: the short-history form (hist_short)
+    bool hist_short = false;                  // every row attends over <= 64 self-attention keys in the forward being launched (host knows the position)
+    bool short_hist_enabled = true;           // CW_NO_SHORT_HIST=1: always request 128 history rows (A/B)
     bool use_graph = true;
     bool fuse_rows = true;                    // fused out-projection / cross-query stage at 17..64 greedy rows (CW_NO_FUSE_ROWS=1: off)
     bool fuse_beam = true;                    // ... and under beam search over the 16-bit cache (round 6; CW_NO_FUSE_BEAM=1: the twelve launches)
@@ -403,6 +405,7 @@ static int create_impl(cw_ctx* c) {
     c->fuse_rows8 = !sw.no_fuse_rows8;
     c->fuse_beam = !sw.no_fuse_beam;
     c->own_cols = !sw.no_own_cols;
+    c->short_hist_enabled = !sw.no_short_hist;
     c->fold_enabled = !sw.no_ln_fold;
     c->fuse6_enabled = !sw.no_fuse6;
     c->rows_ln_enabled = sw.rows_ln;
@@ -1270,6 +1273,7 @@ static int decode_step(cw_ctx* c, int nb, bool want_logits) {
             DecAttnParams p = dec_attn(c->dq, L.sk, L.sv, TGT, 0, c->d_pos, c->dattn, nb, H);
             if (frag && !fuse) p.out_frag = (unsigned short*)c->d_xfrag2;   // the fused stage reads the f32 rows
             if (c->beam_K > 0) p.anc = c->d_anc;
+            p.short_hist = (c->hist_short && c->short_hist_enabled && nb > 8) ? 1 : 0;   // bytes matter from 9 rows up (<= 8: latency-bound, qkv_self)
             STG(DST_SELF_ATTN, KD(c, cw_launch_attn_decode, c->bf16, p, c->st));
         }
         }
@@ -1509,7 +1513,8 @@ static int run_step(cw_ctx* c, int nb) {
         CWCHK(c, decode_step(c, nb, true));
         return launch_sample(c, nb, false);
     }
-    if (!c->step_graph[nb]) {
+    const int gi = nb + ((c->hist_short && c->short_hist_enabled && nb > 8) ? 65 : 0);
+    if (!c->step_graph[gi]) {
         hipGraph_t g = nullptr;
         HIPCHK(c, hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
         int r = decode_step(c, nb, true);
@@ -1517,11 +1522,11 @@ static int run_step(cw_ctx* c, int nb) {
         hipError_t e = hipStreamEndCapture(c->st, &g);
         if (r != CW_OK) { if (g) hipGraphDestroy(g); return r; }
         if (e != hipSuccess) return fail(c, CW_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-        e = hipGraphInstantiate(&c->step_graph[nb], g, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(&c->step_graph[gi], g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
         if (e != hipSuccess) return fail(c, CW_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
     }
-    HIPCHK(c, hipGraphLaunch(c->step_graph[nb], c->st));
+    HIPCHK(c, hipGraphLaunch(c->step_graph[gi], c->st));
     return CW_OK;
 }
 
@@ -1619,6 +1624,7 @@ static int decode_once(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_p
 
     // prompt positions 0 .. n_prompt-2: forward only (their alignment rows are recorded, :254-256)
     for (int pos = 0; pos + 1 < n_prompt; ++pos) {
+        c->hist_short = pos + 1 <= 64;
         CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, pos, nb, c->st, c->d_epoch));
         CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
         CWCHK(c, decode_step(c, nb, false));
@@ -1638,6 +1644,7 @@ static int decode_once(cw_ctx* c, int32_t nb, const int32_t* prompt, int32_t n_p
         int gave_up_word = 0;
         for (;;) {
             // forward at position t-1, logits, fused processors + argmax -> ids[t], x for position t, pos := t
+            c->hist_short = t <= 64;               // keys 0 .. t-1
             CWCHK(c, run_step(c, nb));
             if (c->logits_capture && step < c->logits_capture_steps)
                 HIPCHK(c, hipMemcpy2DAsync(c->logits_capture + (size_t)step * nb * V, (size_t)V * 4, c->dlogits, (size_t)c->Vpad * 4, (size_t)V * 4, nb, hipMemcpyDeviceToHost, c->st));
@@ -1756,6 +1763,7 @@ int32_t cw_no_speech_probs(cw_ctx* c, int32_t nb, int32_t sot_token, float* out)
     for (int attempt = 0;; ++attempt) {
         CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 0, nb, c->st, c->d_epoch));
         CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, 0, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, nb, D, c->st));
+        c->hist_short = false;
         CWCHK(c, decode_step(c, nb, true));
         KCHK(c);
         bool gave_up = false;
@@ -1859,6 +1867,7 @@ int32_t cw_beam_begin(cw_ctx* c, int32_t n_items, int32_t num_beams, const int32
     for (int pos = 0; pos + 1 < n_prompt; ++pos) {          // prompt positions: forward only
         CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, pos, rows, c->st));
         CWCHK(c, KD(c, cw_launch_embed, c->d_ids, TGT, pos, c->embed, c->bf16 ? 1 : 0, c->dec_pos, c->dx, rows, D, c->st));
+        c->hist_short = pos + 1 <= 64;
         CWCHK(c, decode_step(c, rows, false));
     }
     CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, n_prompt - 1, rows, c->st));
@@ -1876,6 +1885,7 @@ int32_t cw_beam_step(cw_ctx* c, int32_t n_cand, float* cand_logprob, int32_t* ca
     if (c->beam_pos + 1 >= c->beam_max_len) return fail(c, CW_ERR_STATE, "beam_step: sequence already has max_length=%d tokens", c->beam_max_len);
     const int rows = c->beam_items * c->beam_K;
     StageTimer tm(c, CW_STAGE_DECODE);
+    c->hist_short = c->beam_pos + 1 <= 64;   // keys 0 .. beam_pos
     CWCHK(c, decode_step(c, rows, true));
     SampleParams sp;
     memset(&sp, 0, sizeof(sp));
@@ -2887,6 +2897,7 @@ int32_t cw_time_decode_stage(cw_ctx* c, int32_t nb, int32_t stage, int32_t iters
     const int D = c->d.d_model, H = c->d.n_heads, F = c->d.ffn_dim, NL = c->d.dec_layers;
     // a hand-off that gave up while timing (shared GPU) must not send the next cw_decode to the fallback path: drain and clear
     struct Restore { cw_ctx* c; ~Restore() { c->stage_sel = -1; c->layer_sel = -1; (void)hipStreamSynchronize(c->st); (void)hipMemset(c->d_err, 0, 4); } } restore{c};
+    c->hist_short = false;                                       // position 64: 65 keys
     CWCHK(c, KD(c, cw_launch_set_pos, c->d_pos, 64, nb, c->st, c->d_epoch));
     // which launches does a layer have at this row count?  (nothing is launched: no stage has this index)
     c->stage_sel = CW_MAX_DEC_STAGES; c->layer_sel = 0;

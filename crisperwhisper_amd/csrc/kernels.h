@@ -73,6 +73,7 @@ struct DecAttnParams {
     int B, H;
     int kv_div;            // > 1: query rows b share cache row b / kv_div (beams of one audio item; cross-attention)
     const int* anc;        // non-null: [B][cap] cache row holding key k of query row b (beam-search self-attention)
+    int short_hist;        // host hint: every row's history is <= 64 keys (self-attention requests 64 rows per (row, head) up front, not 128)
 };
 
 // Cross-attention decode split over the 1500 keys (flash-decoding): ATT_NS blocks per (batch, head) write

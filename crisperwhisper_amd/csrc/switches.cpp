@@ -28,6 +28,7 @@ Switches read_switches() {
     s.no_fuse_rows8 = flag("CW_NO_FUSE_ROWS8");
     s.no_fuse_beam = flag("CW_NO_FUSE_BEAM");
     s.no_own_cols = flag("CW_NO_OWN_COLS");
+    s.no_short_hist = flag("CW_NO_SHORT_HIST");
     s.skinny = num("CW_SKINNY", 0);
     s.prefetch = num("CW_PREFETCH", 0);
     s.prefetch_wide = num("CW_PREFETCH_WIDE", 0);

@@ -10,7 +10,7 @@ namespace cw_sw {
 
 struct Switches {
     // engine (cw_create)
-    bool no_graph, no_ln_fold, no_fuse6, rows_ln, no_rows_hilo, no_stack_center, no_mid16, dtw_block, fuse_mlp, no_wpack, mlp_pair, mlp_pair_fence, declayer, no_qkv_self, mlp_chain, no_fuse_rows, no_fuse_rows8, no_fuse_beam, no_own_cols;
+    bool no_graph, no_ln_fold, no_fuse6, rows_ln, no_rows_hilo, no_stack_center, no_mid16, dtw_block, fuse_mlp, no_wpack, mlp_pair, mlp_pair_fence, declayer, no_qkv_self, mlp_chain, no_fuse_rows, no_fuse_rows8, no_fuse_beam, no_own_cols, no_short_hist;
     int skinny, prefetch, prefetch_wide, prefetch_what, stack_nt3, stack_nt5;
     // attention launchers
     bool attn_v1, anc_attn_v1, cross_per_row, cross_valu, cross_no_tr, cross8_valu, cross_mfma1;
